@@ -1,0 +1,99 @@
+"""Pin the CPU oracle (oracle/mxq_oracle.py) against golden vectors produced by the
+reference's own Python (tests/golden/make_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import mxq_oracle as O
+
+PTQ_KEYS = ("codes2", "sc2", "zero2", "qs2", "qz2", "codes4", "sc4", "zero4", "qs4", "qz4")
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_g1_ptq_codes_and_params_bit_exact(g1):
+    p = O.mxq_quantize(g1["W"], dead=g1["dead"])
+    for k in PTQ_KEYS:
+        assert np.array_equal(p[k], g1[k]), k
+    s2, s4 = O.mxq_scales(p)
+    assert np.array_equal(s2.view(np.uint32), g1["scale2"].view(np.uint32))
+    assert np.array_equal(s4.view(np.uint32), g1["scale4"].view(np.uint32))
+
+
+def test_g1_dequant_bit_exact(g1):
+    p = O.mxq_quantize(g1["W"], dead=g1["dead"])
+    w16 = p["w_deq32"].astype(np.float16)
+    assert np.array_equal(w16.view(np.uint16), g1["w_deq"].view(np.uint16))
+    # dequant from the stored parameterisation only (what the kernels see)
+    w16b = O.mxq_dequant({k: g1[k] for k in PTQ_KEYS} | {"N": 64, "K": 256}).astype(np.float16)
+    assert np.array_equal(w16b.view(np.uint16), g1["w_deq"].view(np.uint16))
+    assert g1["dead"][77]                            # dead column was zeroed before quantising
+
+
+def test_g1_linear(g1):
+    y = O.linear_ref(g1["x"], g1["w_deq"])
+    np.testing.assert_allclose(y, g1["y32"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_g2_llama_width_sha(g2, name):
+    N, K, seed = (int(v) for v in g2[f"{name}_shape"])
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    W16 = (torch.randn(N, K, generator=g) * 0.02).half().numpy()
+    p = O.mxq_quantize(W16)
+    p["w_deq"] = p["w_deq32"].astype(np.float16)
+    s2, s4 = O.mxq_scales(p)
+    p["scale2"], p["scale4"] = s2, s4
+    for k in PTQ_KEYS + ("w_deq", "scale2", "scale4"):
+        assert _sha(p[k]) == str(g2[f"{name}_sha_{k}"]), k
+        ref = g2[f"{name}_rows16_32_{k}"]
+        got = p[k][16:32] if p[k].shape[0] == N else p[k][1:2]
+        assert np.array_equal(got, ref), k
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+def test_g3_fakequant_bit_exact(g3, dt, bits):
+    key = f"{dt}_b{bits}"
+    if dt == "bf16":
+        w, ref = O.bf16_from_bits(g3[f"{key}_w"]), g3[f"{key}_out"]
+        got = O.bf16_bits(O.fakequant_fwd(w, bits, dt))
+        gin = O.bf16_bits(O.fakequant_bwd(O.bf16_from_bits(g3[f"{key}_gout"]), w))
+        assert np.array_equal(got, ref)
+        assert np.array_equal(gin, g3[f"{key}_gin"])
+    else:
+        w = g3[f"{key}_w"].astype(np.float32)
+        got = O.fakequant_fwd(w, bits, dt).astype(g3[f"{key}_out"].dtype)
+        ref = g3[f"{key}_out"]
+        same = (got == ref) | (np.isnan(got) & np.isnan(ref))      # fp16 constant group -> NaN (H5)
+        assert same.all()
+        gin = O.fakequant_bwd(g3[f"{key}_gout"], w)
+        assert np.array_equal(gin, g3[f"{key}_gin"])
+    if dt == "fp16":
+        assert np.isnan(g3[f"{key}_out"][6, 0:16].astype(np.float32)).all()
+
+
+@pytest.mark.parametrize("K", [4096, 11008])
+def test_g3_fakequant_llama_width_bf16(g3, K):
+    w = O.bf16_from_bits(g3[f"bf16_K{K}_w"])
+    got = O.bf16_bits(O.fakequant_fwd(w, 2, "bf16"))
+    assert np.array_equal(got, g3[f"bf16_K{K}_out"])
+
+
+def test_g6_kat_proto_format(g6):
+    """cuda_kernel/test_correct_gemv.py: every output == 4096."""
+    N, K = int(g6["N"]), int(g6["K"])
+    sub = 64                                           # a slice of rows is enough on CPU
+    full = lambda shape, v, dt: np.full(shape, v, dt)
+    y = O.gemv_mxq_proto_ref(
+        full((1, K), g6["x"], np.float16),
+        full((sub, 256), g6["weight_2b"], np.uint32), full((sub, 64), g6["weight_4b"], np.uint32),
+        full((sub, 32), g6["zeros_and_scales_1st"], np.uint32),
+        full((sub // 4, 256), g6["scales_2nd"], np.float16),
+        full((sub // 4, 32), g6["zeros_2nd"], np.uint32),
+        full((sub,), g6["scales_4b"], np.float16), full((sub // 8,), g6["zeros_4b"], np.uint32))
+    assert np.all(y.astype(np.int32) == int(g6["expected"]))
