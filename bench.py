@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: quantized-Linear TFLOP/s (+ tokens/s) of the MXQ W2/4 x A16 dequant-GEMM
+on Llama-2-7B-shaped synthetic weights (BASELINE.json: metric; workload = configs[1]:
+"Llama-2-7B all-Linear W2/4A16, batch=1 seq=2048, 1 x MI355X HIP dequant-GEMM kernel").
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of all 224 quantized Linears (32 layers x q,k,v,o,gate,up,down) over
+one sequence of 2048 tokens = 26.53 TFLOP, inputs and packed weights resident in HBM.
+N > 1: whole decoder layers are sharded over the ranks (rank r owns layers [32r/N, 32(r+1)/N),
+SURVEY.md 8e) and N sequences flow through the layer pipeline per step, the [2048, 4096] fp16
+hidden state hopping rank -> rank+1 by RCCL send/recv: per-GPU work is fixed ("weak").
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (mxq_gemm_f16_kernel,
+MFMA-bound): algorithmic 2*M*N*K flops of the launches of one step / their device time measured
+with HIP events on the launch stream.  `cpu_baseline` times the CPU restatement of the
+reference's dequant + F.linear (oracle/cpu_linear.py) on a bounded sample, rank 0 / N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from mxq_amd import llama_shapes as LS  # noqa: E402
+from mxq_amd import packing  # noqa: E402
+
+SEQ = 2048
+PEAK_F16_TFLOPS = 2500.0     # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def build_layers(layers, dev):
+    """Synthetic MXQ-quantised weights: randn * 0.02 -> fp16 -> fused HIP quantise-and-pack.
+    Seeds as SURVEY.md 8d: 1000 * layer + linear index."""
+    out = []
+    for li in layers:
+        lin = []
+        for idx, (name, N, K) in enumerate(LS.LAYER_LINEARS):
+            g = torch.Generator(device=dev).manual_seed(1000 * li + idx)
+            W = (torch.randn(N, K, generator=g, device=dev, dtype=torch.float32) * 0.02).half()
+            lin.append((name, packing.quantize_pack(W)))
+            del W
+        out.append(lin)
+    return out
+
+
+def cpu_baseline(dev, budget_s=12.0):
+    """Config 1 of BASELINE.json on the host cores: one [4096, 4096] MXQ Linear, batch 1 x
+    seq 128 -> dequant (fp32 scale*(q-zero), fp16 cast) + F.linear per call."""
+    from oracle import cpu_linear
+    N = K = 4096
+    M = 128
+    g = torch.Generator(device=dev).manual_seed(0)
+    W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
+    p = packing.quantize_pack(W)
+    params = {k: v.cpu() for k, v in packing.unpack(p).items()}
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(7)).half()
+    y_gpu = packing.linear(x.to(dev), p, path="gemm").float().cpu()
+    for _ in range(2):
+        y = cpu_linear.dequant_linear(params, N, K, x)
+    rel = ((y - y_gpu).abs().max() / y.abs().max()).item()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and len(times) < 200:
+        t0 = time.perf_counter()
+        cpu_linear.dequant_linear(params, N, K, x)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(2.0 * M * N * K / med / 1e12, 5), "unit": "TFLOP/s", "cores": torch.get_num_threads(),
+            "kind": "port", "tokens_per_s": round(M / med, 1), "ms_per_call": round(med * 1e3, 3),
+            "iters": len(times), "host_cpus": os.cpu_count(), "gpu_vs_cpu_max_rel_err": rel,
+            "sample": "config 1: one 4096x4096 MXQ Linear, M=128 tokens, dequant(fp32)+F.linear per call "
+                      "(4.295 GFLOP), median of the calls that fit ~12 s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    my_layers = list(LS.layer_range(rank, world))
+    layers = build_layers(my_layers, dev)
+    gx = torch.Generator(device=dev).manual_seed(7)
+    x_h = torch.randn(SEQ, LS.HIDDEN, generator=gx, device=dev).half()          # hidden-width input
+    x_i = torch.randn(SEQ, LS.INTERMEDIATE, generator=gx, device=dev).half()    # down_proj input
+    y_h = torch.empty(SEQ, LS.HIDDEN, device=dev, dtype=torch.float16)
+    y_i = torch.empty(SEQ, LS.INTERMEDIATE, device=dev, dtype=torch.float16)
+    recv_buf = torch.empty_like(x_h)
+    n_micro = world          # sequences in flight per step: per-GPU work stays one full-model pass
+
+    def stage(x_hidden):
+        for lin in layers:
+            for name, p in lin:
+                x = x_i if p.K == LS.INTERMEDIATE else x_hidden
+                packing.linear(x, p, out=(y_i if p.N == LS.INTERMEDIATE else y_h), path="gemm")
+
+    def step():
+        for _ in range(n_micro):
+            xin = x_h
+            if world > 1 and rank > 0:
+                dist.recv(recv_buf, src=rank - 1)
+                xin = recv_buf
+            stage(xin)
+            if world > 1 and rank < world - 1:
+                dist.send(xin, dst=rank + 1)      # the hidden state hops to the next pipeline stage
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    tokens_per_step = SEQ * n_micro
+    flops_per_step = LS.linear_flops(SEQ) * n_micro                      # whole job
+    flops_rank_step = LS.linear_flops(SEQ, len(my_layers)) * n_micro     # this rank's launches
+    launches_rank_step = 7 * len(my_layers) * n_micro
+    ms_per_step = elapsed / args.steps * 1e3
+    value = flops_per_step / (elapsed / args.steps) / 1e12
+    kern_ms = dev_ms / args.steps / launches_rank_step
+    achieved = flops_rank_step / (dev_ms / args.steps * 1e-3) / 1e12
+
+    if rank == 0:
+        bpw = sum(p.nbytes() for lin in layers for _, p in lin) * 8.0 / (LS.PARAMS_PER_LAYER * len(my_layers))
+        out = {
+            "metric": "quantized-Linear TFLOP/s, Llama-2-7B W2/4A16 all-Linear prefill (tokens/s alongside)",
+            "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "tokens_per_s": round(tokens_per_step / (elapsed / args.steps), 1),
+            "config": {"workload": "BASELINE configs[1]: Llama-2-7B all 224 quantized Linears (32 layers x "
+                                   "q,k,v,o,gate,up,down), batch=1 seq=2048 (M=2048), MXQ mixed 2/4-bit weights "
+                                   "(48x2b+16x4b per 64), fp16 activations, fp32 accumulate",
+                       "tokens_per_step": tokens_per_step, "flop_per_step": flops_per_step,
+                       "weight_format": "mxq-v1 exact metadata", "bits_per_weight": round(bpw, 3),
+                       "parallelism": "single GPU" if world == 1 else
+                       f"pp{world}: whole layers sharded, {world} sequences in flight, RCCL send/recv of the "
+                       f"[2048,4096] fp16 hidden state"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "kernel": "mxq_gemm_f16_kernel", "avg_launch_ms": round(kern_ms, 5),
+                         "launches_per_step": launches_rank_step,
+                         "algorithmic_flop_per_launch": flops_rank_step / launches_rank_step},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dev)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

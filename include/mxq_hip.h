@@ -1,0 +1,121 @@
+/* libmxq_hip.so -- C ABI of the MI355X-native MXQ hot path (gfx950 / CDNA4).
+ *
+ * This is the drop-in boundary: the entry points below are what a binding of the
+ * reference's native module would call.  The reference's boundary is the pybind11 torch
+ * extension `mxq_inference_engine`
+ *     mxq_quant/cuda_kernel/csrc/pybind.cpp:6-10        (module, two exports)
+ *     mxq_quant/cuda_kernel/csrc/quantization/gemv_cuda.h:4-9       gemv_forward_cuda
+ *     mxq_quant/cuda_kernel/csrc/quantization/gemv_mxq_cuda.h:4-12  gemv_mxq_forward_cuda
+ *     mxq_quant/cuda_kernel/csrc/quantization/gemm_cuda.h:3-4       gemm_forward_cuda (declared, unexported)
+ * plus the Python ops the kernels must agree with
+ *     mxq_quant/lib/quantizer.py:14-20, 61-147   quantize / dequantize / find_params
+ *     mxq_quant/lib/mxqgpt.py:387-448            MXQGPT.fasterquant (layout)
+ *     LLM-QAT/models/utils_quant.py:316-475      MXAsymQuantizer forward / backward
+ *
+ * Conventions
+ *   - plain pointers and sizes; no torch types; every pointer is a DEVICE pointer
+ *     (hipMalloc'd or a torch tensor's data_ptr()) unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - every function returns 0 on success, a positive hipError_t if the HIP runtime
+ *     reported one at launch, or a negative MXQ_E* code for rejected arguments;
+ *   - nothing here allocates, frees, synchronises or keeps state: outputs are
+ *     caller-allocated and the library is re-entrant (safe under hipGraph capture);
+ *   - shapes: weight W[N, K] row-major (nn.Linear.weight), N % 16 == 0, K % 64 == 0.
+ */
+#ifndef MXQ_HIP_H
+#define MXQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MXQ_DTYPE_F32 0
+#define MXQ_DTYPE_F16 1
+#define MXQ_DTYPE_BF16 2
+
+#define MXQ_E_SHAPE (-1)   /* N % 16, K % 64, sizes <= 0, unsupported group size ... */
+#define MXQ_E_NULL (-2)    /* a required pointer is NULL */
+#define MXQ_E_DTYPE (-3)   /* unknown dtype code */
+#define MXQ_E_ALIGN (-4)   /* a pointer is not 16-byte aligned */
+
+/* Library / packed-format version: (format << 16) | api.  No reference counterpart
+ * (the reference has no packed checkpoint format). */
+int mxq_version(void);
+
+/* Bytes of the packed buffers for W[N, K] (format v1, csrc/mxq_format.h): qweight holds
+ * codes + per-group metadata (~4.4 bit/weight), rowmeta one float4 per row.  Host-only
+ * helpers, no device work.  Return 0 for invalid shapes. */
+size_t mxq_qweight_bytes(int N, int K);
+size_t mxq_rowmeta_bytes(int N);
+
+/* Fused quantise-and-pack of a weight matrix on device.
+ * Replaces the Python loop of MXQGPT.fasterquant (mxqgpt.py:404-443: 3 x
+ * Quantizer(bits=2, qq_scale_bits=4) per 64-column chunk + one Quantizer(bits=4) over the
+ * gathered last-16 columns) and produces the packed form instead of fake-quant fp16.
+ * W: [N, K] of `w_dtype`; dead: optional uint8[K] mask of columns to zero first
+ * (diag(H) == 0, mxqgpt.py:401-403), may be NULL. */
+int mxq_quantize_pack(const void* W, int w_dtype, const uint8_t* dead, void* qweight, void* rowmeta, int N, int K,
+                      void* stream);
+
+/* Pack the lossless parameterisation (as produced by Quantizer.quantize / find_params,
+ * quantizer.py:14-16, 114-121) into format v1.  Shapes (G = 3*K/64 two-bit groups per row):
+ *   codes2 u8[N, 3K/4] (chunk-major, 48 per chunk), sc2 u8[N, G], zero2 f32[N, G],
+ *   qs2/qz2 f32[N/16, G], codes4 u8[N, K/4], sc4 u8[N], zero4 f32[N], qs4/qz4 f32[N/16]. */
+int mxq_pack_codes(const uint8_t* codes2, const uint8_t* sc2, const float* zero2, const float* qs2,
+                   const float* qz2, const uint8_t* codes4, const uint8_t* sc4, const float* zero4,
+                   const float* qs4, const float* qz4, void* qweight, void* rowmeta, int N, int K, void* stream);
+
+/* Integer unpack: exact inverse of mxq_pack_codes (the bit-exact unpack contract:
+ * codes == Quantizer.quantize output, quantizer.py:14-16). */
+int mxq_unpack(const void* qweight, const void* rowmeta, uint8_t* codes2, uint8_t* sc2, float* zero2, float* qs2,
+               float* qz2, uint8_t* codes4, uint8_t* sc4, float* zero4, float* qs4, float* qz4, int N, int K,
+               void* stream);
+
+/* Dequantise to a dense fp16 [N, K] matrix: bit-identical to the weight that
+ * MXQGPT.fasterquant writes back (scale*(q-zero) in fp32, one rounding to fp16;
+ * quantizer.py:19-20, mxqgpt.py:448). */
+int mxq_dequant_f16(const void* qweight, const void* rowmeta, void* w16, int N, int K, void* stream);
+
+/* y[M, N] (fp16) = x[M, K] (fp16) . dequant(qweight)[N, K]^T, fp32 accumulation.
+ * The fused unpack + per-group scale/zero + W2/4 x A16 product behind a quantised
+ * nn.Linear.  Counterpart of gemm_forward_cuda (gemm_cuda.h:3-4, MFMA path, any M) and of
+ * gemv_mxq_forward_cuda (gemv_mxq_cuda.h:4-12, streaming path, chosen for M <= 4).
+ * x, y, qweight must be 16-byte aligned; y must not alias x. */
+int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                   void* stream);
+/* The two code paths of mxq_linear_f16, exposed for benchmarking / testing. */
+int mxq_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                 void* stream);
+int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                 void* stream); /* M <= 4 */
+
+/* MXAsymQuantizer.forward (utils_quant.py:316-462; 2-D, layerwise=False branch):
+ * fake-quantise w[rows, cols] of `dtype` into out (same shape/dtype), bit-identical to
+ * the reference in fp32 / bf16 / fp16.  cols % 64 == 0. */
+int mxq_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype, void* stream);
+
+/* MXAsymQuantizer.backward (utils_quant.py:464-475): grad_in = grad_out where
+ * lo < w < hi, else 0.  n elements, n % 8 == 0 (n % 4 for fp32). */
+int mxq_fakequant_bwd(const void* grad_out, const void* w, void* grad_in, int64_t n, float lo, float hi, int dtype,
+                      void* stream);
+
+/* gemv_forward_cuda(in_feats, kernel, scaling_factors, zeros, group_size)
+ * (gemv_cuda.h:4-9; operand layout gemv_cuda.cu:45-59): x f16[B, IC], kernel i32[OC, IC/8],
+ * scales f16[OC, sf_w], zeros i32[OC, zeros_w], group_size in {32, 64, 128}; y f16[B, OC]. */
+int mxq_gemv_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int B,
+                     int IC, int OC, int group_size, void* stream);
+
+/* gemv_mxq_forward_cuda(in_feats, kernel, kernel_last, zeros_and_scales, scales_2nd,
+ * zeros_2nd, scales_4b, zeros_4b, group_size) (gemv_mxq_cuda.h:4-12; operand layout
+ * gemv_mxq_cuda.cu:54-62,96-201).  IC must be 4096 and group_size 16, as in the reference. */
+int mxq_gemv_proto_f16(const void* x, const void* weight, const void* weight_last, const void* zeros_and_scales,
+                       const void* scales_2nd, const void* zeros_2nd, const void* scales_4b, const void* zeros_4b,
+                       void* y, int B, int IC, int OC, int group_size, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXQ_HIP_H */

@@ -1,0 +1,132 @@
+// extern "C" surface of libmxq_hip.so (declared in include/mxq_hip.h): argument
+// validation + dispatch to the launchers.  Never throws, allocates or synchronises.
+#include <hip/hip_runtime.h>
+
+#include "../../include/mxq_hip.h"
+#include "mxq_format.h"
+#include "mxq_kernels.h"
+
+namespace {
+inline bool shape_ok(int N, int K) { return N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0; }
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+inline bool dtype_ok(int d) { return d == MXQ_DTYPE_F32 || d == MXQ_DTYPE_F16 || d == MXQ_DTYPE_BF16; }
+}   // namespace
+
+extern "C" {
+
+int mxq_version(void) { return (MXQ_FORMAT_VERSION << 16) | 1; }
+
+size_t mxq_qweight_bytes(int N, int K) {
+    if (!shape_ok(N, K)) return 0;
+    return (size_t)(N / 16) * mxq_nc4(K) * MXQ_TILE_DW * 4;
+}
+
+size_t mxq_rowmeta_bytes(int N) { return N > 0 && N % 16 == 0 ? (size_t)N * 16 : 0; }
+
+int mxq_quantize_pack(const void* W, int w_dtype, const uint8_t* dead, void* qweight, void* rowmeta, int N, int K,
+                      void* stream) {
+    if (!W || !qweight || !rowmeta) return MXQ_E_NULL;
+    if (!shape_ok(N, K)) return MXQ_E_SHAPE;
+    if (!dtype_ok(w_dtype)) return MXQ_E_DTYPE;
+    if (!aligned16(W) || !aligned16(qweight) || !aligned16(rowmeta)) return MXQ_E_ALIGN;
+    return mxq_launch_quantize_pack(W, w_dtype, dead, qweight, rowmeta, N, K, (hipStream_t)stream);
+}
+
+int mxq_pack_codes(const uint8_t* codes2, const uint8_t* sc2, const float* zero2, const float* qs2,
+                   const float* qz2, const uint8_t* codes4, const uint8_t* sc4, const float* zero4,
+                   const float* qs4, const float* qz4, void* qweight, void* rowmeta, int N, int K, void* stream) {
+    if (!codes2 || !sc2 || !zero2 || !qs2 || !qz2 || !codes4 || !sc4 || !zero4 || !qs4 || !qz4 || !qweight ||
+        !rowmeta)
+        return MXQ_E_NULL;
+    if (!shape_ok(N, K)) return MXQ_E_SHAPE;
+    if (!aligned16(qweight) || !aligned16(rowmeta)) return MXQ_E_ALIGN;
+    return mxq_launch_pack_codes(codes2, sc2, zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4, qweight, rowmeta, N, K,
+                                 (hipStream_t)stream);
+}
+
+int mxq_unpack(const void* qweight, const void* rowmeta, uint8_t* codes2, uint8_t* sc2, float* zero2, float* qs2,
+               float* qz2, uint8_t* codes4, uint8_t* sc4, float* zero4, float* qs4, float* qz4, int N, int K,
+               void* stream) {
+    if (!codes2 || !sc2 || !zero2 || !qs2 || !qz2 || !codes4 || !sc4 || !zero4 || !qs4 || !qz4 || !qweight ||
+        !rowmeta)
+        return MXQ_E_NULL;
+    if (!shape_ok(N, K)) return MXQ_E_SHAPE;
+    if (!aligned16(qweight) || !aligned16(rowmeta)) return MXQ_E_ALIGN;
+    return mxq_launch_unpack(qweight, rowmeta, codes2, sc2, zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4, N, K,
+                             (hipStream_t)stream);
+}
+
+int mxq_dequant_f16(const void* qweight, const void* rowmeta, void* w16, int N, int K, void* stream) {
+    if (!qweight || !rowmeta || !w16) return MXQ_E_NULL;
+    if (!shape_ok(N, K)) return MXQ_E_SHAPE;
+    if (!aligned16(qweight) || !aligned16(rowmeta) || !aligned16(w16)) return MXQ_E_ALIGN;
+    return mxq_launch_dequant_f16(qweight, rowmeta, w16, N, K, (hipStream_t)stream);
+}
+
+static int linear_check(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K) {
+    if (!x || !qweight || !rowmeta || !y) return MXQ_E_NULL;
+    if (!shape_ok(N, K) || M <= 0) return MXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(rowmeta) || !aligned16(y)) return MXQ_E_ALIGN;
+    return 0;
+}
+
+int mxq_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                 void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+}
+
+int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                 void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    if (M > 4) return MXQ_E_SHAPE;
+    return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+}
+
+int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                   void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+    return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+}
+
+int mxq_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype, void* stream) {
+    if (!w || !out) return MXQ_E_NULL;
+    if (rows <= 0 || cols <= 0 || cols % 64 != 0 || num_bits < 1 || num_bits > 31) return MXQ_E_SHAPE;
+    if (!dtype_ok(dtype)) return MXQ_E_DTYPE;
+    if (!aligned16(w) || !aligned16(out)) return MXQ_E_ALIGN;
+    return mxq_launch_fakequant_fwd(w, out, rows, cols, num_bits, dtype, (hipStream_t)stream);
+}
+
+int mxq_fakequant_bwd(const void* grad_out, const void* w, void* grad_in, int64_t n, float lo, float hi, int dtype,
+                      void* stream) {
+    if (!grad_out || !w || !grad_in) return MXQ_E_NULL;
+    if (!dtype_ok(dtype)) return MXQ_E_DTYPE;
+    if (n <= 0 || n % (dtype == MXQ_DTYPE_F32 ? 4 : 8) != 0) return MXQ_E_SHAPE;
+    if (!aligned16(grad_out) || !aligned16(w) || !aligned16(grad_in)) return MXQ_E_ALIGN;
+    return mxq_launch_fakequant_bwd(grad_out, w, grad_in, n, lo, hi, dtype, (hipStream_t)stream);
+}
+
+int mxq_gemv_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int B,
+                     int IC, int OC, int group_size, void* stream) {
+    if (!x || !kernel || !scales || !zeros || !y) return MXQ_E_NULL;
+    if (B <= 0 || OC <= 0 || IC <= 0 || IC % 8 != 0) return MXQ_E_SHAPE;
+    if (group_size != 32 && group_size != 64 && group_size != 128) return MXQ_E_SHAPE;   // gemv_cuda.cu:371-397
+    if (IC % group_size != 0) return MXQ_E_SHAPE;
+    if (!aligned16(x)) return MXQ_E_ALIGN;
+    return mxq_launch_gemv_awq_f16(x, kernel, scales, zeros, y, B, IC, OC, group_size, (hipStream_t)stream);
+}
+
+int mxq_gemv_proto_f16(const void* x, const void* weight, const void* weight_last, const void* zeros_and_scales,
+                       const void* scales_2nd, const void* zeros_2nd, const void* scales_4b, const void* zeros_4b,
+                       void* y, int B, int IC, int OC, int group_size, void* stream) {
+    if (!x || !weight || !weight_last || !zeros_and_scales || !scales_2nd || !zeros_2nd || !scales_4b || !zeros_4b ||
+        !y)
+        return MXQ_E_NULL;
+    if (group_size != 16 || IC != 4096 || B <= 0 || OC <= 0 || OC % 8 != 0) return MXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(weight)) return MXQ_E_ALIGN;
+    return mxq_launch_gemv_proto_f16(x, weight, weight_last, zeros_and_scales, scales_2nd, zeros_2nd, scales_4b,
+                                     zeros_4b, y, B, IC, OC, (hipStream_t)stream);
+}
+
+}   // extern "C"

@@ -1,0 +1,185 @@
+// Fused MXAsymQuantizer forward and STE backward for QAT
+// (reference LLM-QAT/models/utils_quant.py:316-462 forward, :464-475 backward; the live
+// branch only: 2-D input, layerwise=False, in_features % 64 == 0 -- SURVEY.md H6).
+//
+// The reference runs ~1.7k-4.5k tiny torch kernels per weight (a Python loop over 64-wide
+// chunks x 3 groups).  Here: ONE kernel, one wave per weight row, HBM-bound
+// (read + write = 2 * sizeof(T) bytes per element):
+//   pass 1  row min/max of the gathered 4-bit arm (last 16 of every 64 columns, an fp32
+//           buffer in the reference, :347,369-377) -- only those 32/64-B quarters are read;
+//   pass 2  coalesced 16-B-per-lane sweep of the row: 2-bit groups (16 columns) live in 2
+//           (16-bit dtypes) or 4 (fp32) adjacent lanes -> xor-shuffle min/max; every
+//           reference op is done in fp32 and rounded to the tensor dtype T, which is what
+//           PyTorch does for bf16/fp16 tensors -> bit-identical output.
+// The second read of the row hits L2 (a row is 8-44 KB).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "mxq_kernels.h"
+
+namespace {
+
+struct F32 {
+    static constexpr int VEC = 4;
+    __device__ static __forceinline__ float rnd(float x) { return x; }
+    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[4]) {
+        const float4 a = *(const float4*)((const float*)p + e);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    }
+    __device__ static __forceinline__ void store(void* p, int64_t e, const float v[4]) {
+        *(float4*)((float*)p + e) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+
+struct BF16 {
+    static constexpr int VEC = 8;
+    // round-to-nearest-even to 8 significant bits, NaN preserved
+    __device__ static __forceinline__ float rnd(float x) {
+        uint32_t u = __float_as_uint(x);
+        if ((u & 0x7FFFFFFFu) > 0x7F800000u) return x;
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return __uint_as_float(u & 0xFFFF0000u);
+    }
+    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) {
+        const uint4 a = *(const uint4*)((const uint16_t*)p + e);
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+    __device__ static __forceinline__ void store(void* p, int64_t e, const float v[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = (__float_as_uint(v[2 * i]) >> 16) | (__float_as_uint(v[2 * i + 1]) & 0xFFFF0000u);
+        *(uint4*)((uint16_t*)p + e) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+struct F16 {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float rnd(float x) { return (float)(_Float16)x; }
+    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const h8 a = *(const h8*)((const uint16_t*)p + e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
+    __device__ static __forceinline__ void store(void* p, int64_t e, const float v[8]) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (_Float16)v[i];
+        *(h8*)((uint16_t*)p + e) = a;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void mxq_fakequant_fwd_kernel(const void* __restrict__ w, void* __restrict__ out,
+                                                                int rows, int cols, float L2) {
+    constexpr int VEC = T::VEC;
+    constexpr int LPG = 16 / VEC;   // lanes per 16-column group (2 or 4)
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;   // wave-uniform
+    const int64_t base = (int64_t)row * cols;
+    const int NC = cols / 64;
+    float v[VEC];
+
+    // pass 1: min / max over the gathered 4-bit slice of the row
+    float mn4 = INFINITY, mx4 = -INFINITY;
+    for (int c = lane / LPG; c < NC; c += 64 / LPG) {
+        T::load(w, base + (int64_t)c * 64 + 48 + (lane % LPG) * VEC, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { mn4 = fminf(mn4, v[j]); mx4 = fmaxf(mx4, v[j]); }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        mn4 = fminf(mn4, __shfl_xor(mn4, o, 64));
+        mx4 = fmaxf(mx4, __shfl_xor(mx4, o, 64));
+    }
+    const float alpha4 = T::rnd(mx4 - mn4);   // fp32 subtraction, cast on assignment (:369-384)
+
+    // pass 2
+    for (int e0 = lane * VEC; e0 < cols; e0 += 64 * VEC) {
+        T::load(w, base + e0, v);
+        float mn = v[0], mx = v[0];
+#pragma unroll
+        for (int j = 1; j < VEC; ++j) { mn = fminf(mn, v[j]); mx = fmaxf(mx, v[j]); }
+#pragma unroll
+        for (int o = 1; o < LPG; o <<= 1) {
+            mn = fminf(mn, __shfl_xor(mn, o, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        }
+        const bool is4 = (e0 & 63) >= 48;
+        const float alpha = is4 ? alpha4 : T::rnd(mx - mn);
+        const float beta = is4 ? mn4 : mn;
+        const float L = is4 ? 15.0f : L2;
+        const float e = T::rnd(alpha + 1e-8f);
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xn = T::rnd(T::rnd(v[j] - beta) / e);
+            const float q = rintf(T::rnd(xn * L));
+            o[j] = T::rnd(T::rnd(T::rnd(q / L) * e) + beta);
+        }
+        T::store(out, base + e0, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mxq_fakequant_bwd_kernel(const void* __restrict__ gout,
+                                                                const void* __restrict__ w, void* __restrict__ gin,
+                                                                int64_t nvec, float lo, float hi) {
+    constexpr int VEC = T::VEC;
+    float g[VEC], x[VEC];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        T::load(gout, i * VEC, g);
+        T::load(w, i * VEC, x);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            if (x[j] >= hi || x[j] <= lo) g[j] = 0.0f;
+        T::store(gin, i * VEC, g);
+    }
+}
+
+template <typename T>
+int launch_fwd(const void* w, void* out, int rows, int cols, int num_bits, hipStream_t stream) {
+    const float L2 = (float)(exp2((double)num_bits) - 1.0);
+    mxq_fakequant_fwd_kernel<T><<<(rows + 3) / 4, 256, 0, stream>>>(w, out, rows, cols, L2);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_bwd(const void* gout, const void* w, void* gin, int64_t n, float lo, float hi, hipStream_t stream) {
+    const int64_t nvec = n / T::VEC;
+    int64_t blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;   // cap + grid-stride (guide section 6, G11)
+    if (blocks < 1) blocks = 1;
+    mxq_fakequant_bwd_kernel<T><<<(unsigned)blocks, 256, 0, stream>>>(gout, w, gin, nvec, lo, hi);
+    return (int)hipGetLastError();
+}
+
+}   // namespace
+
+int mxq_launch_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype,
+                             hipStream_t stream) {
+    switch (dtype) {
+        case MXQ_DTYPE_F32: return launch_fwd<F32>(w, out, rows, cols, num_bits, stream);
+        case MXQ_DTYPE_F16: return launch_fwd<F16>(w, out, rows, cols, num_bits, stream);
+        case MXQ_DTYPE_BF16: return launch_fwd<BF16>(w, out, rows, cols, num_bits, stream);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+int mxq_launch_fakequant_bwd(const void* grad_out, const void* w, void* grad_in, int64_t n, float lo, float hi,
+                             int dtype, hipStream_t stream) {
+    switch (dtype) {
+        case MXQ_DTYPE_F32: return launch_bwd<F32>(grad_out, w, grad_in, n, lo, hi, stream);
+        case MXQ_DTYPE_F16: return launch_bwd<F16>(grad_out, w, grad_in, n, lo, hi, stream);
+        case MXQ_DTYPE_BF16: return launch_bwd<BF16>(grad_out, w, grad_in, n, lo, hi, stream);
+    }
+    return (int)hipErrorInvalidValue;
+}

@@ -1,0 +1,152 @@
+// Decode-path GEMV / skinny GEMM (M <= 4) on the v1 packed format:
+//   y[m, n] = sum_k x[m, k] * fp16(scale * (q - zero))[n, k], fp32 accumulate, fp16 out.
+//
+// Native counterpart of the reference's fused unpack+dot kernel
+// gemv_mxq_kernel_g16_v0 (mxq_quant/cuda_kernel/csrc/quantization/gemv_mxq_cuda.cu:39-208)
+// -- same idea (never materialise fp16 weights in memory), different everything else:
+//   * HBM-bound: every packed byte is read exactly once, 256 contiguous bytes per wave
+//     load (format v1: fields are [chunk-in-tile][row]-minor), straight to VGPRs
+//     (no LDS round trip for weights; cdna guide section 5, "GEMV / M <= 16" row).
+//   * one workgroup per 16-row block (N/16 >= 256 workgroups for Llama shapes), 8 waves
+//     split K; lane -> (row r = lane & 15, chunk-in-tile cs = lane >> 4), i.e. a wave
+//     consumes one 16 x 256 tile (2272 B) per iteration.
+//   * activations are staged once per workgroup in LDS as fp16 and read as broadcast
+//     ds_read_b128; products use v_dot2_f32_f16 on the LUT-selected fp16 pairs.
+//   * wave64 reduction: 2 xor-shuffles over the 4 chunk slots, then 8 waves through LDS.
+#include <hip/hip_runtime.h>
+
+#include "mxq_dequant.h"
+#include "mxq_format.h"
+#include "mxq_kernels.h"
+
+namespace {
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+constexpr int GEMV_THREADS = 512;
+constexpr int GEMV_WAVES = GEMV_THREADS / 64;
+
+__device__ __forceinline__ float dot8(const uint32_t* w, const uint4 xa, float acc) {
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[0]), __builtin_bit_cast(half2v, xa.x), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[1]), __builtin_bit_cast(half2v, xa.y), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[2]), __builtin_bit_cast(half2v, xa.z), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[3]), __builtin_bit_cast(half2v, xa.w), acc, false);
+    return acc;
+}
+
+template <int MB>
+__global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16_t* __restrict__ x,
+                                                                     const uint32_t* __restrict__ qweight,
+                                                                     const float4* __restrict__ rowmeta,
+                                                                     uint16_t* __restrict__ y, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // MB*K halfs, then reduction scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, cs = lane >> 4;
+    const int rb = blockIdx.x;
+    const int NC = K / 64, NC4 = mxq_nc4(K);
+
+    // stage x[0..MB) in LDS (rows beyond M are zero)
+    {
+        const int vec_per_row = K / 8;
+        for (int i = tid; i < MB * vec_per_row; i += GEMV_THREADS) {
+            const int m = i / vec_per_row, v = i % vec_per_row;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (m < M) val = *(const uint4*)(x + (int64_t)m * K + v * 8);
+            *(uint4*)(smem + (size_t)i * 16) = val;
+        }
+    }
+    const float4 rm = rowmeta[rb * 16 + r];
+    const float s4 = mxq_scale(rm.z, rm.w, (uint32_t)rm.y), z4 = rm.x;
+    __syncthreads();
+
+    float acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+
+    const uint32_t* tiles = qweight + (int64_t)rb * NC4 * MXQ_TILE_DW;
+    for (int c4 = wave; c4 < NC4; c4 += GEMV_WAVES) {
+        const uint32_t* tile = tiles + (int64_t)c4 * MXQ_TILE_DW;
+        const int chunk = c4 * 4 + cs;
+        // 12 loads, each 256 contiguous bytes across the wave (QQ: 4 distinct 8-B words)
+        uint32_t c2w[3], z2w[3], c4w[2];
+        uint2 qq[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            c2w[g] = tile[mxq_c2(g, cs, r)];
+            z2w[g] = tile[mxq_z2(g, cs, r)];
+            qq[g] = *(const uint2*)(tile + mxq_qq(cs, g));
+        }
+        c4w[0] = tile[mxq_c4(0, cs, r)];
+        c4w[1] = tile[mxq_c4(1, cs, r)];
+        const uint32_t scw = ((const uint16_t*)tile)[mxq_sc_u16(cs, r)];
+        if (chunk >= NC) continue;   // chunk padding of the last tile (all-zero words anyway)
+
+        const char* xk = smem + (size_t)chunk * 128;
+        uint32_t o[8];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            mxq_deq2x16(c2w[g], mxq_scale(__uint_as_float(qq[g].x), __uint_as_float(qq[g].y), (scw >> (4 * g)) & 15u),
+                        __uint_as_float(z2w[g]), o);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + g * 32);
+                const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + g * 32 + 16);
+                acc[m] = dot8(o, xa, acc[m]);
+                acc[m] = dot8(o + 4, xb, acc[m]);
+            }
+        }
+        mxq_deq4x8(c4w[0], s4, z4, o);
+        mxq_deq4x8(c4w[1], s4, z4, o + 4);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + 96);
+            const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + 112);
+            acc[m] = dot8(o, xa, acc[m]);
+            acc[m] = dot8(o + 4, xb, acc[m]);
+        }
+    }
+
+    // reduce over the 4 chunk slots of the wave, then over waves
+    float* red = (float*)(smem + (size_t)MB * K * 2);   // [GEMV_WAVES][MB][16]
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        float v = acc[m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (cs == 0) red[(wave * MB + m) * 16 + r] = v;
+    }
+    __syncthreads();
+    if (tid < MB * 16) {
+        const int m = tid >> 4, rr = tid & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < GEMV_WAVES; ++w) v += red[(w * MB + m) * 16 + rr];
+        if (m < M) {
+            const _Float16 h = (_Float16)v;
+            y[(int64_t)m * N + rb * 16 + rr] = __builtin_bit_cast(uint16_t, h);
+        }
+    }
+}
+
+template <int MB>
+int launch(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream) {
+    const size_t smem = (size_t)MB * K * 2 + (size_t)GEMV_WAVES * MB * 16 * 4;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    mxq_gemv_f16_kernel<MB><<<N / 16, GEMV_THREADS, smem, stream>>>((const uint16_t*)x, (const uint32_t*)qweight,
+                                                                    (const float4*)rowmeta, (uint16_t*)y, M, N, K);
+    return (int)hipGetLastError();
+}
+
+}   // namespace
+
+int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                        hipStream_t stream) {
+    if (M == 1) return launch<1>(x, qweight, rowmeta, y, M, N, K, stream);
+    if (M == 2) return launch<2>(x, qweight, rowmeta, y, M, N, K, stream);
+    if (M <= 4) return launch<4>(x, qweight, rowmeta, y, M, N, K, stream);
+    return (int)hipErrorInvalidValue;
+}

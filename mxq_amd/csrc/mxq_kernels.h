@@ -1,0 +1,35 @@
+// Internal launcher declarations shared by the .hip translation units and the C-ABI
+// shim (capi.hip).  Every launcher returns a hipError_t as int, never allocates and
+// never synchronises; all pointers are device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MXQ_DTYPE_F32 0
+#define MXQ_DTYPE_F16 1
+#define MXQ_DTYPE_BF16 2
+
+int mxq_launch_pack_codes(const uint8_t* codes2, const uint8_t* sc2, const float* zero2, const float* qs2,
+                          const float* qz2, const uint8_t* codes4, const uint8_t* sc4, const float* zero4,
+                          const float* qs4, const float* qz4, void* qweight, void* rowmeta, int N, int K,
+                          hipStream_t stream);
+int mxq_launch_unpack(const void* qweight, const void* rowmeta, uint8_t* codes2, uint8_t* sc2, float* zero2,
+                      float* qs2, float* qz2, uint8_t* codes4, uint8_t* sc4, float* zero4, float* qs4, float* qz4,
+                      int N, int K, hipStream_t stream);
+int mxq_launch_dequant_f16(const void* qweight, const void* rowmeta, void* out, int N, int K, hipStream_t stream);
+int mxq_launch_quantize_pack(const void* W, int dtype, const uint8_t* dead, void* qweight, void* rowmeta, int N,
+                             int K, hipStream_t stream);
+int mxq_launch_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                        hipStream_t stream);
+int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                        hipStream_t stream);
+int mxq_launch_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype,
+                             hipStream_t stream);
+int mxq_launch_fakequant_bwd(const void* grad_out, const void* w, void* grad_in, int64_t n, float lo, float hi,
+                             int dtype, hipStream_t stream);
+int mxq_launch_gemv_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y,
+                            int B, int IC, int OC, int group_size, hipStream_t stream);
+int mxq_launch_gemv_proto_f16(const void* x, const void* weight, const void* weight_last,
+                              const void* zeros_and_scales, const void* scales_2nd, const void* zeros_2nd,
+                              const void* scales_4b, const void* zeros_4b, void* y, int B, int IC, int OC,
+                              hipStream_t stream);

@@ -1,0 +1,292 @@
+// Packed-format kernels: pack-from-codes, unpack, dequant-to-fp16, and the fused
+// on-device quantise-and-pack (reference MXQGPT.fasterquant, mxq_quant/lib/mxqgpt.py:387-448,
+// Quantizer.find_params lib/quantizer.py:61-147, restated per SURVEY.md Appendix A1).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "mxq_dequant.h"
+#include "mxq_format.h"
+#include "mxq_pack.h"
+#include "mxq_kernels.h"
+
+// ------------------------------------------------------------------------------------ //
+// pack / unpack: one thread per (row, chunk); utility kernels, not on the timed path.
+// ------------------------------------------------------------------------------------ //
+__global__ void mxq_pack_codes_kernel(const uint8_t* __restrict__ codes2, const uint8_t* __restrict__ sc2,
+                                      const float* __restrict__ zero2, const float* __restrict__ qs2,
+                                      const float* __restrict__ qz2, const uint8_t* __restrict__ codes4,
+                                      const uint8_t* __restrict__ sc4, const float* __restrict__ zero4,
+                                      const float* __restrict__ qs4, const float* __restrict__ qz4,
+                                      uint32_t* __restrict__ qweight, float4* __restrict__ rowmeta, int N, int K) {
+    const int NC = K / 64;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * NC) return;
+    const int n = (int)(idx / NC), c = (int)(idx % NC);
+    uint32_t* tile = qweight + mxq_tile_index(n, c, K) * MXQ_TILE_DW;
+    const int cc = c & 3, r = n & 15;
+    mxq_pack_row_chunk(tile, cc, r, codes2 + (int64_t)n * NC * 48 + c * 48, sc2 + (int64_t)n * NC * 3 + c * 3,
+                       zero2 + (int64_t)n * NC * 3 + c * 3, codes4 + (int64_t)n * NC * 16 + c * 16);
+    if (r == 0) {
+        for (int g = 0; g < 3; ++g) {
+            tile[mxq_qq(cc, g)] = __float_as_uint(qs2[(int64_t)(n / 16) * NC * 3 + c * 3 + g]);
+            tile[mxq_qq(cc, g) + 1] = __float_as_uint(qz2[(int64_t)(n / 16) * NC * 3 + c * 3 + g]);
+        }
+    }
+    if (c == 0) rowmeta[n] = make_float4(zero4[n], (float)sc4[n], qs4[n / 16], qz4[n / 16]);
+}
+
+__global__ void mxq_unpack_kernel(const uint32_t* __restrict__ qweight, const float4* __restrict__ rowmeta,
+                                  uint8_t* __restrict__ codes2, uint8_t* __restrict__ sc2, float* __restrict__ zero2,
+                                  float* __restrict__ qs2, float* __restrict__ qz2, uint8_t* __restrict__ codes4,
+                                  uint8_t* __restrict__ sc4, float* __restrict__ zero4, float* __restrict__ qs4,
+                                  float* __restrict__ qz4, int N, int K) {
+    const int NC = K / 64;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * NC) return;
+    const int n = (int)(idx / NC), c = (int)(idx % NC);
+    const uint32_t* tile = qweight + mxq_tile_index(n, c, K) * MXQ_TILE_DW;
+    const int cc = c & 3, r = n & 15;
+    mxq_unpack_row_chunk(tile, cc, r, codes2 + (int64_t)n * NC * 48 + c * 48, sc2 + (int64_t)n * NC * 3 + c * 3,
+                         zero2 + (int64_t)n * NC * 3 + c * 3, codes4 + (int64_t)n * NC * 16 + c * 16);
+    if (r == 0) {
+        for (int g = 0; g < 3; ++g) {
+            qs2[(int64_t)(n / 16) * NC * 3 + c * 3 + g] = __uint_as_float(tile[mxq_qq(cc, g)]);
+            qz2[(int64_t)(n / 16) * NC * 3 + c * 3 + g] = __uint_as_float(tile[mxq_qq(cc, g) + 1]);
+        }
+    }
+    if (c == 0) {
+        const float4 m = rowmeta[n];
+        zero4[n] = m.x;
+        sc4[n] = (uint8_t)m.y;
+        if (r == 0) {
+            qs4[n / 16] = m.z;
+            qz4[n / 16] = m.w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ //
+// dequant to a dense fp16 [N, K] matrix (bit-exact fake-quant weight, mxqgpt.py:448).
+// One thread per (row, chunk quarter): 16 weights = 32 B.  Block = 256 threads covers a
+// 16-row x 4-chunk tile: thread -> (quarter, cc, r).
+// ------------------------------------------------------------------------------------ //
+__global__ __launch_bounds__(256) void mxq_dequant_f16_kernel(const uint32_t* __restrict__ qweight,
+                                                              const float4* __restrict__ rowmeta,
+                                                              uint16_t* __restrict__ out, int N, int K) {
+    const int NC = K / 64, NC4 = mxq_nc4(K);
+    const int rb = blockIdx.x / NC4, c4 = blockIdx.x % NC4;
+    const int t = threadIdx.x;
+    const int r = t & 15, cc = (t >> 4) & 3, qt = t >> 6;   // qt wave-uniform
+    const int n = rb * 16 + r, c = c4 * 4 + cc;
+    if (c >= NC) return;
+    const uint32_t* tile = qweight + (int64_t)blockIdx.x * MXQ_TILE_DW;
+    uint32_t o[8];
+    if (qt < 3) {
+        const uint32_t d = tile[mxq_c2(qt, cc, r)];
+        const float z = __uint_as_float(tile[mxq_z2(qt, cc, r)]);
+        const uint32_t scw = ((const uint16_t*)tile)[mxq_sc_u16(cc, r)];
+        const float qs = __uint_as_float(tile[mxq_qq(cc, qt)]), qz = __uint_as_float(tile[mxq_qq(cc, qt) + 1]);
+        mxq_deq2x16(d, mxq_scale(qs, qz, (scw >> (4 * qt)) & 15u), z, o);
+    } else {
+        const float4 m = rowmeta[n];
+        const float s = mxq_scale(m.z, m.w, (uint32_t)m.y);
+        mxq_deq4x8(tile[mxq_c4(0, cc, r)], s, m.x, o);
+        mxq_deq4x8(tile[mxq_c4(1, cc, r)], s, m.x, o + 4);
+    }
+    uint4* dst = (uint4*)(out + (int64_t)n * K + c * 64 + qt * 16);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// ------------------------------------------------------------------------------------ //
+// Fused quantise-and-pack.  One 256-thread block per 16-row block (the second-order
+// scale group, quantizer.py:115).  lane -> (r = lane & 15, qt = lane >> 4): 16 rows x the
+// four 16-wide quarters of a chunk; wave w takes chunks c = w (mod 4).
+//   pass 1: 2-bit groups (qt < 3) are finished per chunk: per-row min/max -> s0, z; the
+//           16 lanes of a quarter reduce min/max of s0 (second-order) -> code, scale;
+//           lanes with qt == 3 only track the row min/max of the gathered 4-bit slice
+//           (mxqgpt.py:431-435).
+//   pass 2: 4-bit arm, lane -> (r, chunk cc of a tile).
+// ------------------------------------------------------------------------------------ //
+__device__ __forceinline__ void load16(const void* W, int dtype, int64_t off, float v[16]) {
+    if (dtype == MXQ_DTYPE_F16) {
+        const uint4* p = (const uint4*)((const uint16_t*)W + off);
+        uint4 a = p[0], b = p[1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 h = __builtin_bit_cast(h2, w[i]);
+            v[2 * i] = (float)h[0];
+            v[2 * i + 1] = (float)h[1];
+        }
+    } else if (dtype == MXQ_DTYPE_BF16) {
+        const uint4* p = (const uint4*)((const uint16_t*)W + off);
+        uint4 a = p[0], b = p[1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    } else {
+        const float4* p = (const float4*)((const float*)W + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 a = p[i];
+            v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+        }
+    }
+}
+
+__device__ __forceinline__ float grp16_min(float x) {
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) x = fminf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+__device__ __forceinline__ float grp16_max(float x) {
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+// Quantizer.find_params second half (quantizer.py:90-99,114-121) for one row of a group:
+// (lo, hi) -> zero, scale code, dequantised scale; (qs, qz) shared by the 16 lanes.
+__device__ __forceinline__ void find_params16(float lo, float hi, float maxq, float& z, float& scode, float& s,
+                                              float& qs, float& qz) {
+    if (lo == hi) { lo = -1.0f; hi = 1.0f; }
+    const float s0 = (hi - lo) / maxq;
+    z = (-lo) / s0;
+    float slo = grp16_min(s0), shi = grp16_max(s0);
+    if (slo == shi) { slo = -1.0f; shi = 1.0f; }
+    qs = (shi - slo) / 15.0f;
+    qz = (-slo) / qs;
+    scode = fminf(fmaxf(rintf(s0 / fmaxf(qs, 1e-9f) + qz), 0.0f), 15.0f);
+    s = qs * (scode - qz);
+}
+
+__global__ __launch_bounds__(256) void mxq_quantize_pack_kernel(const void* __restrict__ W, int dtype,
+                                                                const uint8_t* __restrict__ dead,
+                                                                uint32_t* __restrict__ qweight,
+                                                                float4* __restrict__ rowmeta, int N, int K) {
+    const int NC = K / 64, NC4 = mxq_nc4(K);
+    const int rb = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, qt = lane >> 4;
+    const int n = rb * 16 + r;
+    __shared__ float red[2][4][16];
+    float mn4 = INFINITY, mx4 = -INFINITY;
+    float v[16];
+
+    for (int c = wave; c < NC; c += 4) {
+        const int k0 = c * 64 + qt * 16;
+        load16(W, dtype, (int64_t)n * K + k0, v);
+        if (dead) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (dead[k0 + j]) v[j] = 0.0f;
+        }
+        float lo = v[0], hi = v[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) { lo = fminf(lo, v[j]); hi = fmaxf(hi, v[j]); }
+        if (qt == 3) { mn4 = fminf(mn4, lo); mx4 = fmaxf(mx4, hi); }
+        float z, scode, s, qs, qz;
+        find_params16(lo, hi, 3.0f, z, scode, s, qs, qz);
+        const float sd = fmaxf(s, 1e-9f);
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float q = fminf(fmaxf(rintf(v[j] / sd + z), 0.0f), 3.0f);
+            word |= (uint32_t)q << mxq_bit2(j);
+        }
+        const uint32_t sci = (uint32_t)scode;
+        const uint32_t sc1 = __shfl(sci, r + 16, 64), sc2 = __shfl(sci, r + 32, 64);
+        uint32_t* tile = qweight + ((int64_t)rb * NC4 + (c >> 2)) * MXQ_TILE_DW;
+        const int cc = c & 3;
+        if (qt < 3) {
+            tile[mxq_c2(qt, cc, r)] = word;
+            tile[mxq_z2(qt, cc, r)] = __float_as_uint(z);
+            if (r == 0) {
+                tile[mxq_qq(cc, qt)] = __float_as_uint(qs);
+                tile[mxq_qq(cc, qt) + 1] = __float_as_uint(qz);
+            }
+        }
+        if (qt == 0) ((uint16_t*)tile)[mxq_sc_u16(cc, r)] = (uint16_t)(sci | (sc1 << 4) | (sc2 << 8));
+    }
+    if (qt == 3) { red[0][wave][r] = mn4; red[1][wave][r] = mx4; }
+    __syncthreads();
+    float lo4 = fminf(fminf(red[0][0][r], red[0][1][r]), fminf(red[0][2][r], red[0][3][r]));
+    float hi4 = fmaxf(fmaxf(red[1][0][r], red[1][1][r]), fmaxf(red[1][2][r], red[1][3][r]));
+    float z4, sc4, s4, qs4, qz4;
+    find_params16(lo4, hi4, 15.0f, z4, sc4, s4, qs4, qz4);
+    if (wave == 0 && qt == 0) rowmeta[n] = make_float4(z4, sc4, qs4, qz4);
+    const float sd4 = fmaxf(s4, 1e-9f);
+
+    for (int c4 = wave; c4 < NC4; c4 += 4) {
+        const int c = c4 * 4 + qt;   // qt plays the role of the chunk-in-tile index here
+        if (c >= NC) continue;
+        const int k0 = c * 64 + 48;
+        load16(W, dtype, (int64_t)n * K + k0, v);
+        if (dead) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (dead[k0 + j]) v[j] = 0.0f;
+        }
+        uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float q0 = fminf(fmaxf(rintf(v[j] / sd4 + z4), 0.0f), 15.0f);
+            const float q1 = fminf(fmaxf(rintf(v[j + 8] / sd4 + z4), 0.0f), 15.0f);
+            w0 |= (uint32_t)q0 << mxq_bit4(j);
+            w1 |= (uint32_t)q1 << mxq_bit4(j);
+        }
+        uint32_t* tile = qweight + ((int64_t)rb * NC4 + c4) * MXQ_TILE_DW;
+        tile[mxq_c4(0, qt, r)] = w0;
+        tile[mxq_c4(1, qt, r)] = w1;
+    }
+}
+
+// ------------------------------------------------------------------------------------ //
+// launchers
+// ------------------------------------------------------------------------------------ //
+int mxq_launch_pack_codes(const uint8_t* codes2, const uint8_t* sc2, const float* zero2, const float* qs2,
+                          const float* qz2, const uint8_t* codes4, const uint8_t* sc4, const float* zero4,
+                          const float* qs4, const float* qz4, void* qweight, void* rowmeta, int N, int K,
+                          hipStream_t stream) {
+    const size_t bytes = (size_t)(N / 16) * mxq_nc4(K) * MXQ_TILE_DW * 4;
+    hipError_t e = hipMemsetAsync(qweight, 0, bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    const int64_t total = (int64_t)N * (K / 64);
+    mxq_pack_codes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(
+        codes2, sc2, zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4, (uint32_t*)qweight, (float4*)rowmeta, N, K);
+    return (int)hipGetLastError();
+}
+
+int mxq_launch_unpack(const void* qweight, const void* rowmeta, uint8_t* codes2, uint8_t* sc2, float* zero2,
+                      float* qs2, float* qz2, uint8_t* codes4, uint8_t* sc4, float* zero4, float* qs4, float* qz4,
+                      int N, int K, hipStream_t stream) {
+    const int64_t total = (int64_t)N * (K / 64);
+    mxq_unpack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(
+        (const uint32_t*)qweight, (const float4*)rowmeta, codes2, sc2, zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4,
+        N, K);
+    return (int)hipGetLastError();
+}
+
+int mxq_launch_dequant_f16(const void* qweight, const void* rowmeta, void* out, int N, int K, hipStream_t stream) {
+    const unsigned grid = (unsigned)((N / 16) * mxq_nc4(K));
+    mxq_dequant_f16_kernel<<<grid, 256, 0, stream>>>((const uint32_t*)qweight, (const float4*)rowmeta,
+                                                     (uint16_t*)out, N, K);
+    return (int)hipGetLastError();
+}
+
+int mxq_launch_quantize_pack(const void* W, int dtype, const uint8_t* dead, void* qweight, void* rowmeta, int N,
+                             int K, hipStream_t stream) {
+    if ((K / 64) % 4 != 0) {   // chunk padding inside the last tile of each row block must read as zeros
+        const size_t bytes = (size_t)(N / 16) * mxq_nc4(K) * MXQ_TILE_DW * 4;
+        hipError_t e = hipMemsetAsync(qweight, 0, bytes, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    mxq_quantize_pack_kernel<<<(unsigned)(N / 16), 256, 0, stream>>>(W, dtype, dead, (uint32_t*)qweight,
+                                                                      (float4*)rowmeta, N, K);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,173 @@
+"""Packed MXQ weights (format v1, csrc/mxq_format.h) and the ops on them.
+
+Every function here is a thin host wrapper: validate like the reference's launchers
+should have (SURVEY.md 8b "Errors"), allocate outputs with torch, pass raw device pointers
+and torch's current HIP stream to libmxq_hip.so.  No arithmetic happens in Python and
+there is no CPU path: tensors must live on a ROCm device.
+
+Reference semantics implemented by the kernels:
+  quantize_pack  MXQGPT.fasterquant       mxq_quant/lib/mxqgpt.py:387-448
+  unpack         Quantizer.quantize codes mxq_quant/lib/quantizer.py:14-16
+  dequant        Quantizer.dequantize     mxq_quant/lib/quantizer.py:19-20 (+ fp16 cast, mxqgpt.py:448)
+  linear         nn.Linear on that weight mxq_quant/main.py:85 / gemv_mxq_cuda.cu:39-208
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+_TORCH2CODE = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
+
+PARAM_KEYS = ("codes2", "sc2", "zero2", "qs2", "qz2", "codes4", "sc4", "zero4", "qs4", "qz4")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_gpu(*ts: torch.Tensor):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("mxq_amd ops run on the GPU only (no CPU fallback): got a CPU tensor")
+
+
+def check_shape(N: int, K: int):
+    if N <= 0 or K <= 0 or N % 16 != 0 or K % 64 != 0:
+        raise ValueError(f"MXQ layout needs out_features % 16 == 0 and in_features % 64 == 0, got [{N}, {K}]")
+
+
+def qweight_bytes(N: int, K: int) -> int:
+    check_shape(N, K)
+    return (N // 16) * ((K // 64 + 3) // 4) * 568 * 4
+
+
+@dataclass
+class PackedMXQ:
+    """qweight: int32 [N/16 * ceil(K/256) * 568]; rowmeta: float32 [N, 4]."""
+    qweight: torch.Tensor
+    rowmeta: torch.Tensor
+    N: int
+    K: int
+
+    @property
+    def device(self):
+        return self.qweight.device
+
+    def nbytes(self) -> int:
+        return self.qweight.numel() * 4 + self.rowmeta.numel() * 4
+
+    def bits_per_weight(self) -> float:
+        return 8.0 * self.nbytes() / (self.N * self.K)
+
+
+def _alloc(N: int, K: int, device) -> PackedMXQ:
+    lib = _lib.load()
+    nbytes = lib.mxq_qweight_bytes(N, K)
+    assert nbytes == qweight_bytes(N, K)
+    return PackedMXQ(torch.empty(nbytes // 4, dtype=torch.int32, device=device),
+                     torch.empty((N, 4), dtype=torch.float32, device=device), N, K)
+
+
+def quantize_pack(W: torch.Tensor, dead: Optional[torch.Tensor] = None) -> PackedMXQ:
+    """MXQ-quantise W [N, K] (fp16 / bf16 / fp32) on device and return the packed form."""
+    _need_gpu(W, dead)
+    if W.dim() != 2:
+        raise ValueError("weight must be 2-D [out_features, in_features]")
+    if W.dtype not in _TORCH2CODE:
+        raise ValueError(f"unsupported weight dtype {W.dtype}")
+    N, K = W.shape
+    check_shape(N, K)
+    W = W.contiguous()
+    dead_p = None
+    if dead is not None:
+        if dead.numel() != K:
+            raise ValueError("dead-column mask must have in_features entries")
+        dead = dead.to(device=W.device, dtype=torch.uint8).contiguous()
+        dead_p = dead.data_ptr()
+    lib = _lib.load()
+    p = _alloc(N, K, W.device)
+    with torch.cuda.device(W.device):
+        _lib.check(lib.mxq_quantize_pack(W.data_ptr(), _TORCH2CODE[W.dtype], dead_p, p.qweight.data_ptr(),
+                                         p.rowmeta.data_ptr(), N, K, _stream(W)), "mxq_quantize_pack")
+    return p
+
+
+def _param_shapes(N: int, K: int) -> Dict[str, tuple]:
+    G = 3 * K // 64
+    return dict(codes2=((N, 3 * K // 4), torch.uint8), sc2=((N, G), torch.uint8), zero2=((N, G), torch.float32),
+                qs2=((N // 16, G), torch.float32), qz2=((N // 16, G), torch.float32),
+                codes4=((N, K // 4), torch.uint8), sc4=((N,), torch.uint8), zero4=((N,), torch.float32),
+                qs4=((N // 16,), torch.float32), qz4=((N // 16,), torch.float32))
+
+
+def pack_codes(params: Dict[str, torch.Tensor], N: int, K: int) -> PackedMXQ:
+    """Pack integer codes + parameters (the output of Quantizer.quantize / find_params)."""
+    check_shape(N, K)
+    shapes = _param_shapes(N, K)
+    ts = []
+    for k in PARAM_KEYS:
+        t = params[k]
+        _need_gpu(t)
+        shape, dt = shapes[k]
+        if tuple(t.shape) != shape or t.dtype != dt:
+            raise ValueError(f"{k}: expected {shape} {dt}, got {tuple(t.shape)} {t.dtype}")
+        ts.append(t.contiguous())
+    lib = _lib.load()
+    p = _alloc(N, K, ts[0].device)
+    with torch.cuda.device(p.device):
+        _lib.check(lib.mxq_pack_codes(*[t.data_ptr() for t in ts], p.qweight.data_ptr(), p.rowmeta.data_ptr(), N, K,
+                                      _stream(p.qweight)), "mxq_pack_codes")
+    return p
+
+
+def unpack(p: PackedMXQ) -> Dict[str, torch.Tensor]:
+    """Integer unpack: codes and parameters exactly as packed."""
+    _need_gpu(p.qweight)
+    out = {k: torch.empty(shape, dtype=dt, device=p.device) for k, (shape, dt) in _param_shapes(p.N, p.K).items()}
+    lib = _lib.load()
+    with torch.cuda.device(p.device):
+        _lib.check(lib.mxq_unpack(p.qweight.data_ptr(), p.rowmeta.data_ptr(), *[out[k].data_ptr() for k in PARAM_KEYS],
+                                  p.N, p.K, _stream(p.qweight)), "mxq_unpack")
+    return out
+
+
+def dequant(p: PackedMXQ) -> torch.Tensor:
+    """Dense fp16 [N, K] fake-quant weight (bit-identical to the reference's write-back)."""
+    _need_gpu(p.qweight)
+    out = torch.empty((p.N, p.K), dtype=torch.float16, device=p.device)
+    lib = _lib.load()
+    with torch.cuda.device(p.device):
+        _lib.check(lib.mxq_dequant_f16(p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), p.N, p.K,
+                                       _stream(out)), "mxq_dequant_f16")
+    return out
+
+
+def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
+    """y = x @ dequant(p).T for x [..., K] fp16 -> [..., N] fp16 (fp32 accumulation).
+
+    path: "auto" (GEMV kernel for <= 4 tokens, MFMA GEMM otherwise), "gemm" or "gemv"."""
+    _need_gpu(x, p.qweight)
+    if x.dtype != torch.float16:
+        raise ValueError(f"activations must be float16 (W2/4 x A16), got {x.dtype}")
+    if x.shape[-1] != p.K:
+        raise ValueError(f"in_features mismatch: x has {x.shape[-1]}, weight has {p.K}")
+    if x.device != p.device:
+        raise ValueError("x and the packed weight live on different devices")
+    x2 = x.reshape(-1, p.K).contiguous()
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty((M, p.N), dtype=torch.float16, device=x.device)
+    elif out.shape != (M, p.N) or out.dtype != torch.float16 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float16 [tokens, out_features] tensor")
+    if M == 0:
+        return out.reshape(*x.shape[:-1], p.N)
+    lib = _lib.load()
+    fn = {"auto": lib.mxq_linear_f16, "gemm": lib.mxq_gemm_f16, "gemv": lib.mxq_gemv_f16}[path]
+    with torch.cuda.device(x.device):
+        _lib.check(fn(x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K,
+                      _stream(x2)), f"mxq_linear_f16[{path}]")
+    return out.reshape(*x.shape[:-1], p.N)

@@ -1,0 +1,228 @@
+"""QAT op surface with the reference's names and signatures
+(reference LLM-QAT/models/utils_quant.py), so that ``modeling_llama_quant.py`` /
+``train.py`` work with ``from mxq_amd.utils_quant import QuantizeLinear, SymQuantizer``
+(or by aliasing this module as ``models.utils_quant``).
+
+* ``MXAsymQuantizer`` (utils_quant.py:310-475) -- the hot path: forward and STE backward
+  each run as ONE fused HIP kernel (csrc/fakequant.hip) instead of ~1.7k-4.5k torch ops,
+  bit-identical to the reference in fp32 / bf16 / fp16.
+* ``QuantizeLinear`` (utils_quant.py:601-727) -- same constructor, same ``state_dict``
+  (``weight`` only), fake-quant weight then ``F.linear``.
+* ``SymQuantizer`` / ``AsymQuantizer`` (utils_quant.py:31-199) -- activation / KV
+  fake-quant; outside the hot path, kept as vectorised torch so the
+  reference's model file imports and runs; the README recipe (a_bits = kv_bits = 32)
+  never calls them.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+_CODE = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def mx_fake_quant(w: torch.Tensor, num_bits: int) -> torch.Tensor:
+    """MXAsymQuantizer.forward arithmetic on a 2-D weight (HIP kernel)."""
+    if not w.is_cuda:
+        raise ValueError("MXAsymQuantizer runs on the GPU only (no CPU fallback): got a CPU tensor")
+    if w.dim() != 2:
+        # the reference's 3-D / 4-D branches are dead (UnboundLocalError on `s`)
+        raise UnboundLocalError("MXAsymQuantizer: only the 2-D, non-layerwise branch of the reference is live")
+    if w.dtype not in _CODE:
+        raise ValueError(f"unsupported dtype {w.dtype}")
+    rows, cols = w.shape
+    if cols % 64 != 0:
+        raise ValueError(f"in_features must be a multiple of 64 for the MXQ layout, got {cols}")
+    w = w.contiguous()
+    out = torch.empty_like(w)
+    lib = _lib.load()
+    with torch.cuda.device(w.device):
+        _lib.check(lib.mxq_fakequant_fwd(w.data_ptr(), out.data_ptr(), rows, cols, int(num_bits), _CODE[w.dtype],
+                                         _stream(w)), "mxq_fakequant_fwd")
+    return out
+
+
+def ste_clip_backward(grad_out: torch.Tensor, w: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+    """MXAsymQuantizer.backward: grad where lo < w < hi, else 0 (HIP kernel)."""
+    if not (grad_out.is_cuda and w.is_cuda):
+        raise ValueError("MXAsymQuantizer backward runs on the GPU only (no CPU fallback)")
+    if grad_out.dtype != w.dtype:
+        grad_out = grad_out.to(w.dtype)
+    grad_out = grad_out.contiguous()
+    w = w.contiguous()
+    gin = torch.empty_like(grad_out)
+    lib = _lib.load()
+    with torch.cuda.device(w.device):
+        _lib.check(lib.mxq_fakequant_bwd(grad_out.data_ptr(), w.data_ptr(), gin.data_ptr(), w.numel(), float(lo),
+                                         float(hi), _CODE[w.dtype], _stream(w)), "mxq_fakequant_bwd")
+    return gin
+
+
+class MXAsymQuantizer(torch.autograd.Function):
+    """Mixed 2/4-bit min-max fake quantiser; ``apply(input, clip_val, num_bits, layerwise)``."""
+
+    @staticmethod
+    def forward(ctx, input, clip_val, num_bits, layerwise):
+        if layerwise:
+            raise UnboundLocalError("MXAsymQuantizer: layerwise=True is a dead branch in the reference "
+                                    "(local variable 's' referenced before assignment)")
+        ctx.save_for_backward(input, clip_val)
+        return mx_fake_quant(input, num_bits)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, clip_val = ctx.saved_tensors
+        lo, hi = (float(v) for v in clip_val.tolist())   # CPU tensor in the reference (:636): no device sync
+        return ste_clip_backward(grad_output, input, lo, hi), None, None, None
+
+
+def _ste_clip_torch(grad_output, input, clip_val):
+    g = grad_output.clone()
+    g[input.ge(clip_val[1])] = 0
+    g[input.le(clip_val[0])] = 0
+    return g
+
+
+def _dim1_groups(input, groupsize):
+    """The reference's activation quantisers slice ``input[:, i1:i2]`` -- dimension 1 --
+    with a group count derived from the LAST dimension (utils_quant.py:57-66, 134-147).
+    Returns (group id per index of dim 1, number of covered indices)."""
+    n_groups = input.shape[-1] // groupsize
+    covered = min(input.shape[1], n_groups * groupsize)
+    return n_groups, covered
+
+
+class SymQuantizer(torch.autograd.Function):
+    """Symmetric group-128 fake quantiser for activations / KV (utils_quant.py:31-102)."""
+
+    @staticmethod
+    def forward(ctx, input, clip_val, num_bits, layerwise):
+        ctx.save_for_backward(input, clip_val)
+        if layerwise:
+            max_input = input.abs().max().expand_as(input)
+        elif input.dim() <= 3:
+            _, covered = _dim1_groups(input, 128)
+            max_input = torch.zeros_like(input)
+            if covered > 0:
+                head = input[:, :covered].abs()
+                if input.dim() == 2:     # groups of 128 columns, per row
+                    g = head.reshape(input.shape[0], covered // 128, 128).amax(dim=-1, keepdim=True)
+                    max_input[:, :covered] = g.expand(-1, -1, 128).reshape(input.shape[0], covered)
+                else:                    # 3-D: the slice runs over dim 1, the max over the last dim
+                    max_input[:, :covered] = head.amax(dim=-1, keepdim=True).expand_as(head)
+        elif input.dim() == 4:
+            m = input.abs().flatten(2).amax(dim=-1)
+            max_input = m[:, :, None, None].expand_as(input)
+        else:
+            raise ValueError
+        s = (2 ** (num_bits - 1) - 1) / (max_input + 1e-6)
+        return torch.round(input * s).div(s + 1e-6)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, clip_val = ctx.saved_tensors
+        return _ste_clip_torch(grad_output, input, clip_val), None, None, None
+
+
+class AsymQuantizer(torch.autograd.Function):
+    """Asymmetric group-8 min-max fake quantiser (utils_quant.py:105-199)."""
+
+    @staticmethod
+    def forward(ctx, input, clip_val, num_bits, layerwise):
+        ctx.save_for_backward(input, clip_val)
+        if layerwise:
+            beta = input.min()
+            alpha = input.max() - beta
+        elif input.dim() <= 3:
+            _, covered = _dim1_groups(input, 8)
+            alpha = torch.zeros_like(input)
+            beta = torch.zeros_like(input)
+            if covered > 0:
+                head = input[:, :covered]
+                if input.dim() == 2:
+                    g = head.reshape(input.shape[0], covered // 8, 8)
+                    lo, hi = g.amin(dim=-1, keepdim=True), g.amax(dim=-1, keepdim=True)
+                    alpha[:, :covered] = (hi - lo).expand(-1, -1, 8).reshape(input.shape[0], covered)
+                    beta[:, :covered] = lo.expand(-1, -1, 8).reshape(input.shape[0], covered)
+                else:
+                    lo, hi = head.amin(dim=-1, keepdim=True), head.amax(dim=-1, keepdim=True)
+                    alpha[:, :covered] = (hi - lo).expand_as(head)
+                    beta[:, :covered] = lo.expand_as(head)
+        elif input.dim() == 4:
+            flat = input.flatten(2)
+            lo, hi = flat.amin(dim=-1), flat.amax(dim=-1)
+            alpha = (hi - lo)[:, :, None, None].expand_as(input)
+            beta = lo[:, :, None, None].expand_as(input)
+        else:
+            raise ValueError
+        s = 2 ** num_bits - 1
+        normalized = (input - beta) / (alpha + 1e-8)
+        return torch.round(normalized * s).div(s) * (alpha + 1e-8) + beta
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, clip_val = ctx.saved_tensors
+        return _ste_clip_torch(grad_output, input, clip_val), None, None, None
+
+
+class QuantizeLinear(nn.Linear):
+    """nn.Linear(bias=False) whose weight is fake-quantised on every forward
+    (utils_quant.py:601-727).  ``w_bits >= 32``: plain; ``2 <= w_bits < 32``: MXAsymQuantizer
+    (HIP); ``w_bits < 2``: the reference's sign / clipped-uniform quantisers."""
+
+    def __init__(self, *kargs, symmetric=True, bias=False, w_bits=32, a_bits=32, act_layerwise=False,
+                 weight_layerwise=False, is_qk=False):
+        super().__init__(*kargs, bias=False)    # the reference ignores `bias` as well (:613)
+        self.w_bits = w_bits
+        self.a_bits = a_bits
+        self.act_layerwise = act_layerwise
+        self.weight_layerwise = weight_layerwise
+        self.is_qk = is_qk
+        if 2 < self.a_bits < 32:
+            self.act_quantizer = SymQuantizer if symmetric else AsymQuantizer
+
+    def _legacy_weight(self, w):
+        """w_bits == 1 (sign with a group-8 mean-abs scale) and the w_bits < 1 fallback
+        (:649-715); straight-through via (q - w).detach() + w."""
+        if self.w_bits == 1:
+            if self.weight_layerwise:
+                scale = w.abs().mean().detach()
+            else:
+                scale = torch.zeros_like(w)
+                covered = (w.shape[-1] // 8) * 8
+                g = w[:, :covered].abs().reshape(w.shape[0], covered // 8, 8).mean(dim=-1, keepdim=True)
+                scale[:, :covered] = g.expand(-1, -1, 8).reshape(w.shape[0], covered).detach()
+            q = scale * torch.sign(w / scale)
+        else:
+            levels = 2 ** (self.w_bits - 1)
+            clip = 1 - 1e-2
+            if self.weight_layerwise:
+                scale = 2 * w.abs().mean().detach()
+            else:
+                scale = 2 * w.abs().mean(dim=1, keepdim=True).detach()
+            q = scale * (torch.round(torch.clamp(w / scale, -clip, clip) * levels - 0.5) + 0.5) / levels
+        return q.detach() - w.detach() + w
+
+    def forward(self, input_):
+        assert self.weight.dim() == 2
+        if self.w_bits >= 32:
+            weight = self.weight
+        elif self.w_bits >= 2:
+            weight_clip_val = torch.tensor([-2.0, 2.0])      # CPU constant, as in the reference (:636)
+            weight = MXAsymQuantizer.apply(self.weight, weight_clip_val, self.w_bits, self.weight_layerwise)
+        else:
+            weight = self._legacy_weight(self.weight)
+        if 2 < self.a_bits < 32:
+            act_clip_val = torch.tensor([-2.0, 2.0])
+            input_ = self.act_quantizer.apply(input_, act_clip_val, self.a_bits, self.act_layerwise)
+        out = F.linear(input_, weight)
+        if self.bias is not None:
+            out += self.bias.view(1, -1).expand_as(out)
+        return out

@@ -1,0 +1,82 @@
+"""Drop-in for the reference's native module ``mxq_inference_engine``
+(mxq_quant/cuda_kernel/csrc/pybind.cpp:6-10, built by cuda_kernel/setup.py:32-44).
+
+Same two callables, same positional signatures, tensors on ``torch.device('cuda')`` (the HIP
+device on ROCm), so ``cuda_kernel/test_correct_gemv.py`` and ``test_mxq_gemv.py`` run
+unmodified.  Implemented as ctypes calls into libmxq_hip.so; unlike the reference the
+operands are validated, the kernels run on PyTorch's current stream, and an unsupported
+``group_size`` raises instead of returning uninitialised memory.
+"""
+from __future__ import annotations
+
+import torch
+
+from mxq_amd import _lib
+
+
+def _chk(t, name, dtype):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")     # data_ptr<at::Half>() throws in the reference
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def gemv_forward_cuda(in_feats, kernel, scaling_factors, zeros, group_size):
+    """Uniform 4-bit group GEMV (reference gemv_cuda.h:4-9). Returns f16 [B, OC]."""
+    _chk(in_feats, "in_feats", torch.float16); _chk(kernel, "kernel", torch.int32)
+    _chk(scaling_factors, "scaling_factors", torch.float16); _chk(zeros, "zeros", torch.int32)
+    B, IC = in_feats.shape
+    OC = kernel.shape[0]
+    if kernel.shape[1] * 8 != IC:
+        raise ValueError("kernel must be [OC, IC/8] int32")
+    ng = IC // int(group_size) if group_size in (32, 64, 128) else 0
+    zeros_w = ((ng + 7) // 8 + 3) // 4 * 4
+    if ng and (zeros.numel() < OC * ((ng + 7) // 8) or scaling_factors.numel() < OC * ng):
+        raise ValueError("zeros / scaling_factors too small for IC / group_size groups")
+    if ng and (zeros.shape[-1] != zeros_w or scaling_factors.shape[-1] != zeros_w * 8):
+        raise ValueError(f"the kernel format pads the group dimension: zeros [OC, {zeros_w}], "
+                         f"scaling_factors [OC, {zeros_w * 8}] (gemv_cuda.cu:54-59)")
+    out = torch.empty((B, OC), dtype=in_feats.dtype, device=in_feats.device)
+    lib = _lib.load()
+    with torch.cuda.device(in_feats.device):
+        _lib.check(lib.mxq_gemv_awq_f16(in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(),
+                                        zeros.data_ptr(), out.data_ptr(), B, IC, OC, int(group_size),
+                                        torch.cuda.current_stream().cuda_stream), "gemv_forward_cuda")
+    return out
+
+
+def gemv_mxq_forward_cuda(in_feats, kernel, kernel_last, zeros_and_scales, scales_2nd, zeros_2nd, scales_4b,
+                          zeros_4b, group_size):
+    """MXQ "2.8-bit" prototype-format GEMV (reference gemv_mxq_cuda.h:4-12). Returns f16 [B, OC]."""
+    _chk(in_feats, "in_feats", torch.float16); _chk(kernel, "kernel", torch.int32)
+    _chk(kernel_last, "kernel_last", torch.int32); _chk(zeros_and_scales, "zeros_and_scales", torch.int32)
+    _chk(scales_2nd, "scales_2nd", torch.float16); _chk(zeros_2nd, "zeros_2nd", torch.int32)
+    _chk(scales_4b, "scales_4b", torch.float16); _chk(zeros_4b, "zeros_4b", torch.int32)
+    B, IC = in_feats.shape
+    OC = kernel.shape[0]
+    need = dict(kernel=OC * IC // 16, kernel_last=OC * IC // 64, zeros_and_scales=OC * 32,
+                scales_2nd=(OC // 4) * 192, zeros_2nd=(OC // 4) * 32, scales_4b=OC, zeros_4b=OC // 8)
+    have = dict(kernel=kernel, kernel_last=kernel_last, zeros_and_scales=zeros_and_scales, scales_2nd=scales_2nd,
+                zeros_2nd=zeros_2nd, scales_4b=scales_4b, zeros_4b=zeros_4b)
+    if zeros_2nd.numel() < need["zeros_2nd"]:
+        # cuda_kernel/test_mxq_gemv.py:71 allocates zeros_2nd as [OC/4, 16] although the kernel
+        # indexes it with a row stride of 32 (gemv_mxq_cuda.cu:59,70): the reference reads out of
+        # bounds there.  To keep that script running unmodified the operand is zero-padded
+        # instead (the script checks no values).
+        padded = torch.zeros(need["zeros_2nd"], dtype=torch.int32, device=zeros_2nd.device)
+        padded[: zeros_2nd.numel()] = zeros_2nd.reshape(-1)
+        have["zeros_2nd"] = zeros_2nd = padded
+    for k, n in need.items():
+        if have[k].numel() < n:
+            raise ValueError(f"{k} has {have[k].numel()} elements, the kernel reads {n}")
+    out = torch.empty((B, OC), dtype=in_feats.dtype, device=in_feats.device)
+    lib = _lib.load()
+    with torch.cuda.device(in_feats.device):
+        _lib.check(lib.mxq_gemv_proto_f16(in_feats.data_ptr(), kernel.data_ptr(), kernel_last.data_ptr(),
+                                          zeros_and_scales.data_ptr(), scales_2nd.data_ptr(), zeros_2nd.data_ptr(),
+                                          scales_4b.data_ptr(), zeros_4b.data_ptr(), out.data_ptr(), B, IC, OC,
+                                          int(group_size), torch.cuda.current_stream().cuda_stream),
+                   "gemv_mxq_forward_cuda")
+    return out

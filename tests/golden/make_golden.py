@@ -17,6 +17,7 @@ Reference entry points exercised:
   G4 qlinear     models.utils_quant.QuantizeLinear fwd/bwd (fp32, bf16).
   G5 block_small models.modeling_llama_quant.LlamaDecoderLayer fwd/bwd (w_bits=2).
   G6 kat         constants of cuda_kernel/test_correct_gemv.py (expected == 4096).
+  G7 act         models.utils_quant.SymQuantizer / AsymQuantizer fwd/bwd (2-D, 3-D, 4-D).
 """
 import hashlib
 import os
@@ -39,7 +40,7 @@ torch.cuda.empty_cache = lambda *a, **k: None
 
 import lib.mxqgpt as ref_mxqgpt          # noqa: E402
 import lib.quantizer as ref_quantizer    # noqa: E402
-from models.utils_quant import MXAsymQuantizer, QuantizeLinear   # noqa: E402
+from models.utils_quant import AsymQuantizer, MXAsymQuantizer, QuantizeLinear, SymQuantizer   # noqa: E402
 
 
 def bf16_bits(t):
@@ -247,6 +248,27 @@ def g6_kat():
         shape_zeros_4b=np.array([512]))
 
 
+def g7_act_quantizers():
+    """SymQuantizer / AsymQuantizer (utils_quant.py:31-199): outside the hot path, but
+    QuantizeLinear(a_bits=16) and the decoder layer call SymQuantizer on activations."""
+    out = {}
+    clip = torch.tensor([-2.0, 2.0])
+    cases = {"w2d": (8, 256), "a3d": (2, 8, 256), "a3d_long": (1, 140, 128), "s4d": (1, 2, 4, 4)}
+    for cname, shape in cases.items():
+        for qname, Q in (("sym", SymQuantizer), ("asym", AsymQuantizer)):
+            for bits in (4, 16):
+                for layerwise in (False, True):
+                    torch.manual_seed(100 * len(cname) + bits)
+                    x = (torch.randn(*shape) * 1.2).requires_grad_()
+                    y = Q.apply(x, clip, bits, layerwise)
+                    go = torch.randn(*shape)
+                    y.backward(go)
+                    key = f"{cname}_{qname}_b{bits}_{int(layerwise)}"
+                    out[key + "_x"], out[key + "_y"] = x.detach().numpy(), y.detach().numpy()
+                    out[key + "_gy"], out[key + "_gx"] = go.numpy(), x.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g7_act_quantizers.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     g1_ptq_small(); print("G1 ok")
@@ -255,3 +277,4 @@ if __name__ == "__main__":
     g4_qlinear(); print("G4 ok")
     g5_block_small(); print("G5 ok")
     g6_kat(); print("G6 ok")
+    g7_act_quantizers(); print("G7 ok")

@@ -1,0 +1,82 @@
+"""Host-side logic that needs no GPU: error behaviour of the wrappers, module surface,
+state_dict layout, and the (out-of-hot-path) activation quantisers against golden G7."""
+import numpy as np
+import pytest
+import torch
+
+from mxq_amd import packing
+from mxq_amd.quant_linear import QuantLinear
+from mxq_amd.utils_quant import AsymQuantizer, MXAsymQuantizer, QuantizeLinear, SymQuantizer
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(ValueError, match="GPU only"):
+        packing.quantize_pack(torch.zeros(16, 64, dtype=torch.float16))
+    with pytest.raises(ValueError, match="GPU only"):
+        MXAsymQuantizer.apply(torch.zeros(16, 64), torch.tensor([-2.0, 2.0]), 2, False)
+    lin = QuantizeLinear(64, 16, w_bits=2, a_bits=32)
+    with pytest.raises(ValueError, match="GPU only"):
+        lin(torch.zeros(1, 64))
+
+
+def test_dead_branches_raise_like_the_reference():
+    with pytest.raises(UnboundLocalError):
+        MXAsymQuantizer.apply(torch.zeros(16, 64), torch.tensor([-2.0, 2.0]), 2, True)
+
+
+def test_shape_checks():
+    for N, K in ((15, 64), (16, 100), (0, 64)):
+        with pytest.raises(ValueError):
+            packing.check_shape(N, K)
+    assert packing.qweight_bytes(4096, 4096) == 9306112
+    with pytest.raises(ValueError):
+        QuantLinear(100, 16)
+
+
+def test_quantlinear_state_dict_layout():
+    m = QuantLinear(256, 64, bias=True)
+    sd = m.state_dict()
+    assert set(sd) == {"qweight", "rowmeta", "fmt", "bias"}
+    assert sd["qweight"].dtype == torch.int32 and sd["qweight"].numel() == 4 * 1 * 568
+    assert sd["rowmeta"].shape == (64, 4) and sd["fmt"].tolist() == [1, 64, 256]
+    m2 = QuantLinear(256, 64, bias=True)
+    m2.load_state_dict(sd)
+    assert "QuantLinear" in repr(m2) and "bit/weight" in repr(m2)
+
+
+def test_quantizelinear_surface_matches_reference():
+    lin = QuantizeLinear(256, 64, w_bits=32, a_bits=32)
+    assert set(lin.state_dict()) == {"weight"} and lin.bias is None        # utils_quant.py:613
+    x = torch.randn(2, 3, 256)
+    assert torch.equal(lin(x), torch.nn.functional.linear(x, lin.weight))
+    assert QuantizeLinear(256, 64, w_bits=2, a_bits=16).act_quantizer is SymQuantizer
+    assert QuantizeLinear(256, 64, w_bits=2, a_bits=8, symmetric=False).act_quantizer is AsymQuantizer
+    # w_bits == 1 sign path runs in torch and keeps the straight-through gradient
+    l1 = QuantizeLinear(64, 16, w_bits=1)
+    y = l1(torch.randn(4, 64)); y.sum().backward()
+    assert l1.weight.grad is not None and torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("q", ["sym", "asym"])
+@pytest.mark.parametrize("case", ["w2d", "a3d", "a3d_long", "s4d"])
+def test_g7_activation_quantizers(q, case):
+    from tests.conftest import load_golden
+    g7 = load_golden("g7_act_quantizers.npz")
+    Q = SymQuantizer if q == "sym" else AsymQuantizer
+    clip = torch.tensor([-2.0, 2.0])
+    for bits in (4, 16):
+        for lw in (0, 1):
+            key = f"{case}_{q}_b{bits}_{lw}"
+            x = torch.from_numpy(g7[key + "_x"]).requires_grad_()
+            y = Q.apply(x, clip, bits, bool(lw))
+            y.backward(torch.from_numpy(g7[key + "_gy"]))
+            assert np.array_equal(y.detach().numpy(), g7[key + "_y"]), key
+            assert np.array_equal(x.grad.numpy(), g7[key + "_gx"]), key
+
+
+def test_inference_engine_validation():
+    import mxq_inference_engine as eng
+    x = torch.zeros(1, 4096, dtype=torch.float16)
+    with pytest.raises(ValueError):
+        eng.gemv_forward_cuda(x, x, x, x, 128)          # CPU tensors are rejected
+    assert callable(eng.gemv_mxq_forward_cuda)
