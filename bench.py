@@ -58,6 +58,8 @@ def cpu_baseline(dev, budget_s=12.0):
     """Config 1 of BASELINE.json on the host cores: one [4096, 4096] MXQ Linear, batch 1 x
     seq 128 -> dequant (fp32 scale*(q-zero), fp16 cast) + F.linear per call."""
     from oracle import cpu_linear
+    # the 1-GPU box gives this job a 16-core CPU share; more torch threads than that only thrash
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     N = K = 4096
     M = 128
     g = torch.Generator(device=dev).manual_seed(0)
