@@ -91,6 +91,10 @@ int mxq_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* 
                  void* stream);
 int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                  void* stream); /* M <= 4 */
+/* mxq_gemm_f16 with an explicit kernel variant, for A/B benchmarking and tests:
+ * 0 = auto, 1 = 128x128 two-stage kernel, 2 = 256x128 LDS-DMA-pipelined kernel. */
+int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                    int variant, void* stream);
 
 /* MXAsymQuantizer.forward (utils_quant.py:316-462; 2-D, layerwise=False branch):
  * fake-quantise w[rows, cols] of `dtype` into out (same shape/dtype), bit-identical to

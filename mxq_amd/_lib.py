@@ -35,6 +35,7 @@ SIGNATURES = {
     "mxq_dequant_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mxq_linear_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "mxq_gemm_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
+    "mxq_gemm_f16_ex": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_gemv_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "mxq_fakequant_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_fakequant_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),

@@ -18,7 +18,7 @@ int mxq_version(void) { return (MXQ_FORMAT_VERSION << 16) | 1; }
 
 size_t mxq_qweight_bytes(int N, int K) {
     if (!shape_ok(N, K)) return 0;
-    return (size_t)(N / 16) * mxq_nc4(K) * MXQ_TILE_DW * 4;
+    return (size_t)(N / 16) * (K / 64) * MXQ_BLK_BYTES;
 }
 
 size_t mxq_rowmeta_bytes(int N) { return N > 0 && N % 16 == 0 ? (size_t)N * 16 : 0; }
@@ -74,6 +74,17 @@ int mxq_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* 
                  void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+}
+
+int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                    int variant, void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    switch (variant) {
+        case 0: return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+        case 1: return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+        case 2: return mxq_launch_gemm2_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+    }
+    return MXQ_E_SHAPE;
 }
 
 int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void mxq_gemm_f16_kernel(const uint16_t* __
                                                               int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NT = K / BK, NC4 = mxq_nc4(K);
+    const int NT = K / BK;
 
     // XCD-aware tile order: blocks b, b+8, ... share an L2; give each XCD a contiguous run
     // of tiles (bijective remap, cdna guide T1).  Placement only affects speed.
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void mxq_gemm_f16_kernel(const uint16_t* __
     int gn = n0 + b_row;
     gn = gn < N ? gn : N - 1;
     const int b_r = gn & 15;
-    const uint32_t* b_tile0 = qweight + (int64_t)(gn >> 4) * NC4 * MXQ_TILE_DW;
+    const uint32_t* b_tile0 = qweight + (int64_t)(gn >> 4) * NT * MXQ_BLK_DW;
     float s4 = 0.f, z4 = 0.f;
     if (qp == 1) {
         const float4 m = rowmeta[gn];
@@ -101,22 +101,21 @@ __global__ __launch_bounds__(256, 2) void mxq_gemm_f16_kernel(const uint16_t* __
         }
     };
     auto load_b = [&](int t, BStage& st) {
-        const uint32_t* tile = b_tile0 + (int64_t)(t >> 2) * MXQ_TILE_DW;
-        const int cc = t & 3;
-        st.sc = ((const uint16_t*)tile)[mxq_sc_u16(cc, b_r)];
+        const uint32_t* tile = b_tile0 + (int64_t)t * MXQ_BLK_DW;
+        st.sc = ((const uint16_t*)tile)[mxq_sc_u16(b_r)];
         if (qp == 0) {
-            st.c0 = tile[mxq_c2(0, cc, b_r)];
-            st.c1 = tile[mxq_c2(1, cc, b_r)];
-            st.z0 = tile[mxq_z2(0, cc, b_r)];
-            st.z1 = tile[mxq_z2(1, cc, b_r)];
-            st.qa = *(const uint2*)(tile + mxq_qq(cc, 0));
-            st.qb = *(const uint2*)(tile + mxq_qq(cc, 1));
+            st.c0 = tile[mxq_c2(0, b_r)];
+            st.c1 = tile[mxq_c2(1, b_r)];
+            st.z0 = tile[mxq_z2(0, b_r)];
+            st.z1 = tile[mxq_z2(1, b_r)];
+            st.qa = *(const uint2*)(tile + mxq_qq(0));
+            st.qb = *(const uint2*)(tile + mxq_qq(1));
         } else {
-            st.c0 = tile[mxq_c2(2, cc, b_r)];
-            st.c1 = tile[mxq_c4(0, cc, b_r)];
-            st.z0 = tile[mxq_z2(2, cc, b_r)];
-            st.z1 = tile[mxq_c4(1, cc, b_r)];
-            st.qa = *(const uint2*)(tile + mxq_qq(cc, 2));
+            st.c0 = tile[mxq_c2(2, b_r)];
+            st.c1 = tile[mxq_c4(0, b_r)];
+            st.z0 = tile[mxq_z2(2, b_r)];
+            st.z1 = tile[mxq_c4(1, b_r)];
+            st.qa = *(const uint2*)(tile + mxq_qq(2));
             st.qb = make_uint2(0u, 0u);
         }
     };
@@ -204,13 +203,16 @@ __global__ __launch_bounds__(256, 2) void mxq_gemm_f16_kernel(const uint16_t* __
 
 int mxq_launch_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm_f16_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    // tokens <= 128 fit one 128-row tile; beyond that the 256 x 128 pipelined kernel wins
+    if (M > 128) return mxq_launch_gemm2_f16(x, qweight, rowmeta, y, M, N, K, stream);
+    return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, stream);
+}
+
+int mxq_launch_gemm1_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                         hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     mxq_gemm_f16_kernel<<<tiles_m * tiles_n, 256, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m,

@@ -4,12 +4,11 @@
 // Native counterpart of the reference's fused unpack+dot kernel
 // gemv_mxq_kernel_g16_v0 (mxq_quant/cuda_kernel/csrc/quantization/gemv_mxq_cuda.cu:39-208)
 // -- same idea (never materialise fp16 weights in memory), different everything else:
-//   * HBM-bound: every packed byte is read exactly once, 256 contiguous bytes per wave
-//     load (format v1: fields are [chunk-in-tile][row]-minor), straight to VGPRs
+//   * HBM-bound: every packed byte is read exactly once; a wave consumes 4 consecutive
+//     16x64 blocks (2304 contiguous bytes) per iteration, straight to VGPRs
 //     (no LDS round trip for weights; cdna guide section 5, "GEMV / M <= 16" row).
 //   * one workgroup per 16-row block (N/16 >= 256 workgroups for Llama shapes), 8 waves
-//     split K; lane -> (row r = lane & 15, chunk-in-tile cs = lane >> 4), i.e. a wave
-//     consumes one 16 x 256 tile (2272 B) per iteration.
+//     split K; lane -> (row r = lane & 15, chunk slot cs = lane >> 4).
 //   * activations are staged once per workgroup in LDS as fp16 and read as broadcast
 //     ds_read_b128; products use v_dot2_f32_f16 on the LUT-selected fp16 pairs.
 //   * wave64 reduction: 2 xor-shuffles over the 4 chunk slots, then 8 waves through LDS.
@@ -43,7 +42,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, cs = lane >> 4;
     const int rb = blockIdx.x;
-    const int NC = K / 64, NC4 = mxq_nc4(K);
+    const int NC = K / 64, NC4 = (NC + 3) / 4;
 
     // stage x[0..MB) in LDS (rows beyond M are zero)
     {
@@ -63,24 +62,24 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = 0.f;
 
-    const uint32_t* tiles = qweight + (int64_t)rb * NC4 * MXQ_TILE_DW;
+    const uint32_t* tiles = qweight + (int64_t)rb * NC * MXQ_BLK_DW;
     for (int c4 = wave; c4 < NC4; c4 += GEMV_WAVES) {
-        const uint32_t* tile = tiles + (int64_t)c4 * MXQ_TILE_DW;
         const int chunk = c4 * 4 + cs;
-        // 12 loads, each 256 contiguous bytes across the wave (QQ: 4 distinct 8-B words)
+        if (chunk >= NC) continue;   // ragged tail: K/64 not a multiple of 4
+        const uint32_t* tile = tiles + (int64_t)chunk * MXQ_BLK_DW;
+        // the wave reads 4 consecutive blocks = 2304 contiguous bytes; each load touches four
+        // 64-B segments (one per chunk slot)
         uint32_t c2w[3], z2w[3], c4w[2];
         uint2 qq[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-            c2w[g] = tile[mxq_c2(g, cs, r)];
-            z2w[g] = tile[mxq_z2(g, cs, r)];
-            qq[g] = *(const uint2*)(tile + mxq_qq(cs, g));
+            c2w[g] = tile[mxq_c2(g, r)];
+            z2w[g] = tile[mxq_z2(g, r)];
+            qq[g] = *(const uint2*)(tile + mxq_qq(g));
         }
-        c4w[0] = tile[mxq_c4(0, cs, r)];
-        c4w[1] = tile[mxq_c4(1, cs, r)];
-        const uint32_t scw = ((const uint16_t*)tile)[mxq_sc_u16(cs, r)];
-        if (chunk >= NC) continue;   // chunk padding of the last tile (all-zero words anyway)
-
+        c4w[0] = tile[mxq_c4(0, r)];
+        c4w[1] = tile[mxq_c4(1, r)];
+        const uint32_t scw = ((const uint16_t*)tile)[mxq_sc_u16(r)];
         const char* xk = smem + (size_t)chunk * 128;
         uint32_t o[8];
 #pragma unroll

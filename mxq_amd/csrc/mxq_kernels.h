@@ -21,6 +21,10 @@ int mxq_launch_quantize_pack(const void* W, int dtype, const uint8_t* dead, void
                              int K, hipStream_t stream);
 int mxq_launch_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream);
+int mxq_launch_gemm1_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                         hipStream_t stream);   // 128x128 tile, two LDS stages (gemm.hip)
+int mxq_launch_gemm2_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                         hipStream_t stream);   // 256x128 tile, LDS-DMA rings, counted waits (gemm2.hip)
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream);
 int mxq_launch_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype,

@@ -22,15 +22,17 @@ __global__ void mxq_pack_codes_kernel(const uint8_t* __restrict__ codes2, const 
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)N * NC) return;
     const int n = (int)(idx / NC), c = (int)(idx % NC);
-    uint32_t* tile = qweight + mxq_tile_index(n, c, K) * MXQ_TILE_DW;
-    const int cc = c & 3, r = n & 15;
-    mxq_pack_row_chunk(tile, cc, r, codes2 + (int64_t)n * NC * 48 + c * 48, sc2 + (int64_t)n * NC * 3 + c * 3,
+    uint32_t* tile = qweight + mxq_blk_index(n, c, K) * MXQ_BLK_DW;
+    const int r = n & 15;
+    mxq_pack_row_chunk(tile, r, codes2 + (int64_t)n * NC * 48 + c * 48, sc2 + (int64_t)n * NC * 3 + c * 3,
                        zero2 + (int64_t)n * NC * 3 + c * 3, codes4 + (int64_t)n * NC * 16 + c * 16);
     if (r == 0) {
         for (int g = 0; g < 3; ++g) {
-            tile[mxq_qq(cc, g)] = __float_as_uint(qs2[(int64_t)(n / 16) * NC * 3 + c * 3 + g]);
-            tile[mxq_qq(cc, g) + 1] = __float_as_uint(qz2[(int64_t)(n / 16) * NC * 3 + c * 3 + g]);
+            tile[mxq_qq(g)] = __float_as_uint(qs2[(int64_t)(n / 16) * NC * 3 + c * 3 + g]);
+            tile[mxq_qq(g) + 1] = __float_as_uint(qz2[(int64_t)(n / 16) * NC * 3 + c * 3 + g]);
         }
+        tile[mxq_qq(3)] = 0u;   // unused slot: keep the packed bytes deterministic
+        tile[mxq_qq(3) + 1] = 0u;
     }
     if (c == 0) rowmeta[n] = make_float4(zero4[n], (float)sc4[n], qs4[n / 16], qz4[n / 16]);
 }
@@ -44,14 +46,14 @@ __global__ void mxq_unpack_kernel(const uint32_t* __restrict__ qweight, const fl
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)N * NC) return;
     const int n = (int)(idx / NC), c = (int)(idx % NC);
-    const uint32_t* tile = qweight + mxq_tile_index(n, c, K) * MXQ_TILE_DW;
-    const int cc = c & 3, r = n & 15;
-    mxq_unpack_row_chunk(tile, cc, r, codes2 + (int64_t)n * NC * 48 + c * 48, sc2 + (int64_t)n * NC * 3 + c * 3,
+    const uint32_t* tile = qweight + mxq_blk_index(n, c, K) * MXQ_BLK_DW;
+    const int r = n & 15;
+    mxq_unpack_row_chunk(tile, r, codes2 + (int64_t)n * NC * 48 + c * 48, sc2 + (int64_t)n * NC * 3 + c * 3,
                          zero2 + (int64_t)n * NC * 3 + c * 3, codes4 + (int64_t)n * NC * 16 + c * 16);
     if (r == 0) {
         for (int g = 0; g < 3; ++g) {
-            qs2[(int64_t)(n / 16) * NC * 3 + c * 3 + g] = __uint_as_float(tile[mxq_qq(cc, g)]);
-            qz2[(int64_t)(n / 16) * NC * 3 + c * 3 + g] = __uint_as_float(tile[mxq_qq(cc, g) + 1]);
+            qs2[(int64_t)(n / 16) * NC * 3 + c * 3 + g] = __uint_as_float(tile[mxq_qq(g)]);
+            qz2[(int64_t)(n / 16) * NC * 3 + c * 3 + g] = __uint_as_float(tile[mxq_qq(g) + 1]);
         }
     }
     if (c == 0) {
@@ -67,31 +69,31 @@ __global__ void mxq_unpack_kernel(const uint32_t* __restrict__ qweight, const fl
 
 // ------------------------------------------------------------------------------------ //
 // dequant to a dense fp16 [N, K] matrix (bit-exact fake-quant weight, mxqgpt.py:448).
-// One thread per (row, chunk quarter): 16 weights = 32 B.  Block = 256 threads covers a
-// 16-row x 4-chunk tile: thread -> (quarter, cc, r).
+// One thread per (row, chunk quarter): 16 weights = 32 B.  Block = 256 threads covers
+// 16 rows x 4 chunks: thread -> (quarter, chunk slot, r).
 // ------------------------------------------------------------------------------------ //
 __global__ __launch_bounds__(256) void mxq_dequant_f16_kernel(const uint32_t* __restrict__ qweight,
                                                               const float4* __restrict__ rowmeta,
                                                               uint16_t* __restrict__ out, int N, int K) {
-    const int NC = K / 64, NC4 = mxq_nc4(K);
+    const int NC = K / 64, NC4 = (NC + 3) / 4;
     const int rb = blockIdx.x / NC4, c4 = blockIdx.x % NC4;
     const int t = threadIdx.x;
-    const int r = t & 15, cc = (t >> 4) & 3, qt = t >> 6;   // qt wave-uniform
-    const int n = rb * 16 + r, c = c4 * 4 + cc;
+    const int r = t & 15, cs = (t >> 4) & 3, qt = t >> 6;   // qt wave-uniform
+    const int n = rb * 16 + r, c = c4 * 4 + cs;
     if (c >= NC) return;
-    const uint32_t* tile = qweight + (int64_t)blockIdx.x * MXQ_TILE_DW;
+    const uint32_t* tile = qweight + ((int64_t)rb * NC + c) * MXQ_BLK_DW;
     uint32_t o[8];
     if (qt < 3) {
-        const uint32_t d = tile[mxq_c2(qt, cc, r)];
-        const float z = __uint_as_float(tile[mxq_z2(qt, cc, r)]);
-        const uint32_t scw = ((const uint16_t*)tile)[mxq_sc_u16(cc, r)];
-        const float qs = __uint_as_float(tile[mxq_qq(cc, qt)]), qz = __uint_as_float(tile[mxq_qq(cc, qt) + 1]);
+        const uint32_t d = tile[mxq_c2(qt, r)];
+        const float z = __uint_as_float(tile[mxq_z2(qt, r)]);
+        const uint32_t scw = ((const uint16_t*)tile)[mxq_sc_u16(r)];
+        const float qs = __uint_as_float(tile[mxq_qq(qt)]), qz = __uint_as_float(tile[mxq_qq(qt) + 1]);
         mxq_deq2x16(d, mxq_scale(qs, qz, (scw >> (4 * qt)) & 15u), z, o);
     } else {
         const float4 m = rowmeta[n];
         const float s = mxq_scale(m.z, m.w, (uint32_t)m.y);
-        mxq_deq4x8(tile[mxq_c4(0, cc, r)], s, m.x, o);
-        mxq_deq4x8(tile[mxq_c4(1, cc, r)], s, m.x, o + 4);
+        mxq_deq4x8(tile[mxq_c4(0, r)], s, m.x, o);
+        mxq_deq4x8(tile[mxq_c4(1, r)], s, m.x, o + 4);
     }
     uint4* dst = (uint4*)(out + (int64_t)n * K + c * 64 + qt * 16);
     dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void mxq_quantize_pack_kernel(const void* __re
                                                                 const uint8_t* __restrict__ dead,
                                                                 uint32_t* __restrict__ qweight,
                                                                 float4* __restrict__ rowmeta, int N, int K) {
-    const int NC = K / 64, NC4 = mxq_nc4(K);
+    const int NC = K / 64, NC4 = (NC + 3) / 4;
     const int rb = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, qt = lane >> 4;
@@ -201,17 +203,19 @@ __global__ __launch_bounds__(256) void mxq_quantize_pack_kernel(const void* __re
         }
         const uint32_t sci = (uint32_t)scode;
         const uint32_t sc1 = __shfl(sci, r + 16, 64), sc2 = __shfl(sci, r + 32, 64);
-        uint32_t* tile = qweight + ((int64_t)rb * NC4 + (c >> 2)) * MXQ_TILE_DW;
-        const int cc = c & 3;
+        uint32_t* tile = qweight + ((int64_t)rb * NC + c) * MXQ_BLK_DW;
         if (qt < 3) {
-            tile[mxq_c2(qt, cc, r)] = word;
-            tile[mxq_z2(qt, cc, r)] = __float_as_uint(z);
+            tile[mxq_c2(qt, r)] = word;
+            tile[mxq_z2(qt, r)] = __float_as_uint(z);
             if (r == 0) {
-                tile[mxq_qq(cc, qt)] = __float_as_uint(qs);
-                tile[mxq_qq(cc, qt) + 1] = __float_as_uint(qz);
+                tile[mxq_qq(qt)] = __float_as_uint(qs);
+                tile[mxq_qq(qt) + 1] = __float_as_uint(qz);
             }
+        } else if (r == 0) {   // unused fourth QQ slot: keep the packed bytes deterministic
+            tile[mxq_qq(3)] = 0u;
+            tile[mxq_qq(3) + 1] = 0u;
         }
-        if (qt == 0) ((uint16_t*)tile)[mxq_sc_u16(cc, r)] = (uint16_t)(sci | (sc1 << 4) | (sc2 << 8));
+        if (qt == 0) ((uint16_t*)tile)[mxq_sc_u16(r)] = (uint16_t)(sci | (sc1 << 4) | (sc2 << 8));
     }
     if (qt == 3) { red[0][wave][r] = mn4; red[1][wave][r] = mx4; }
     __syncthreads();
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256) void mxq_quantize_pack_kernel(const void* __re
     const float sd4 = fmaxf(s4, 1e-9f);
 
     for (int c4 = wave; c4 < NC4; c4 += 4) {
-        const int c = c4 * 4 + qt;   // qt plays the role of the chunk-in-tile index here
+        const int c = c4 * 4 + qt;   // qt plays the role of the chunk slot here
         if (c >= NC) continue;
         const int k0 = c * 64 + 48;
         load16(W, dtype, (int64_t)n * K + k0, v);
@@ -240,9 +244,9 @@ __global__ __launch_bounds__(256) void mxq_quantize_pack_kernel(const void* __re
             w0 |= (uint32_t)q0 << mxq_bit4(j);
             w1 |= (uint32_t)q1 << mxq_bit4(j);
         }
-        uint32_t* tile = qweight + ((int64_t)rb * NC4 + c4) * MXQ_TILE_DW;
-        tile[mxq_c4(0, qt, r)] = w0;
-        tile[mxq_c4(1, qt, r)] = w1;
+        uint32_t* tile = qweight + ((int64_t)rb * NC + c) * MXQ_BLK_DW;
+        tile[mxq_c4(0, r)] = w0;
+        tile[mxq_c4(1, r)] = w1;
     }
 }
 
@@ -253,10 +257,8 @@ int mxq_launch_pack_codes(const uint8_t* codes2, const uint8_t* sc2, const float
                           const float* qz2, const uint8_t* codes4, const uint8_t* sc4, const float* zero4,
                           const float* qs4, const float* qz4, void* qweight, void* rowmeta, int N, int K,
                           hipStream_t stream) {
-    const size_t bytes = (size_t)(N / 16) * mxq_nc4(K) * MXQ_TILE_DW * 4;
-    hipError_t e = hipMemsetAsync(qweight, 0, bytes, stream);
-    if (e != hipSuccess) return (int)e;
     const int64_t total = (int64_t)N * (K / 64);
+    // (every dword of every block is written by the kernel except the unused 4th QQ slot)
     mxq_pack_codes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(
         codes2, sc2, zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4, (uint32_t*)qweight, (float4*)rowmeta, N, K);
     return (int)hipGetLastError();
@@ -273,7 +275,7 @@ int mxq_launch_unpack(const void* qweight, const void* rowmeta, uint8_t* codes2,
 }
 
 int mxq_launch_dequant_f16(const void* qweight, const void* rowmeta, void* out, int N, int K, hipStream_t stream) {
-    const unsigned grid = (unsigned)((N / 16) * mxq_nc4(K));
+    const unsigned grid = (unsigned)((N / 16) * ((K / 64 + 3) / 4));
     mxq_dequant_f16_kernel<<<grid, 256, 0, stream>>>((const uint32_t*)qweight, (const float4*)rowmeta,
                                                      (uint16_t*)out, N, K);
     return (int)hipGetLastError();
@@ -281,11 +283,6 @@ int mxq_launch_dequant_f16(const void* qweight, const void* rowmeta, void* out, 
 
 int mxq_launch_quantize_pack(const void* W, int dtype, const uint8_t* dead, void* qweight, void* rowmeta, int N,
                              int K, hipStream_t stream) {
-    if ((K / 64) % 4 != 0) {   // chunk padding inside the last tile of each row block must read as zeros
-        const size_t bytes = (size_t)(N / 16) * mxq_nc4(K) * MXQ_TILE_DW * 4;
-        hipError_t e = hipMemsetAsync(qweight, 0, bytes, stream);
-        if (e != hipSuccess) return (int)e;
-    }
     mxq_quantize_pack_kernel<<<(unsigned)(N / 16), 256, 0, stream>>>(W, dtype, dead, (uint32_t*)qweight,
                                                                       (float4*)rowmeta, N, K);
     return (int)hipGetLastError();

@@ -42,12 +42,12 @@ def check_shape(N: int, K: int):
 
 def qweight_bytes(N: int, K: int) -> int:
     check_shape(N, K)
-    return (N // 16) * ((K // 64 + 3) // 4) * 568 * 4
+    return (N // 16) * (K // 64) * 576
 
 
 @dataclass
 class PackedMXQ:
-    """qweight: int32 [N/16 * ceil(K/256) * 568]; rowmeta: float32 [N, 4]."""
+    """qweight: int32 [N/16 * K/64 * 144] (576-B blocks); rowmeta: float32 [N, 4]."""
     qweight: torch.Tensor
     rowmeta: torch.Tensor
     N: int
@@ -149,7 +149,8 @@ def dequant(p: PackedMXQ) -> torch.Tensor:
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
     """y = x @ dequant(p).T for x [..., K] fp16 -> [..., N] fp16 (fp32 accumulation).
 
-    path: "auto" (GEMV kernel for <= 4 tokens, MFMA GEMM otherwise), "gemm" or "gemv"."""
+    path: "auto" (GEMV kernel for <= 4 tokens, MFMA GEMM otherwise), "gemm", "gemv", or an
+    explicit GEMM kernel variant "gemm1" (128x128) / "gemm2" (256x128 pipelined)."""
     _need_gpu(x, p.qweight)
     if x.dtype != torch.float16:
         raise ValueError(f"activations must be float16 (W2/4 x A16), got {x.dtype}")
@@ -166,8 +167,12 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
     if M == 0:
         return out.reshape(*x.shape[:-1], p.N)
     lib = _lib.load()
-    fn = {"auto": lib.mxq_linear_f16, "gemm": lib.mxq_gemm_f16, "gemv": lib.mxq_gemv_f16}[path]
+    args = (x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K)
     with torch.cuda.device(x.device):
-        _lib.check(fn(x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K,
-                      _stream(x2)), f"mxq_linear_f16[{path}]")
+        if path in ("gemm1", "gemm2"):      # explicit kernel variant (benchmarks / tests)
+            rc = lib.mxq_gemm_f16_ex(*args, int(path[-1]), _stream(x2))
+        else:
+            fn = {"auto": lib.mxq_linear_f16, "gemm": lib.mxq_gemm_f16, "gemv": lib.mxq_gemv_f16}[path]
+            rc = fn(*args, _stream(x2))
+        _lib.check(rc, f"mxq_linear_f16[{path}]")
     return out.reshape(*x.shape[:-1], p.N)

@@ -6,7 +6,7 @@ around its CUDA prototype; this is the module the name
 ``QuantLinear`` in BASELINE.json maps to on the inference side.  ``nas_quant``
 (mxq_quant/lib/prune.py:409-414) can swap it in after ``MXQGPT.fasterquant``.
 
-state_dict: ``qweight`` int32 [N/16 * ceil(K/256) * 568], ``rowmeta`` float32 [N, 4],
+state_dict: ``qweight`` int32 [N/16 * K/64 * 144], ``rowmeta`` float32 [N, 4],
 ``fmt`` int32 [3] = (format version, N, K), optional ``bias`` float16 [N].
 """
 from __future__ import annotations

@@ -15,7 +15,7 @@ uint16_t mxq_host_f32_to_f16(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEARES
 
 extern "C" {
 
-long emu_qweight_dwords(int N, int K) { return (long)(N / 16) * mxq_nc4(K) * MXQ_TILE_DW; }
+long emu_qweight_dwords(int N, int K) { return (long)(N / 16) * (K / 64) * MXQ_BLK_DW; }
 
 void emu_pack(const uint8_t* codes2, const uint8_t* sc2, const float* zero2, const float* qs2, const float* qz2,
               const uint8_t* codes4, const uint8_t* sc4, const float* zero4, const float* qs4, const float* qz4,
@@ -24,13 +24,13 @@ void emu_pack(const uint8_t* codes2, const uint8_t* sc2, const float* zero2, con
     memset(qweight, 0, emu_qweight_dwords(N, K) * 4);
     for (int n = 0; n < N; ++n) {
         for (int c = 0; c < NC; ++c) {
-            uint32_t* tile = qweight + mxq_tile_index(n, c, K) * MXQ_TILE_DW;
-            mxq_pack_row_chunk(tile, c & 3, n & 15, codes2 + (long)n * NC * 48 + c * 48, sc2 + (long)n * NC * 3 + c * 3,
+            uint32_t* tile = qweight + mxq_blk_index(n, c, K) * MXQ_BLK_DW;
+            mxq_pack_row_chunk(tile, n & 15, codes2 + (long)n * NC * 48 + c * 48, sc2 + (long)n * NC * 3 + c * 3,
                                zero2 + (long)n * NC * 3 + c * 3, codes4 + (long)n * NC * 16 + c * 16);
             if ((n & 15) == 0)
                 for (int g = 0; g < 3; ++g) {
-                    memcpy(tile + mxq_qq(c & 3, g), qs2 + (long)(n / 16) * NC * 3 + c * 3 + g, 4);
-                    memcpy(tile + mxq_qq(c & 3, g) + 1, qz2 + (long)(n / 16) * NC * 3 + c * 3 + g, 4);
+                    memcpy(tile + mxq_qq(g), qs2 + (long)(n / 16) * NC * 3 + c * 3 + g, 4);
+                    memcpy(tile + mxq_qq(g) + 1, qz2 + (long)(n / 16) * NC * 3 + c * 3 + g, 4);
                 }
         }
         rowmeta[4 * n] = zero4[n];
@@ -44,7 +44,7 @@ void emu_unpack(const uint32_t* qweight, uint8_t* codes2, uint8_t* sc2, float* z
     const int NC = K / 64;
     for (int n = 0; n < N; ++n)
         for (int c = 0; c < NC; ++c)
-            mxq_unpack_row_chunk(qweight + mxq_tile_index(n, c, K) * MXQ_TILE_DW, c & 3, n & 15,
+            mxq_unpack_row_chunk(qweight + mxq_blk_index(n, c, K) * MXQ_BLK_DW, n & 15,
                                  codes2 + (long)n * NC * 48 + c * 48, sc2 + (long)n * NC * 3 + c * 3,
                                  zero2 + (long)n * NC * 3 + c * 3, codes4 + (long)n * NC * 16 + c * 16);
 }
@@ -54,22 +54,22 @@ void emu_dequant_f16(const uint32_t* qweight, const float* rowmeta, uint16_t* ou
     const int NC = K / 64;
     for (int n = 0; n < N; ++n)
         for (int c = 0; c < NC; ++c) {
-            const uint32_t* tile = qweight + mxq_tile_index(n, c, K) * MXQ_TILE_DW;
-            const int cc = c & 3, r = n & 15;
+            const uint32_t* tile = qweight + mxq_blk_index(n, c, K) * MXQ_BLK_DW;
+            const int r = n & 15;
             uint32_t o[8];
-            const uint32_t scw = ((const uint16_t*)tile)[mxq_sc_u16(cc, r)];
+            const uint32_t scw = ((const uint16_t*)tile)[mxq_sc_u16(r)];
             for (int g = 0; g < 3; ++g) {
                 float qs, qz, z;
-                memcpy(&qs, tile + mxq_qq(cc, g), 4);
-                memcpy(&qz, tile + mxq_qq(cc, g) + 1, 4);
-                memcpy(&z, tile + mxq_z2(g, cc, r), 4);
-                mxq_deq2x16(tile[mxq_c2(g, cc, r)], mxq_scale(qs, qz, (scw >> (4 * g)) & 15u), z, o);
+                memcpy(&qs, tile + mxq_qq(g), 4);
+                memcpy(&qz, tile + mxq_qq(g) + 1, 4);
+                memcpy(&z, tile + mxq_z2(g, r), 4);
+                mxq_deq2x16(tile[mxq_c2(g, r)], mxq_scale(qs, qz, (scw >> (4 * g)) & 15u), z, o);
                 memcpy(out + (long)n * K + c * 64 + g * 16, o, 32);
             }
             const float* m = rowmeta + 4 * n;
             const float s4 = mxq_scale(m[2], m[3], (uint32_t)m[1]);
-            mxq_deq4x8(tile[mxq_c4(0, cc, r)], s4, m[0], o);
-            mxq_deq4x8(tile[mxq_c4(1, cc, r)], s4, m[0], o + 4);
+            mxq_deq4x8(tile[mxq_c4(0, r)], s4, m[0], o);
+            mxq_deq4x8(tile[mxq_c4(1, r)], s4, m[0], o + 4);
             memcpy(out + (long)n * K + c * 64 + 48, o, 32);
         }
 }

@@ -35,13 +35,13 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_version_and_size_helpers(lib):
     assert lib.mxq_version() >> 16 == 1
-    assert lib.mxq_qweight_bytes(4096, 4096) == 256 * 16 * 2272
-    assert lib.mxq_qweight_bytes(4096, 11008) == 256 * 43 * 2272
-    assert lib.mxq_qweight_bytes(64, 320) == 4 * 2 * 2272            # chunk padding
+    assert lib.mxq_qweight_bytes(4096, 4096) == 256 * 64 * 576
+    assert lib.mxq_qweight_bytes(4096, 11008) == 256 * 172 * 576
+    assert lib.mxq_qweight_bytes(64, 320) == 4 * 5 * 576
     assert lib.mxq_qweight_bytes(100, 4096) == 0 and lib.mxq_qweight_bytes(4096, 100) == 0
     assert lib.mxq_rowmeta_bytes(4096) == 4096 * 16
     bits = 8.0 * (lib.mxq_qweight_bytes(4096, 4096) + lib.mxq_rowmeta_bytes(4096)) / 4096 ** 2
-    assert 4.4 < bits < 4.5
+    assert 4.5 < bits < 4.55
 
 
 def test_argument_validation_without_gpu(lib):

@@ -28,7 +28,7 @@ def test_shape_checks():
     for N, K in ((15, 64), (16, 100), (0, 64)):
         with pytest.raises(ValueError):
             packing.check_shape(N, K)
-    assert packing.qweight_bytes(4096, 4096) == 9306112
+    assert packing.qweight_bytes(4096, 4096) == 9437184
     with pytest.raises(ValueError):
         QuantLinear(100, 16)
 
@@ -37,7 +37,7 @@ def test_quantlinear_state_dict_layout():
     m = QuantLinear(256, 64, bias=True)
     sd = m.state_dict()
     assert set(sd) == {"qweight", "rowmeta", "fmt", "bias"}
-    assert sd["qweight"].dtype == torch.int32 and sd["qweight"].numel() == 4 * 1 * 568
+    assert sd["qweight"].dtype == torch.int32 and sd["qweight"].numel() == 4 * 4 * 144
     assert sd["rowmeta"].shape == (64, 4) and sd["fmt"].tolist() == [1, 64, 256]
     m2 = QuantLinear(256, 64, bias=True)
     m2.load_state_dict(sd)
