@@ -92,7 +92,8 @@ int mxq_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* 
 int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                  void* stream); /* M <= 4 */
 /* mxq_gemm_f16 with an explicit kernel variant, for A/B benchmarking and tests:
- * 0 = auto, 1 = 128x128 two-stage kernel, 2 = 256x128 LDS-DMA-pipelined kernel. */
+ * 0 = auto, 1 = 128x128 two-stage kernel, 2 = 256x128 LDS-DMA-pipelined kernel,
+ * 3 = 256x128 ping-pong kernel (two wave groups alternate MFMA and memory slots). */
 int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* stream);
 

@@ -83,6 +83,7 @@ int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, voi
         case 0: return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
         case 1: return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
         case 2: return mxq_launch_gemm2_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+        case 3: return mxq_launch_gemm3_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
     }
     return MXQ_E_SHAPE;
 }

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--m", type=int, default=2048)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--variants", default="gemm1,gemm2")
+    ap.add_argument("--variants", default="gemm1,gemm2,gemm3")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     variants = args.variants.split(",")
