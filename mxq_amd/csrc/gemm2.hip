@@ -58,6 +58,9 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// ABL: ablation bits for profiling builds only (wrong results): 1 = no x DMA in the loop,
+// 2 = no MFMA, 4 = no dequant, 8 = no fragment reads.  ABL = 0 is the product kernel.
+template <int ABL>
 __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_t* __restrict__ x,
                                                                   const uint32_t* __restrict__ qweight,
                                                                   const float4* __restrict__ rowmeta,
@@ -148,14 +151,22 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
         for (int kk = 0; kk < 2; ++kk) {
             half8 wf[4], xf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(w_base + swz(wn * 64 + i * 16 + fr, kk * 4 + fq));
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (ABL & 8) wf[i] = (half8){1, 2, 3, 4, 5, 6, 7, 8};
+                else wf[i] = *(const half8*)(w_base + swz(wn * 64 + i * 16 + fr, kk * 4 + fq));
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz(wm * 64 + j * 16 + fr, kk * 4 + fq));
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (ABL & 8) xf[j] = (half8){1, 2, 3, 4, 5, 6, 7, 8};
+                else xf[j] = *(const half8*)(a_base + swz(wm * 64 + j * 16 + fr, kk * 4 + fq));
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (ABL & 2) asm volatile("" ::"v"(wf[i]), "v"(xf[j]));
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                }
         }
     };
 
@@ -174,11 +185,17 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
     // ---- main loop ---------------------------------------------------------------------------
     for (int t = 0; t < NT; ++t) {
         const bool steady = (t + 3 < NT);
-        if (t + 2 < NT) issue_a(t + 2);
+        if constexpr (!(ABL & 1)) {
+            if (t + 2 < NT) issue_a(t + 2);
+        }
         if (t + 3 < NT) issue_bp(t + 3);
         compute(t);
-        if (t + 1 < NT) dequant(t + 1);
+        if constexpr (!(ABL & 4)) {
+            if (t + 1 < NT) dequant(t + 1);
+        }
         if (steady) {
+            if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+            else
             asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   // this step's 5 DMAs stay in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -204,13 +221,34 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
 
 }   // namespace
 
-int mxq_launch_gemm2_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm2_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       SMEM_BYTES);
+template <int ABL>
+static int launch2(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                   hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm2_f16_kernel<ABL>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    mxq_gemm2_f16_kernel<<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
+    mxq_gemm2_f16_kernel<ABL><<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n);
     return (int)hipGetLastError();
+}
+
+int mxq_launch_gemm2_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                         hipStream_t stream) {
+    return launch2<0>(x, qweight, rowmeta, y, M, N, K, stream);
+}
+
+// profiling-only ablation builds (outputs are wrong by construction)
+int mxq_launch_gemm2_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                int abl, hipStream_t stream) {
+    switch (abl) {
+        case 1: return launch2<1>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 2: return launch2<2>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 4: return launch2<4>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 8: return launch2<8>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 6: return launch2<6>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 14: return launch2<14>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 13: return launch2<13>(x, qweight, rowmeta, y, M, N, K, stream);
+    }
+    return (int)hipErrorInvalidValue;
 }

@@ -25,6 +25,8 @@ int mxq_launch_gemm1_f16(const void* x, const void* qweight, const void* rowmeta
                          hipStream_t stream);   // 128x128 tile, two LDS stages (gemm.hip)
 int mxq_launch_gemm2_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          hipStream_t stream);   // 256x128 tile, LDS-DMA rings, counted waits (gemm2.hip)
+int mxq_launch_gemm2_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+                                int K, int abl, hipStream_t stream);   // profiling only
 int mxq_launch_gemm3_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          hipStream_t stream);   // 256x128 tile, two wave groups ping-pong MFMA / memory slots (gemm3.hip)
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,

@@ -169,8 +169,8 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
     lib = _lib.load()
     args = (x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K)
     with torch.cuda.device(x.device):
-        if path in ("gemm1", "gemm2", "gemm3"):      # explicit kernel variant (benchmarks / tests)
-            rc = lib.mxq_gemm_f16_ex(*args, int(path[-1]), _stream(x2))
+        if path.startswith("gemm") and path[4:].isdigit():      # explicit kernel variant (benchmarks / tests)
+            rc = lib.mxq_gemm_f16_ex(*args, int(path[4:]), _stream(x2))
         else:
             fn = {"auto": lib.mxq_linear_f16, "gemm": lib.mxq_gemm_f16, "gemv": lib.mxq_gemv_f16}[path]
             rc = fn(*args, _stream(x2))

@@ -26,7 +26,11 @@ def _asm(src):
 
 def test_gemm2_main_loop_keeps_dma_in_flight():
     s = _asm("gemm2.hip")
-    body = s[s.index("mxq_gemm2_f16_kernel"):]
+    # the product kernel is the ABL = 0 instantiation (the others are profiling-only ablations)
+    m = re.search(r"^(\S*mxq_gemm2_f16_kernelILi0E\S*):\s*$", s, flags=re.M)
+    assert m, "mxq_gemm2_f16_kernel<0> not found"
+    body = s[m.end():]
+    body = body[:body.index(".Lfunc_end")]
     lines = body.splitlines()
     # the main loop = from the loop header that contains the counted wait back to its s_barrier
     idx = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(5) lgkmcnt(0)" in l]

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Run ONE GEMM kernel variant at ONE shape a few times (for rocprofv3 --pmc runs).
+    python3 tools/gemm_prof.py gemm2 2048 4096 4096 [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mxq_amd import packing  # noqa: E402
+
+variant, M, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(1)
+W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
+p = packing.quantize_pack(W)
+x = torch.randn(M, K, generator=g, device=dev).half()
+out = torch.empty(M, N, device=dev, dtype=torch.float16)
+for _ in range(iters):
+    packing.linear(x, p, out=out, path=variant)
+torch.cuda.synchronize()
