@@ -18,9 +18,17 @@
 //     the newest stage stays in flight across the barrier (cdna guide T3/T4).
 //   * dequant is done ONCE per workgroup per K-step: every thread turns 16 packed weights
 //     (read from the LDS copy of the block) into fp16 with the LUT / v_perm_b32 helpers and
-//     writes 32 B into a double-buffered, XOR-swizzled W16 tile; the MFMAs of step t overlap
-//     the dequant of step t+1.  The fp16 weight never exists outside LDS.
+//     writes 32 B into a double-buffered, XOR-swizzled W16 tile.  The fp16 weight never
+//     exists outside LDS.
+//   * the K-loop body is ONE straight-line basic block per wave role (the kernel is
+//     specialised on "this wave dequantises a 2-bit group" / "... the 4-bit arm", and the
+//     pipeline tail is peeled), with all 16 fragment reads and the dequant operand reads
+//     issued up front, so the compiler interleaves the dequant VALU chain and the LDS
+//     latencies with the 32 MFMAs instead of serialising them (measured by ablation, round 1:
+//     DMA 33 us + MFMA 30 us + dequant 19 us + fragment reads 18 us were simply adding up).
 //   * D^T = W . x^T: a lane owns 4 consecutive output channels of one token (8-B stores).
+//   * tiles are dealt to the 8 XCDs as compact 2-D blocks (4 x 2 regions of the tile grid) so
+//     that an XCD's L2 sees 1/4 of x and 1/2 of W instead of all of x.
 //
 // hipcc note (ROCm 7.2): SIInsertWaitcnts puts `s_waitcnt vmcnt(0)` in front of any LDS access
 // that TBAA says may alias an in-flight LDS-DMA.  Struct-typed accesses (`uint2`, `uint4` =
@@ -58,6 +66,145 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// Tile order.  Blocks b, b+8, ... share an XCD (round-robin dispatch; speed only, never
+// correctness).  When the tile grid splits into 4 x 2 regions every XCD works on one region,
+// walking it in 16-wide channel panels so that the ~32 concurrently resident tiles of an XCD
+// form a 2 x 16 block; otherwise fall back to the bijective linear remap (guide T1).
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0) {
+        const int e = bid & 7, l = bid >> 3;
+        const int rm = tiles_m >> 2, rn = tiles_n >> 1;   // region size in tiles
+        const int full = rm * 16;                           // tiles in a full 16-wide panel
+        const int p = l / full;                             // panel index
+        const int j = l - p * full;                         // index inside the panel
+        const int left = rn - p * 16;
+        const int pw = left < 16 ? left : 16;               // width of this (maybe ragged) panel
+        tm = (e & 3) * rm + j / pw;
+        tn = (e >> 2) * rn + p * 16 + j % pw;
+        return;
+    }
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tm = lin % tiles_m;
+    tn = lin / tiles_m;
+}
+
+struct Ctx {
+    char* smem;
+    const uint16_t* a_src[4];
+    const char* bp_src;
+    int wave, lane;
+    int d_row, d_q, d_blk, d_r;
+    float s4, z4;
+    int wm, wn, fr, fq;
+    int NT;
+};
+
+__device__ __forceinline__ void issue_a(const Ctx& c, int t) {
+    char* dst = c.smem + OFF_A + (t % A_SLOTS) * A_STAGE + c.wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(c.a_src[i] + t * BK, dst + i * 1024);
+}
+__device__ __forceinline__ void issue_bp(const Ctx& c, int t) {
+    char* dst = c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.wave * MXQ_BLK_BYTES;
+    if (c.lane < 36) glds16(c.bp_src + (int64_t)t * MXQ_BLK_BYTES, dst);
+}
+
+// packed operands of this thread's 16 weights of K-step t, from the LDS copy of the block
+struct DeqIn {
+    uint32_t a, b, c, d, e;
+};
+template <bool IS4>
+__device__ __forceinline__ DeqIn deq_load(const Ctx& c, int t) {
+    const uint32_t* blk = (const uint32_t*)(c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.d_blk * MXQ_BLK_BYTES);
+    DeqIn r;
+    if constexpr (IS4) {
+        r.a = blk[mxq_c4(0, c.d_r)];
+        r.b = blk[mxq_c4(1, c.d_r)];
+        r.c = r.d = r.e = 0;
+    } else {
+        r.a = blk[mxq_c2(c.d_q, c.d_r)];
+        r.b = blk[mxq_z2(c.d_q, c.d_r)];
+        r.c = ((const uint16_t*)blk)[mxq_sc_u16(c.d_r)];
+        r.d = blk[mxq_qq(c.d_q)];
+        r.e = blk[mxq_qq(c.d_q) + 1];
+    }
+    return r;
+}
+template <bool IS4>
+__device__ __forceinline__ void deq_math(const Ctx& c, const DeqIn& in, uint32_t o[8]) {
+    if constexpr (IS4) {
+        mxq_deq4x8(in.a, c.s4, c.z4, o);
+        mxq_deq4x8(in.b, c.s4, c.z4, o + 4);
+    } else {
+        mxq_deq2x16(in.a, mxq_scale(__uint_as_float(in.d), __uint_as_float(in.e), (in.c >> (4 * c.d_q)) & 15u),
+                    __uint_as_float(in.b), o);
+    }
+}
+__device__ __forceinline__ void deq_store(const Ctx& c, int t, const uint32_t o[8]) {
+    char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
+    *(u32x4*)(wt + swz(c.d_row, c.d_q * 2)) = (u32x4){o[0], o[1], o[2], o[3]};
+    *(u32x4*)(wt + swz(c.d_row, c.d_q * 2 + 1)) = (u32x4){o[4], o[5], o[6], o[7]};
+}
+
+// One K-step.  TAIL = false: steady state, everything unconditional -> a single basic block.
+template <bool IS4, bool TAIL, int ABL>
+__device__ __forceinline__ void kstep(const Ctx& c, int t, f32x4 (&acc)[4][4]) {
+    if constexpr (!(ABL & 1)) {
+        if (!TAIL || t + 2 < c.NT) issue_a(c, t + 2);
+    }
+    if (!TAIL || t + 3 < c.NT) issue_bp(c, t + 3);
+
+    const bool do_deq = (!TAIL || t + 1 < c.NT) && !(ABL & 4);
+    DeqIn din = {};
+    if (do_deq) din = deq_load<IS4>(c, t + 1);
+
+    const char* a_base = c.smem + OFF_A + (t % A_SLOTS) * A_STAGE;
+    const char* w_base = c.smem + OFF_W + (t & 1) * W_STAGE;
+    half8 wf[2][4], xf[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (ABL & 8) wf[kk][i] = (half8){1, 2, 3, 4, 5, 6, 7, 8};
+            else wf[kk][i] = *(const half8*)(w_base + swz(c.wn * 64 + i * 16 + c.fr, kk * 4 + c.fq));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (ABL & 8) xf[kk][j] = (half8){1, 2, 3, 4, 5, 6, 7, 8};
+            else xf[kk][j] = *(const half8*)(a_base + swz(c.wm * 64 + j * 16 + c.fr, kk * 4 + c.fq));
+        }
+    }
+    uint32_t o[8];
+    if (do_deq) deq_math<IS4>(c, din, o);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (ABL & 2) asm volatile("" ::"v"(wf[kk][i]), "v"(xf[kk][j]));
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+            }
+    if (do_deq) deq_store(c, t + 1, o);
+
+    if (!TAIL) {
+        if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   // this step's 5 DMAs stay in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+}
+
+template <bool IS4, int ABL>
+__device__ __forceinline__ void kloop(const Ctx& c, f32x4 (&acc)[4][4]) {
+    int t = 0;
+    for (; t + 3 < c.NT; ++t) kstep<IS4, false, ABL>(c, t, acc);
+    for (; t < c.NT; ++t) kstep<IS4, true, ABL>(c, t, acc);
+}
+
 // ABL: ablation bits for profiling builds only (wrong results): 1 = no x DMA in the loop,
 // 2 = no MFMA, 4 = no dequant, 8 = no fragment reads.  ABL = 0 is the product kernel.
 template <int ABL>
@@ -67,150 +214,90 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
                                                                   uint16_t* __restrict__ y, int M, int N, int K,
                                                                   int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NT = K / BK;
-
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {   // XCD-aware bijective remap (guide T1): speed only
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    Ctx c;
+    c.smem = smem;
+    const int tid = threadIdx.x;
+    c.lane = tid & 63;
+    c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    c.NT = K / BK;
+    int tm, tn;
+    tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA sources -------------------------------------------------------------------
     // x: DMA i of wave w fills rows 8*(4w+i) .. +7 of the A slot; LDS slot lane%8 of a row
     // receives global 16-B slot (lane%8) ^ (row&7).
-    const uint16_t* a_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int row = (c.wave * 4 + i) * 8 + (c.lane >> 3);
         int gm = m0 + row;
         gm = gm < M ? gm : M - 1;
-        a_src[i] = x + (int64_t)gm * K + (((lane & 7) ^ (row & 7)) << 3);
+        c.a_src[i] = x + (int64_t)gm * K + (((c.lane & 7) ^ (row & 7)) << 3);
     }
     // packed W: wave w copies the 576-B block of 16-row block (n0/16 + w), lanes 0..35.
-    int rb = (n0 >> 4) + wave;
+    int rb = (n0 >> 4) + c.wave;
     rb = rb < (N >> 4) ? rb : (N >> 4) - 1;
-    const char* bp_src = (const char*)(qweight + (int64_t)rb * NT * MXQ_BLK_DW) + lane * 16;
-
-    auto issue_a = [&](int t) {
-        char* dst = smem + OFF_A + (t % A_SLOTS) * A_STAGE + wave * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(a_src[i] + t * BK, dst + i * 1024);
-    };
-    auto issue_bp = [&](int t) {
-        char* dst = smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + wave * MXQ_BLK_BYTES;
-        if (lane < 36) glds16(bp_src + (int64_t)t * MXQ_BLK_BYTES, dst);
-    };
+    c.bp_src = (const char*)(qweight + (int64_t)rb * c.NT * MXQ_BLK_DW) + c.lane * 16;
 
     // ---- dequant role: thread -> (W row = 64*(wave&1) + lane, chunk quarter = wave>>1) ---
-    const int d_row = (wave & 1) * 64 + lane, d_q = wave >> 1;   // d_q wave-uniform
-    const int d_blk = d_row >> 4, d_r = d_row & 15;
-    float s4 = 0.f, z4 = 0.f;
-    if (d_q == 3) {
-        int gn = n0 + d_row;
+    c.d_row = (c.wave & 1) * 64 + c.lane;
+    c.d_q = c.wave >> 1;   // wave-uniform
+    c.d_blk = c.d_row >> 4;
+    c.d_r = c.d_row & 15;
+    c.s4 = 0.f;
+    c.z4 = 0.f;
+    if (c.d_q == 3) {
+        int gn = n0 + c.d_row;
         gn = gn < N ? gn : N - 1;
         const float4 m = rowmeta[gn];
-        s4 = mxq_scale(m.z, m.w, (uint32_t)m.y);
-        z4 = m.x;
+        c.s4 = mxq_scale(m.z, m.w, (uint32_t)m.y);
+        c.z4 = m.x;
     }
-    auto dequant = [&](int t) {   // packed block copy of step t -> W16[t & 1]
-        const uint32_t* blk = (const uint32_t*)(smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + d_blk * MXQ_BLK_BYTES);
-        uint32_t o[8];
-        if (d_q < 3) {
-            const uint32_t d = blk[mxq_c2(d_q, d_r)];
-            const float z = __uint_as_float(blk[mxq_z2(d_q, d_r)]);
-            const uint32_t scw = ((const uint16_t*)blk)[mxq_sc_u16(d_r)];
-            const uint32_t qq_x = blk[mxq_qq(d_q)], qq_y = blk[mxq_qq(d_q) + 1];
-            mxq_deq2x16(d, mxq_scale(__uint_as_float(qq_x), __uint_as_float(qq_y), (scw >> (4 * d_q)) & 15u), z, o);
-        } else {
-            mxq_deq4x8(blk[mxq_c4(0, d_r)], s4, z4, o);
-            mxq_deq4x8(blk[mxq_c4(1, d_r)], s4, z4, o + 4);
-        }
-        char* wt = smem + OFF_W + (t & 1) * W_STAGE;
-        *(u32x4*)(wt + swz(d_row, d_q * 2)) = (u32x4){o[0], o[1], o[2], o[3]};
-        *(u32x4*)(wt + swz(d_row, d_q * 2 + 1)) = (u32x4){o[4], o[5], o[6], o[7]};
-    };
-
     // ---- MFMA role: wave (wm, wn) owns tokens [64wm, +64) x channels [64wn, +64) ----------
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 15, fq = lane >> 4;
+    c.wm = c.wave >> 1;
+    c.wn = c.wave & 1;
+    c.fr = c.lane & 15;
+    c.fq = c.lane >> 4;
     f32x4 acc[4][4];   // [channel block i][token block j]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int t) {
-        const char* a_base = smem + OFF_A + (t % A_SLOTS) * A_STAGE;
-        const char* w_base = smem + OFF_W + (t & 1) * W_STAGE;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8 wf[4], xf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if constexpr (ABL & 8) wf[i] = (half8){1, 2, 3, 4, 5, 6, 7, 8};
-                else wf[i] = *(const half8*)(w_base + swz(wn * 64 + i * 16 + fr, kk * 4 + fq));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (ABL & 8) xf[j] = (half8){1, 2, 3, 4, 5, 6, 7, 8};
-                else xf[j] = *(const half8*)(a_base + swz(wm * 64 + j * 16 + fr, kk * 4 + fq));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (ABL & 2) asm volatile("" ::"v"(wf[i]), "v"(xf[j]));
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                }
-        }
-    };
-
     // ---- prologue: fill the rings, dequantise step 0 ---------------------------------------
-    issue_a(0);
-    if (NT > 1) issue_a(1);
-    issue_bp(0);
-    if (NT > 1) issue_bp(1);
-    if (NT > 2) issue_bp(2);
+    issue_a(c, 0);
+    if (c.NT > 1) issue_a(c, 1);
+    issue_bp(c, 0);
+    if (c.NT > 1) issue_bp(c, 1);
+    if (c.NT > 2) issue_bp(c, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    dequant(0);
+    {
+        uint32_t o[8];
+        if (c.d_q == 3) {
+            const DeqIn in = deq_load<true>(c, 0);
+            deq_math<true>(c, in, o);
+        } else {
+            const DeqIn in = deq_load<false>(c, 0);
+            deq_math<false>(c, in, o);
+        }
+        deq_store(c, 0, o);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- main loop ---------------------------------------------------------------------------
-    for (int t = 0; t < NT; ++t) {
-        const bool steady = (t + 3 < NT);
-        if constexpr (!(ABL & 1)) {
-            if (t + 2 < NT) issue_a(t + 2);
-        }
-        if (t + 3 < NT) issue_bp(t + 3);
-        compute(t);
-        if constexpr (!(ABL & 4)) {
-            if (t + 1 < NT) dequant(t + 1);
-        }
-        if (steady) {
-            if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-            else
-            asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   // this step's 5 DMAs stay in flight
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-    }
+    // ---- main loop, specialised on the wave's dequant role ------------------------------------
+    if (c.d_q == 3) kloop<true, ABL>(c, acc);
+    else kloop<false, ABL>(c, acc);
 
     // ---- epilogue ------------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + fr;
+        const int m = m0 + c.wm * 64 + j * 16 + c.fr;
         if (m >= M) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fq * 4;
+            const int n = n0 + c.wn * 64 + i * 16 + c.fq * 4;
             if (n >= N) continue;
             half4 h = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2],
                        (_Float16)acc[i][j][3]};
@@ -219,11 +306,9 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
     }
 }
 
-}   // namespace
-
 template <int ABL>
-static int launch2(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                   hipStream_t stream) {
+int launch2(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+            hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm2_f16_kernel<ABL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
@@ -232,6 +317,8 @@ static int launch2(const void* x, const void* qweight, const void* rowmeta, void
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n);
     return (int)hipGetLastError();
 }
+
+}   // namespace
 
 int mxq_launch_gemm2_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          hipStream_t stream) {
@@ -246,9 +333,7 @@ int mxq_launch_gemm2_ablate_f16(const void* x, const void* qweight, const void* 
         case 2: return launch2<2>(x, qweight, rowmeta, y, M, N, K, stream);
         case 4: return launch2<4>(x, qweight, rowmeta, y, M, N, K, stream);
         case 8: return launch2<8>(x, qweight, rowmeta, y, M, N, K, stream);
-        case 6: return launch2<6>(x, qweight, rowmeta, y, M, N, K, stream);
         case 14: return launch2<14>(x, qweight, rowmeta, y, M, N, K, stream);
-        case 13: return launch2<13>(x, qweight, rowmeta, y, M, N, K, stream);
     }
     return (int)hipErrorInvalidValue;
 }

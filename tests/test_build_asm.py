@@ -27,23 +27,27 @@ def _asm(src):
 def test_gemm2_main_loop_keeps_dma_in_flight():
     s = _asm("gemm2.hip")
     # the product kernel is the ABL = 0 instantiation (the others are profiling-only ablations)
-    m = re.search(r"^(\S*mxq_gemm2_f16_kernelILi0E\S*):\s*$", s, flags=re.M)
+    m = re.search(r"^(\S*mxq_gemm2_f16_kernelILi0E\S*):", s, flags=re.M)
     assert m, "mxq_gemm2_f16_kernel<0> not found"
     body = s[m.end():]
     body = body[:body.index(".Lfunc_end")]
     lines = body.splitlines()
-    # the main loop = from the loop header that contains the counted wait back to its s_barrier
+    # one steady-state K-step per wave role (2-bit dequant waves, 4-bit dequant waves): the code
+    # between the previous s_barrier and the counted wait
     idx = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(5) lgkmcnt(0)" in l]
-    assert len(idx) == 1, "expected exactly one counted steady-state wait"
-    loop_hdr = max(i for i, l in enumerate(lines[:idx[0]]) if "Loop Header" in l)
-    loop = lines[loop_hdr:idx[0] + 1]
-    drains = [l for l in loop if re.search(r"s_waitcnt.*vmcnt\(0\)", l) and "lgkmcnt(0)" not in l]
-    assert not drains, f"compiler-inserted drain inside the K loop: {drains}"
-    assert sum("v_mfma_f32_16x16x32_f16" in l for l in loop) == 32
-    assert sum("ds_read_b128" in l for l in loop) == 16
-    # the loop is rotated by the compiler (next step's x-tile DMAs sit above the header), so
-    # count LDS-DMA instructions over the whole kernel: 11 in the prologue + 5 per step
-    assert sum("global_load_lds_dwordx4" in l for l in lines) == 16
+    assert len(idx) == 2, "expected one counted steady-state wait per wave role"
+    for end in idx:
+        start = max(i for i, l in enumerate(lines[:end]) if "s_barrier" in l)
+        step = lines[start:end + 1]
+        drains = [l for l in step if re.search(r"s_waitcnt.*vmcnt\(0\)", l)]
+        assert not drains, f"compiler-inserted drain inside the K loop: {drains}"
+        # hipcc may sink register-only MFMAs below the wait/barrier (legal, they touch no memory):
+        # count them up to the loop's backward branch
+        tail_end = end + next(i for i, l in enumerate(lines[end:]) if "s_cbranch_scc" in l)
+        assert sum("v_mfma_f32_16x16x32_f16" in l for l in lines[start:tail_end]) == 32
+        assert sum("ds_read_b128" in l for l in step) == 16
+        assert sum("global_load_lds_dwordx4" in l for l in step) in (1, 5)   # loop rotation may hoist the x DMAs
+        assert not any("s_cbranch" in l and "execz" not in l for l in step), "steady K-step must be straight-line"
 
 
 @pytest.mark.parametrize("src", ["gemm.hip", "gemm2.hip", "gemv.hip", "fakequant.hip", "pack.hip"])
