@@ -12,10 +12,13 @@
 //   * EVERY global->LDS byte moves by LDS-DMA (global_load_lds_dwordx4), so the only VMEM
 //     counter traffic in the loop is counted: 4 DMAs/wave/step for the x tile (XOR-swizzled
 //     through the source address) + 1 DMA/wave/step that copies one whole 576-B packed block
-//     (16 rows x 64 channels: codes, zeros, scale codes, (qs,qz)) verbatim.
-//   * the x tile is prefetched 2 K-steps ahead (3-slot ring), the packed W blocks 3 ahead
-//     (4-slot ring); each step ends with a COUNTED s_waitcnt vmcnt(5) + raw s_barrier, so
-//     the newest stage stays in flight across the barrier (cdna guide T3/T4).
+//     (16 rows x 64 channels: codes, zeros, scale codes, (qs,qz)) verbatim into a 1-KiB slot.
+//   * the x tile is DMA'd 3 K-steps ahead of its MFMAs (3-slot ring), the packed W blocks 4
+//     ahead (4-slot ring); each step ends with a COUNTED s_waitcnt vmcnt(5) + raw s_barrier,
+//     so the newest stage stays in flight across the barrier (cdna guide T3/T4).
+//   * fragment reads are software-pipelined by half a K-step in registers (two 32-VGPR sets) and
+//     W16(t+2) is dequantised during step t: nothing the 32 MFMAs of a step need is produced
+//     in that step, so LDS latency and the dequant VALU chain hide under the matrix pipe.
 //   * dequant is done ONCE per workgroup per K-step: every thread turns 16 packed weights
 //     (read from the LDS copy of the block) into fp16 with the LUT / v_perm_b32 helpers and
 //     writes 32 B into a double-buffered, XOR-swizzled W16 tile.  The fp16 weight never
@@ -51,13 +54,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 256, BN = 128, BK = 64, THREADS = 512;
 constexpr int A_STAGE = BM * BK * 2;            // 32 KiB
 constexpr int A_SLOTS = 3;
-constexpr int BP_STAGE = (BN / 16) * MXQ_BLK_BYTES;   // 8 blocks = 4608 B
+constexpr int BP_WAVE = 1024;                  // one 64-lane DMA per wave: 576-B block + 448 B of padding
+constexpr int BP_STAGE = (BN / 16) * BP_WAVE;   // 8 KiB
 constexpr int BP_SLOTS = 4;
 constexpr int W_STAGE = BN * BK * 2;            // 16 KiB
 constexpr int OFF_A = 0;
 constexpr int OFF_BP = OFF_A + A_SLOTS * A_STAGE;
 constexpr int OFF_W = OFF_BP + BP_SLOTS * BP_STAGE;
-constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;   // 149,504 B of the CU's 160 KiB
+constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;   // 163,840 B = all of the CU's 160 KiB
+static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
@@ -107,8 +112,10 @@ __device__ __forceinline__ void issue_a(const Ctx& c, int t) {
     for (int i = 0; i < 4; ++i) glds16(c.a_src[i] + t * BK, dst + i * 1024);
 }
 __device__ __forceinline__ void issue_bp(const Ctx& c, int t) {
-    char* dst = c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.wave * MXQ_BLK_BYTES;
-    if (c.lane < 36) glds16(c.bp_src + (int64_t)t * MXQ_BLK_BYTES, dst);
+    // all 64 lanes take part (no exec-masked branch in the K loop): lanes >= 36 re-read the block's
+    // last 16 bytes and land in the slot's padding
+    char* dst = c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.wave * BP_WAVE;
+    glds16(c.bp_src + (int64_t)t * MXQ_BLK_BYTES, dst);
 }
 
 // packed operands of this thread's 16 weights of K-step t, from the LDS copy of the block
@@ -117,7 +124,7 @@ struct DeqIn {
 };
 template <bool IS4>
 __device__ __forceinline__ DeqIn deq_load(const Ctx& c, int t) {
-    const uint32_t* blk = (const uint32_t*)(c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.d_blk * MXQ_BLK_BYTES);
+    const uint32_t* blk = (const uint32_t*)(c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.d_blk * BP_WAVE);
     DeqIn r;
     if constexpr (IS4) {
         r.a = blk[mxq_c4(0, c.d_r)];
@@ -148,46 +155,71 @@ __device__ __forceinline__ void deq_store(const Ctx& c, int t, const uint32_t o[
     *(u32x4*)(wt + swz(c.d_row, c.d_q * 2 + 1)) = (u32x4){o[4], o[5], o[6], o[7]};
 }
 
-// One K-step.  TAIL = false: steady state, everything unconditional -> a single basic block.
-template <bool IS4, bool TAIL, int ABL>
-__device__ __forceinline__ void kstep(const Ctx& c, int t, f32x4 (&acc)[4][4]) {
-    if constexpr (!(ABL & 1)) {
-        if (!TAIL || t + 2 < c.NT) issue_a(c, t + 2);
-    }
-    if (!TAIL || t + 3 < c.NT) issue_bp(c, t + 3);
+typedef half8 Frag4[4];
 
-    const bool do_deq = (!TAIL || t + 1 < c.NT) && !(ABL & 4);
-    DeqIn din = {};
-    if (do_deq) din = deq_load<IS4>(c, t + 1);
-
+// fragments of K-step t, half kk (32 of the 64 channels of the chunk)
+__device__ __forceinline__ void load_frags(const Ctx& c, int t, int kk, Frag4& wf, Frag4& xf) {
     const char* a_base = c.smem + OFF_A + (t % A_SLOTS) * A_STAGE;
     const char* w_base = c.smem + OFF_W + (t & 1) * W_STAGE;
-    half8 wf[2][4], xf[2][4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(w_base + swz(c.wn * 64 + i * 16 + c.fr, kk * 4 + c.fq));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if constexpr (ABL & 8) wf[kk][i] = (half8){1, 2, 3, 4, 5, 6, 7, 8};
-            else wf[kk][i] = *(const half8*)(w_base + swz(c.wn * 64 + i * 16 + c.fr, kk * 4 + c.fq));
-        }
+    for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz(c.wm * 64 + j * 16 + c.fr, kk * 4 + c.fq));
+}
+
+template <int ABL>
+__device__ __forceinline__ void mfma16(f32x4 (&acc)[4][4], const Frag4& wf, const Frag4& xf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if constexpr (ABL & 8) xf[kk][j] = (half8){1, 2, 3, 4, 5, 6, 7, 8};
-            else xf[kk][j] = *(const half8*)(a_base + swz(c.wm * 64 + j * 16 + c.fr, kk * 4 + c.fq));
+            if constexpr (ABL & 2) asm volatile("" ::"v"(wf[i]), "v"(xf[j]));
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
+}
+
+// One K-step t, software-pipelined by half a step in registers: on entry (wf0, xf0) hold the
+// kk = 0 fragments of step t (read during step t-1).  The kk = 1 fragments are read while the
+// kk = 0 MFMAs run, the kk = 0 fragments of step t+1 while the kk = 1 MFMAs run; W16(t+2) is
+// dequantised and the DMAs of x tile t+3 / packed block t+4 are issued -- nothing the MFMAs of
+// this step need is produced in this step, so LDS latency and the dequant VALU chain hide
+// under the matrix pipe.  TAIL = false: steady state, unconditional -> one basic block.
+template <bool IS4, bool TAIL, int ABL>
+__device__ __forceinline__ void kstep(const Ctx& c, int t, f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1,
+                                      Frag4& xf1) {
+    if constexpr (!(ABL & 1)) {
+        if (!TAIL || t + 3 < c.NT) issue_a(c, t + 3);
     }
+    if (!TAIL || t + 4 < c.NT) issue_bp(c, t + 4);
+
+    const bool do_deq = (!TAIL || t + 2 < c.NT) && !(ABL & 4);
+    constexpr int MFMA = 0x8, VALU = 0x2;
+    // phase 1: every LDS read that does not depend on this step
+    DeqIn din = {};
+    if (do_deq) din = deq_load<IS4>(c, t + 2);
+    if constexpr (!(ABL & 8)) load_frags(c, t, 1, wf1, xf1);
+    __builtin_amdgcn_sched_barrier(0);
+    // phase 2: kk = 0 MFMAs with the dequant VALU chain threaded between them (guide T19)
+    mfma16<ABL>(acc, wf0, xf0);
     uint32_t o[8];
     if (do_deq) deq_math<IS4>(c, din, o);
+    if constexpr (!TAIL && ABL == 0) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (ABL & 2) asm volatile("" ::"v"(wf[kk][i]), "v"(xf[kk][j]));
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
-            }
-    if (do_deq) deq_store(c, t + 1, o);
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(VALU, IS4 ? 4 : 3, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // phase 3: kk = 0 fragments of the next step (their registers are free now)
+    if constexpr (!(ABL & 8)) {
+        if (!TAIL || t + 1 < c.NT) load_frags(c, t + 1, 0, wf0, xf0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // phase 4: kk = 1 MFMAs, W16(t+2) stores
+    mfma16<ABL>(acc, wf1, xf1);
+    if (do_deq) deq_store(c, t + 2, o);
+    __builtin_amdgcn_sched_barrier(0);
 
     if (!TAIL) {
         if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
@@ -200,9 +232,15 @@ __device__ __forceinline__ void kstep(const Ctx& c, int t, f32x4 (&acc)[4][4]) {
 
 template <bool IS4, int ABL>
 __device__ __forceinline__ void kloop(const Ctx& c, f32x4 (&acc)[4][4]) {
+    Frag4 wf0, xf0, wf1, xf1;   // named register sets (static indexing: guide rule 20)
+    load_frags(c, 0, 0, wf0, xf0);
+    if constexpr (ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf1[i] = xf1[i] = wf0[i];
+    }
     int t = 0;
-    for (; t + 3 < c.NT; ++t) kstep<IS4, false, ABL>(c, t, acc);
-    for (; t < c.NT; ++t) kstep<IS4, true, ABL>(c, t, acc);
+    for (; t + 4 < c.NT; ++t) kstep<IS4, false, ABL>(c, t, acc, wf0, xf0, wf1, xf1);
+    for (; t < c.NT; ++t) kstep<IS4, true, ABL>(c, t, acc, wf0, xf0, wf1, xf1);
 }
 
 // ABL: ablation bits for profiling builds only (wrong results): 1 = no x DMA in the loop,
@@ -237,7 +275,7 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
     // packed W: wave w copies the 576-B block of 16-row block (n0/16 + w), lanes 0..35.
     int rb = (n0 >> 4) + c.wave;
     rb = rb < (N >> 4) ? rb : (N >> 4) - 1;
-    c.bp_src = (const char*)(qweight + (int64_t)rb * c.NT * MXQ_BLK_DW) + c.lane * 16;
+    c.bp_src = (const char*)(qweight + (int64_t)rb * c.NT * MXQ_BLK_DW) + (c.lane < 36 ? c.lane : 35) * 16;
 
     // ---- dequant role: thread -> (W row = 64*(wave&1) + lane, chunk quarter = wave>>1) ---
     c.d_row = (c.wave & 1) * 64 + c.lane;
@@ -265,23 +303,20 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: fill the rings, dequantise step 0 ---------------------------------------
-    issue_a(c, 0);
-    if (c.NT > 1) issue_a(c, 1);
-    issue_bp(c, 0);
-    if (c.NT > 1) issue_bp(c, 1);
-    if (c.NT > 2) issue_bp(c, 2);
+    for (int t = 0; t < 3 && t < c.NT; ++t) issue_a(c, t);
+    for (int t = 0; t < 4 && t < c.NT; ++t) issue_bp(c, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    {
+    for (int t = 0; t < 2 && t < c.NT; ++t) {   // W16(0), W16(1): both buffers
         uint32_t o[8];
         if (c.d_q == 3) {
-            const DeqIn in = deq_load<true>(c, 0);
+            const DeqIn in = deq_load<true>(c, t);
             deq_math<true>(c, in, o);
         } else {
-            const DeqIn in = deq_load<false>(c, 0);
+            const DeqIn in = deq_load<false>(c, t);
             deq_math<false>(c, in, o);
         }
-        deq_store(c, 0, o);
+        deq_store(c, t, o);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
