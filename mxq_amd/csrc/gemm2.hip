@@ -9,26 +9,27 @@
 //   * workgroup tile 256 tokens (M) x 128 output channels (N), K-step 64 = one MXQ chunk;
 //     8 waves (2 per SIMD), each a 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_f16.
 //     256 x 128 gives exactly 256 workgroups (one per CU) for [2048 x 4096] outputs.
-//   * EVERY global->LDS byte moves by LDS-DMA (global_load_lds_dwordx4), so the only VMEM
-//     counter traffic in the loop is counted: 4 DMAs/wave/step for the x tile (XOR-swizzled
-//     through the source address) + 1 DMA/wave/step that copies one whole 576-B packed block
-//     (16 rows x 64 channels: codes, zeros, scale codes, (qs,qz)) verbatim into a 1-KiB slot.
-//   * the x tile is DMA'd 3 K-steps ahead of its MFMAs (3-slot ring), the packed W blocks 4
-//     ahead (4-slot ring); each step ends with a COUNTED s_waitcnt vmcnt(5) + raw s_barrier,
-//     so the newest stage stays in flight across the barrier (cdna guide T3/T4).
-//   * fragment reads are software-pipelined by half a K-step in registers (two 32-VGPR sets) and
-//     W16(t+2) is dequantised during step t: nothing the 32 MFMAs of a step need is produced
-//     in that step, so LDS latency and the dequant VALU chain hide under the matrix pipe.
+//   * EVERY global->LDS byte moves by LDS-DMA (global_load_lds_dwordx4): per wave and K-step
+//     4 DMAs for the x tile + 1 DMA that copies one whole 576-B packed block (16 rows x 64
+//     channels: codes, zeros, scale codes, (qs,qz)) verbatim into a 1-KiB slot.  Each step
+//     ends with a COUNTED s_waitcnt vmcnt(5) + raw s_barrier: the newest step's DMAs stay in
+//     flight across the barrier (cdna guide T3/T4).
+//   * everything is software-pipelined in HALF K-steps ("halves": 32 channels, one MFMA
+//     k-block), because a half is what one batch of 16 MFMAs consumes:
+//       - x lives in a ring of 6 half-slots [256 rows][32 ch] (16 KiB each, XOR-swizzled
+//         through the DMA source address), DMA'd 2.5-3 steps ahead of its MFMAs;
+//       - MFMA fragments are double-buffered in registers by halves: while the 16 MFMAs of
+//         (t, kk=0) run, the fragments of (t, kk=1) are read; while those run, (t+1, kk=0);
+//       - W16 (the fp16 weight tile, [2][128 rows][64 ch], XOR-swizzled) is produced half a
+//         step ahead of its first reader: in step t the waves owning chunk quarters 2,3
+//         dequantise chunk t+1 and those owning quarters 0,1 dequantise chunk t+2.
+//     So nothing the MFMAs of a step need is produced in that step: LDS latency and the
+//     dequant VALU chain hide under the matrix pipe.  Hazard table in DESIGN.md section 4.
 //   * dequant is done ONCE per workgroup per K-step: every thread turns 16 packed weights
-//     (read from the LDS copy of the block) into fp16 with the LUT / v_perm_b32 helpers and
-//     writes 32 B into a double-buffered, XOR-swizzled W16 tile.  The fp16 weight never
-//     exists outside LDS.
-//   * the K-loop body is ONE straight-line basic block per wave role (the kernel is
-//     specialised on "this wave dequantises a 2-bit group" / "... the 4-bit arm", and the
-//     pipeline tail is peeled), with all 16 fragment reads and the dequant operand reads
-//     issued up front, so the compiler interleaves the dequant VALU chain and the LDS
-//     latencies with the 32 MFMAs instead of serialising them (measured by ablation, round 1:
-//     DMA 33 us + MFMA 30 us + dequant 19 us + fragment reads 18 us were simply adding up).
+//     (read from the LDS copy of the block) into fp16 with the LUT / v_perm_b32 helpers; the
+//     fp16 weight never exists outside LDS.  The K loop is specialised on the wave's dequant
+//     role (2-bit group / 4-bit arm) and the pipeline tail is peeled, so a steady-state step
+//     is one straight-line block fenced into phases with sched_barrier.
 //   * D^T = W . x^T: a lane owns 4 consecutive output channels of one token (8-B stores).
 //   * tiles are dealt to the 8 XCDs as compact 2-D blocks (4 x 2 regions of the tile grid) so
 //     that an XCD's L2 sees 1/4 of x and 1/2 of W instead of all of x.
@@ -52,19 +53,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 256, BN = 128, BK = 64, THREADS = 512;
-constexpr int A_STAGE = BM * BK * 2;            // 32 KiB
-constexpr int A_SLOTS = 3;
-constexpr int BP_WAVE = 1024;                  // one 64-lane DMA per wave: 576-B block + 448 B of padding
+constexpr int AH_BYTES = BM * 32 * 2;           // one x half-slot: 256 rows x 32 channels = 16 KiB
+constexpr int AH_SLOTS = 6;
+constexpr int BP_WAVE = 1024;                   // one 64-lane DMA per wave: 576-B block + 448 B padding
 constexpr int BP_STAGE = (BN / 16) * BP_WAVE;   // 8 KiB
 constexpr int BP_SLOTS = 4;
 constexpr int W_STAGE = BN * BK * 2;            // 16 KiB
 constexpr int OFF_A = 0;
-constexpr int OFF_BP = OFF_A + A_SLOTS * A_STAGE;
+constexpr int OFF_BP = OFF_A + AH_SLOTS * AH_BYTES;
 constexpr int OFF_W = OFF_BP + BP_SLOTS * BP_STAGE;
 constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;   // 163,840 B = all of the CU's 160 KiB
 static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 
-__device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+// W16 tile: [128 rows][8 slots of 16 B], slot' = slot ^ (row & 7)
+__device__ __forceinline__ int swz_w(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+// x half-slot: [256 rows][4 pieces of 16 B], piece' = piece ^ g(row), g = (-(row >> 2)) & 3:
+// makes the ds_read_b128 of a 16-row x 4-piece fragment conflict-free (64-B rows alias every
+// 4 rows in the 256-B bank window).
+__device__ __forceinline__ int ga(int row) { return (0 - (row >> 2)) & 3; }
+__device__ __forceinline__ int swz_a(int row, int piece) { return row * 64 + ((piece ^ ga(row)) << 4); }
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -97,7 +104,7 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
 
 struct Ctx {
     char* smem;
-    const uint16_t* a_src[4];
+    const uint16_t* a_src[2];   // this lane's source for the wave's two 16-row DMA groups
     const char* bp_src;
     int wave, lane;
     int d_row, d_q, d_blk, d_r;
@@ -106,19 +113,20 @@ struct Ctx {
     int NT;
 };
 
-__device__ __forceinline__ void issue_a(const Ctx& c, int t) {
-    char* dst = c.smem + OFF_A + (t % A_SLOTS) * A_STAGE + c.wave * 4096;
+// x half h (channels 32h .. 32h+31): wave w's DMA i fills rows 16*(2w+i) .. +15 of the half-slot
+__device__ __forceinline__ void issue_a_half(const Ctx& c, int h) {
+    char* dst = c.smem + OFF_A + (h % AH_SLOTS) * AH_BYTES + c.wave * 2048;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(c.a_src[i] + t * BK, dst + i * 1024);
+    for (int i = 0; i < 2; ++i) glds16(c.a_src[i] + h * 32, dst + i * 1024);
 }
 __device__ __forceinline__ void issue_bp(const Ctx& c, int t) {
-    // all 64 lanes take part (no exec-masked branch in the K loop): lanes >= 36 re-read the block's
-    // last 16 bytes and land in the slot's padding
+    // all 64 lanes take part (no exec-masked branch in the K loop): lanes >= 36 re-read the
+    // block's last 16 bytes and land in the slot's padding
     char* dst = c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.wave * BP_WAVE;
     glds16(c.bp_src + (int64_t)t * MXQ_BLK_BYTES, dst);
 }
 
-// packed operands of this thread's 16 weights of K-step t, from the LDS copy of the block
+// packed operands of this thread's 16 weights of chunk t, from the LDS copy of the block
 struct DeqIn {
     uint32_t a, b, c, d, e;
 };
@@ -151,26 +159,26 @@ __device__ __forceinline__ void deq_math(const Ctx& c, const DeqIn& in, uint32_t
 }
 __device__ __forceinline__ void deq_store(const Ctx& c, int t, const uint32_t o[8]) {
     char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
-    *(u32x4*)(wt + swz(c.d_row, c.d_q * 2)) = (u32x4){o[0], o[1], o[2], o[3]};
-    *(u32x4*)(wt + swz(c.d_row, c.d_q * 2 + 1)) = (u32x4){o[4], o[5], o[6], o[7]};
+    *(u32x4*)(wt + swz_w(c.d_row, c.d_q * 2)) = (u32x4){o[0], o[1], o[2], o[3]};
+    *(u32x4*)(wt + swz_w(c.d_row, c.d_q * 2 + 1)) = (u32x4){o[4], o[5], o[6], o[7]};
 }
 
 typedef half8 Frag4[4];
 
-// fragments of K-step t, half kk (32 of the 64 channels of the chunk)
+// fragments of K-step t, half kk
 __device__ __forceinline__ void load_frags(const Ctx& c, int t, int kk, Frag4& wf, Frag4& xf) {
-    const char* a_base = c.smem + OFF_A + (t % A_SLOTS) * A_STAGE;
+    const char* a_base = c.smem + OFF_A + ((2 * t + kk) % AH_SLOTS) * AH_BYTES;
     const char* w_base = c.smem + OFF_W + (t & 1) * W_STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(w_base + swz(c.wn * 64 + i * 16 + c.fr, kk * 4 + c.fq));
+    for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(w_base + swz_w(c.wn * 64 + i * 16 + c.fr, kk * 4 + c.fq));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz(c.wm * 64 + j * 16 + c.fr, kk * 4 + c.fq));
+    for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz_a(c.wm * 64 + j * 16 + c.fr, c.fq));
 }
 
-template <int ABL>
-__device__ __forceinline__ void mfma16(f32x4 (&acc)[4][4], const Frag4& wf, const Frag4& xf) {
+template <int ABL, int I0, int I1>
+__device__ __forceinline__ void mfma_rows(f32x4 (&acc)[4][4], const Frag4& wf, const Frag4& xf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = I0; i < I1; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (ABL & 2) asm volatile("" ::"v"(wf[i]), "v"(xf[j]));
@@ -178,47 +186,50 @@ __device__ __forceinline__ void mfma16(f32x4 (&acc)[4][4], const Frag4& wf, cons
         }
 }
 
-// One K-step t, software-pipelined by half a step in registers: on entry (wf0, xf0) hold the
-// kk = 0 fragments of step t (read during step t-1).  The kk = 1 fragments are read while the
-// kk = 0 MFMAs run, the kk = 0 fragments of step t+1 while the kk = 1 MFMAs run; W16(t+2) is
-// dequantised and the DMAs of x tile t+3 / packed block t+4 are issued -- nothing the MFMAs of
-// this step need is produced in this step, so LDS latency and the dequant VALU chain hide
-// under the matrix pipe.  TAIL = false: steady state, unconditional -> one basic block.
+// One K-step t.  On entry (wf0, xf0) hold the kk = 0 fragments of step t (read in step t-1).
+// TAIL = false: steady state, unconditional -> one straight-line block.
 template <bool IS4, bool TAIL, int ABL>
 __device__ __forceinline__ void kstep(const Ctx& c, int t, f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1,
                                       Frag4& xf1) {
+    // DMAs: x halves 2t+5, 2t+6 and packed block t+4 (5 per wave)
     if constexpr (!(ABL & 1)) {
-        if (!TAIL || t + 3 < c.NT) issue_a(c, t + 3);
+        if (!TAIL || t + 2 < c.NT) issue_a_half(c, 2 * t + 5);
+        if (!TAIL || t + 3 < c.NT) issue_a_half(c, 2 * t + 6);
     }
     if (!TAIL || t + 4 < c.NT) issue_bp(c, t + 4);
+    // the first 4 MFMAs go out before any LDS read of this step is queued (their operands
+    // were waited for at the end of the previous step)
+    mfma_rows<ABL, 0, 1>(acc, wf0, xf0);
+    __builtin_amdgcn_sched_barrier(0);
 
-    const bool do_deq = (!TAIL || t + 2 < c.NT) && !(ABL & 4);
-    constexpr int MFMA = 0x8, VALU = 0x2;
-    // phase 1: every LDS read that does not depend on this step
+    // this wave dequantises chunk t+2 (quarters 0,1 = half kk 0) or t+1 (quarters 2,3 = kk 1)
+    const int dc = t + (c.d_q < 2 ? 2 : 1);
+    const bool do_deq = (!TAIL || dc < c.NT) && !(ABL & 4);
     DeqIn din = {};
-    if (do_deq) din = deq_load<IS4>(c, t + 2);
+    if (do_deq) din = deq_load<IS4>(c, dc);
     if constexpr (!(ABL & 8)) load_frags(c, t, 1, wf1, xf1);
     __builtin_amdgcn_sched_barrier(0);
-    // phase 2: kk = 0 MFMAs with the dequant VALU chain threaded between them (guide T19)
-    mfma16<ABL>(acc, wf0, xf0);
+
+    mfma_rows<ABL, 1, 4>(acc, wf0, xf0);
     uint32_t o[8];
     if (do_deq) deq_math<IS4>(c, din, o);
     if constexpr (!TAIL && ABL == 0) {
+        constexpr int MFMA = 0x8, VALU = 0x2;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 12; ++i) {   // thread the dequant VALU chain between the MFMAs (guide T19)
             __builtin_amdgcn_sched_group_barrier(MFMA, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(VALU, IS4 ? 4 : 3, 0);
+            __builtin_amdgcn_sched_group_barrier(VALU, IS4 ? 5 : 3, 0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    // phase 3: kk = 0 fragments of the next step (their registers are free now)
-    if constexpr (!(ABL & 8)) {
+
+    if constexpr (!(ABL & 8)) {   // kk = 0 fragments of the next step (their registers are free now)
         if (!TAIL || t + 1 < c.NT) load_frags(c, t + 1, 0, wf0, xf0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // phase 4: kk = 1 MFMAs, W16(t+2) stores
-    mfma16<ABL>(acc, wf1, xf1);
-    if (do_deq) deq_store(c, t + 2, o);
+
+    mfma_rows<ABL, 0, 4>(acc, wf1, xf1);
+    if (do_deq) deq_store(c, dc, o);
     __builtin_amdgcn_sched_barrier(0);
 
     if (!TAIL) {
@@ -238,6 +249,8 @@ __device__ __forceinline__ void kloop(const Ctx& c, f32x4 (&acc)[4][4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) wf1[i] = xf1[i] = wf0[i];
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave holds its (0, kk=0) fragments before W16[0] is rewritten
     int t = 0;
     for (; t + 4 < c.NT; ++t) kstep<IS4, false, ABL>(c, t, acc, wf0, xf0, wf1, xf1);
     for (; t < c.NT; ++t) kstep<IS4, true, ABL>(c, t, acc, wf0, xf0, wf1, xf1);
@@ -263,16 +276,16 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA sources -------------------------------------------------------------------
-    // x: DMA i of wave w fills rows 8*(4w+i) .. +7 of the A slot; LDS slot lane%8 of a row
-    // receives global 16-B slot (lane%8) ^ (row&7).
+    // x: lane -> row 16*(2w+i) + lane/4; LDS piece lane%4 of that row receives global piece
+    // (lane%4) ^ g(row) of the half.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (c.wave * 4 + i) * 8 + (c.lane >> 3);
+    for (int i = 0; i < 2; ++i) {
+        const int row = (c.wave * 2 + i) * 16 + (c.lane >> 2);
         int gm = m0 + row;
         gm = gm < M ? gm : M - 1;
-        c.a_src[i] = x + (int64_t)gm * K + (((c.lane & 7) ^ (row & 7)) << 3);
+        c.a_src[i] = x + (int64_t)gm * K + (((c.lane & 3) ^ ga(row)) << 3);
     }
-    // packed W: wave w copies the 576-B block of 16-row block (n0/16 + w), lanes 0..35.
+    // packed W: wave w copies the 576-B block of 16-row block (n0/16 + w)
     int rb = (n0 >> 4) + c.wave;
     rb = rb < (N >> 4) ? rb : (N >> 4) - 1;
     c.bp_src = (const char*)(qweight + (int64_t)rb * c.NT * MXQ_BLK_DW) + (c.lane < 36 ? c.lane : 35) * 16;
@@ -302,12 +315,13 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: fill the rings, dequantise step 0 ---------------------------------------
-    for (int t = 0; t < 3 && t < c.NT; ++t) issue_a(c, t);
+    // ---- prologue: x halves 0..4, packed blocks 0..3; W16(0) entirely, W16(1) quarters 0,1 ----
+    for (int h = 0; h < 5 && h < 2 * c.NT; ++h) issue_a_half(c, h);
     for (int t = 0; t < 4 && t < c.NT; ++t) issue_bp(c, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < 2 && t < c.NT; ++t) {   // W16(0), W16(1): both buffers
+    for (int t = 0; t < 2 && t < c.NT; ++t) {
+        if (t == 1 && c.d_q >= 2) break;   // (1, kk=1) is produced by step 0
         uint32_t o[8];
         if (c.d_q == 3) {
             const DeqIn in = deq_load<true>(c, t);
