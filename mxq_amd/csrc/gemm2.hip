@@ -14,17 +14,14 @@
 //     channels: codes, zeros, scale codes, (qs,qz)) verbatim into a 1-KiB slot.  Each step
 //     ends with a COUNTED s_waitcnt vmcnt(5) + raw s_barrier: the newest step's DMAs stay in
 //     flight across the barrier (cdna guide T3/T4).
-//   * everything is software-pipelined in HALF K-steps ("halves": 32 channels, one MFMA
-//     k-block), because a half is what one batch of 16 MFMAs consumes:
-//       - x lives in a ring of 6 half-slots [256 rows][32 ch] (16 KiB each, XOR-swizzled
-//         through the DMA source address), DMA'd 2.5-3 steps ahead of its MFMAs;
-//       - MFMA fragments are double-buffered in registers by halves: while the 16 MFMAs of
-//         (t, kk=0) run, the fragments of (t, kk=1) are read; while those run, (t+1, kk=0);
-//       - W16 (the fp16 weight tile, [2][128 rows][64 ch], XOR-swizzled) is produced half a
-//         step ahead of its first reader: in step t the waves owning chunk quarters 2,3
-//         dequantise chunk t+1 and those owning quarters 0,1 dequantise chunk t+2.
-//     So nothing the MFMAs of a step need is produced in that step: LDS latency and the
-//     dequant VALU chain hide under the matrix pipe.  Hazard table in DESIGN.md section 4.
+//   * the x tile is DMA'd 2 K-steps ahead (3 slots of [256 rows][64 ch], XOR-swizzled through
+//     the DMA source address, 8 full 128-B lines per DMA), the packed blocks 3 ahead (4 slots).
+//   * the MFMA schedule is shifted by HALF a K-step against the loop: step t runs the 16 MFMAs
+//     of (t-1, kk=1) and then those of (t, kk=0), with the fragments double-buffered in two
+//     32-VGPR register sets: while one batch runs, the other batch's fragments and the dequant
+//     operands are read; W16(t+1) is dequantised during step t.  Nothing an MFMA batch needs
+//     is produced while it runs, so LDS latency and the dequant VALU chain hide under the
+//     matrix pipe, and chunk t is only ever read during step t (hazards: DESIGN.md section 4).
 //   * dequant is done ONCE per workgroup per K-step: every thread turns 16 packed weights
 //     (read from the LDS copy of the block) into fp16 with the LUT / v_perm_b32 helpers; the
 //     fp16 weight never exists outside LDS.  The K loop is specialised on the wave's dequant
@@ -53,25 +50,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 256, BN = 128, BK = 64, THREADS = 512;
-constexpr int AH_BYTES = BM * 32 * 2;           // one x half-slot: 256 rows x 32 channels = 16 KiB
-constexpr int AH_SLOTS = 6;
+constexpr int A_STAGE = BM * BK * 2;            // one x slot: 256 rows x 64 channels = 32 KiB
+constexpr int A_SLOTS = 3;
 constexpr int BP_WAVE = 1024;                   // one 64-lane DMA per wave: 576-B block + 448 B padding
 constexpr int BP_STAGE = (BN / 16) * BP_WAVE;   // 8 KiB
 constexpr int BP_SLOTS = 4;
 constexpr int W_STAGE = BN * BK * 2;            // 16 KiB
 constexpr int OFF_A = 0;
-constexpr int OFF_BP = OFF_A + AH_SLOTS * AH_BYTES;
+constexpr int OFF_BP = OFF_A + A_SLOTS * A_STAGE;
 constexpr int OFF_W = OFF_BP + BP_SLOTS * BP_STAGE;
 constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;   // 163,840 B = all of the CU's 160 KiB
 static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 
-// W16 tile: [128 rows][8 slots of 16 B], slot' = slot ^ (row & 7)
-__device__ __forceinline__ int swz_w(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
-// x half-slot: [256 rows][4 pieces of 16 B], piece' = piece ^ g(row), g = (-(row >> 2)) & 3:
-// makes the ds_read_b128 of a 16-row x 4-piece fragment conflict-free (64-B rows alias every
-// 4 rows in the 256-B bank window).
-__device__ __forceinline__ int ga(int row) { return (0 - (row >> 2)) & 3; }
-__device__ __forceinline__ int swz_a(int row, int piece) { return row * 64 + ((piece ^ ga(row)) << 4); }
+// x and W16 tiles: [rows][8 slots of 16 B], slot' = slot ^ (row & 7) (conflict-free ds_read_b128
+// of a 16-row x 4-slot fragment and ds_write_b128 of 8 consecutive rows)
+__device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -104,7 +97,7 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
 
 struct Ctx {
     char* smem;
-    const uint16_t* a_src[2];   // this lane's source for the wave's two 16-row DMA groups
+    const uint16_t* a_src[4];   // this lane's source for the wave's four 8-row DMA groups
     const char* bp_src;
     int wave, lane;
     int d_row, d_q, d_blk, d_r;
@@ -113,11 +106,11 @@ struct Ctx {
     int NT;
 };
 
-// x half h (channels 32h .. 32h+31): wave w's DMA i fills rows 16*(2w+i) .. +15 of the half-slot
-__device__ __forceinline__ void issue_a_half(const Ctx& c, int h) {
-    char* dst = c.smem + OFF_A + (h % AH_SLOTS) * AH_BYTES + c.wave * 2048;
+// x tile of K-step t: wave w's DMA i fills rows 8*(4w+i) .. +7 (8 full 128-B lines per DMA)
+__device__ __forceinline__ void issue_a(const Ctx& c, int t) {
+    char* dst = c.smem + OFF_A + (t % A_SLOTS) * A_STAGE + c.wave * 4096;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(c.a_src[i] + h * 32, dst + i * 1024);
+    for (int i = 0; i < 4; ++i) glds16(c.a_src[i] + t * BK, dst + i * 1024);
 }
 __device__ __forceinline__ void issue_bp(const Ctx& c, int t) {
     // all 64 lanes take part (no exec-masked branch in the K loop): lanes >= 36 re-read the
@@ -159,20 +152,20 @@ __device__ __forceinline__ void deq_math(const Ctx& c, const DeqIn& in, uint32_t
 }
 __device__ __forceinline__ void deq_store(const Ctx& c, int t, const uint32_t o[8]) {
     char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
-    *(u32x4*)(wt + swz_w(c.d_row, c.d_q * 2)) = (u32x4){o[0], o[1], o[2], o[3]};
-    *(u32x4*)(wt + swz_w(c.d_row, c.d_q * 2 + 1)) = (u32x4){o[4], o[5], o[6], o[7]};
+    *(u32x4*)(wt + swz(c.d_row, c.d_q * 2)) = (u32x4){o[0], o[1], o[2], o[3]};
+    *(u32x4*)(wt + swz(c.d_row, c.d_q * 2 + 1)) = (u32x4){o[4], o[5], o[6], o[7]};
 }
 
 typedef half8 Frag4[4];
 
 // fragments of K-step t, half kk
 __device__ __forceinline__ void load_frags(const Ctx& c, int t, int kk, Frag4& wf, Frag4& xf) {
-    const char* a_base = c.smem + OFF_A + ((2 * t + kk) % AH_SLOTS) * AH_BYTES;
+    const char* a_base = c.smem + OFF_A + (t % A_SLOTS) * A_STAGE;
     const char* w_base = c.smem + OFF_W + (t & 1) * W_STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(w_base + swz_w(c.wn * 64 + i * 16 + c.fr, kk * 4 + c.fq));
+    for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(w_base + swz(c.wn * 64 + i * 16 + c.fr, kk * 4 + c.fq));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz_a(c.wm * 64 + j * 16 + c.fr, c.fq));
+    for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz(c.wm * 64 + j * 16 + c.fr, kk * 4 + c.fq));
 }
 
 template <int ABL, int I0, int I1>
@@ -186,50 +179,40 @@ __device__ __forceinline__ void mfma_rows(f32x4 (&acc)[4][4], const Frag4& wf, c
         }
 }
 
-// One K-step t.  On entry (wf0, xf0) hold the kk = 0 fragments of step t (read in step t-1).
-// TAIL = false: steady state, unconditional -> one straight-line block.
-template <bool IS4, bool TAIL, int ABL>
+// One K-step t, shifted by half a step against the MFMAs: it runs the 16 MFMAs of (t-1, kk=1)
+// from (wf1, xf1) -- read at the end of step t-1 -- then the 16 MFMAs of (t, kk=0).  While the
+// first batch runs the (t, kk=0) fragments and the dequant operands of chunk t+1 are read;
+// while the second runs, the (t, kk=1) fragments.  So chunk t is only read during step t
+// (3 full x slots and 2 W16 buffers suffice) and nothing an MFMA batch needs is produced
+// while it runs.  FIRST: step 0 (no previous half).  TAIL: pipeline drain, conditional issue.
+template <bool IS4, bool FIRST, bool TAIL, int ABL>
 __device__ __forceinline__ void kstep(const Ctx& c, int t, f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1,
                                       Frag4& xf1) {
-    // DMAs: x halves 2t+5, 2t+6 and packed block t+4 (5 per wave)
     if constexpr (!(ABL & 1)) {
-        if (!TAIL || t + 2 < c.NT) issue_a_half(c, 2 * t + 5);
-        if (!TAIL || t + 3 < c.NT) issue_a_half(c, 2 * t + 6);
+        if (!TAIL || t + 2 < c.NT) issue_a(c, t + 2);
     }
-    if (!TAIL || t + 4 < c.NT) issue_bp(c, t + 4);
-    // the first 4 MFMAs go out before any LDS read of this step is queued (their operands
-    // were waited for at the end of the previous step)
-    mfma_rows<ABL, 0, 1>(acc, wf0, xf0);
+    if (!TAIL || t + 3 < c.NT) issue_bp(c, t + 3);
+    // 4 MFMAs go out before any LDS read of this step is queued (operands were waited for at
+    // the end of the previous step)
+    if constexpr (!FIRST) mfma_rows<ABL, 0, 1>(acc, wf1, xf1);
     __builtin_amdgcn_sched_barrier(0);
 
-    // this wave dequantises chunk t+2 (quarters 0,1 = half kk 0) or t+1 (quarters 2,3 = kk 1)
-    const int dc = t + (c.d_q < 2 ? 2 : 1);
-    const bool do_deq = (!TAIL || dc < c.NT) && !(ABL & 4);
+    const bool do_deq = (!TAIL || t + 1 < c.NT) && !(ABL & 4);
     DeqIn din = {};
-    if (do_deq) din = deq_load<IS4>(c, dc);
-    if constexpr (!(ABL & 8)) load_frags(c, t, 1, wf1, xf1);
+    if (do_deq) din = deq_load<IS4>(c, t + 1);
+    if constexpr (!(ABL & 8)) load_frags(c, t, 0, wf0, xf0);
     __builtin_amdgcn_sched_barrier(0);
 
-    mfma_rows<ABL, 1, 4>(acc, wf0, xf0);
+    if constexpr (!FIRST) mfma_rows<ABL, 1, 4>(acc, wf1, xf1);
     uint32_t o[8];
     if (do_deq) deq_math<IS4>(c, din, o);
-    if constexpr (!TAIL && ABL == 0) {
-        constexpr int MFMA = 0x8, VALU = 0x2;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {   // thread the dequant VALU chain between the MFMAs (guide T19)
-            __builtin_amdgcn_sched_group_barrier(MFMA, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(VALU, IS4 ? 5 : 3, 0);
-        }
-    }
     __builtin_amdgcn_sched_barrier(0);
 
-    if constexpr (!(ABL & 8)) {   // kk = 0 fragments of the next step (their registers are free now)
-        if (!TAIL || t + 1 < c.NT) load_frags(c, t + 1, 0, wf0, xf0);
-    }
+    if constexpr (!(ABL & 8)) load_frags(c, t, 1, wf1, xf1);   // (wf1, xf1) are free now
     __builtin_amdgcn_sched_barrier(0);
 
-    mfma_rows<ABL, 0, 4>(acc, wf1, xf1);
-    if (do_deq) deq_store(c, dc, o);
+    mfma_rows<ABL, 0, 4>(acc, wf0, xf0);
+    if (do_deq) deq_store(c, t + 1, o);
     __builtin_amdgcn_sched_barrier(0);
 
     if (!TAIL) {
@@ -244,16 +227,16 @@ __device__ __forceinline__ void kstep(const Ctx& c, int t, f32x4 (&acc)[4][4], F
 template <bool IS4, int ABL>
 __device__ __forceinline__ void kloop(const Ctx& c, f32x4 (&acc)[4][4]) {
     Frag4 wf0, xf0, wf1, xf1;   // named register sets (static indexing: guide rule 20)
-    load_frags(c, 0, 0, wf0, xf0);
     if constexpr (ABL & 8) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wf1[i] = xf1[i] = wf0[i];
+        for (int i = 0; i < 4; ++i) wf0[i] = xf0[i] = wf1[i] = xf1[i] = (half8){1, 2, 3, 4, 5, 6, 7, 8};
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // every wave holds its (0, kk=0) fragments before W16[0] is rewritten
     int t = 0;
-    for (; t + 4 < c.NT; ++t) kstep<IS4, false, ABL>(c, t, acc, wf0, xf0, wf1, xf1);
-    for (; t < c.NT; ++t) kstep<IS4, true, ABL>(c, t, acc, wf0, xf0, wf1, xf1);
+    if (c.NT > 3) kstep<IS4, true, false, ABL>(c, 0, acc, wf0, xf0, wf1, xf1);
+    else kstep<IS4, true, true, ABL>(c, 0, acc, wf0, xf0, wf1, xf1);
+    for (t = 1; t + 3 < c.NT; ++t) kstep<IS4, false, false, ABL>(c, t, acc, wf0, xf0, wf1, xf1);
+    for (; t < c.NT; ++t) kstep<IS4, false, true, ABL>(c, t, acc, wf0, xf0, wf1, xf1);
+    mfma_rows<ABL, 0, 4>(acc, wf1, xf1);   // (NT-1, kk=1)
 }
 
 // ABL: ablation bits for profiling builds only (wrong results): 1 = no x DMA in the loop,
@@ -276,14 +259,14 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA sources -------------------------------------------------------------------
-    // x: lane -> row 16*(2w+i) + lane/4; LDS piece lane%4 of that row receives global piece
-    // (lane%4) ^ g(row) of the half.
+    // x: lane -> row 8*(4w+i) + lane/8; LDS slot lane%8 of that row receives global 16-B slot
+    // (lane%8) ^ (row&7).
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (c.wave * 2 + i) * 16 + (c.lane >> 2);
+    for (int i = 0; i < 4; ++i) {
+        const int row = (c.wave * 4 + i) * 8 + (c.lane >> 3);
         int gm = m0 + row;
         gm = gm < M ? gm : M - 1;
-        c.a_src[i] = x + (int64_t)gm * K + (((c.lane & 3) ^ ga(row)) << 3);
+        c.a_src[i] = x + (int64_t)gm * K + (((c.lane & 7) ^ (row & 7)) << 3);
     }
     // packed W: wave w copies the 576-B block of 16-row block (n0/16 + w)
     int rb = (n0 >> 4) + c.wave;
@@ -315,22 +298,21 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: x halves 0..4, packed blocks 0..3; W16(0) entirely, W16(1) quarters 0,1 ----
-    for (int h = 0; h < 5 && h < 2 * c.NT; ++h) issue_a_half(c, h);
-    for (int t = 0; t < 4 && t < c.NT; ++t) issue_bp(c, t);
+    // ---- prologue: x tiles 0,1, packed blocks 0..2; W16(0) ------------------------------------
+    for (int t = 0; t < 2 && t < c.NT; ++t) issue_a(c, t);
+    for (int t = 0; t < 3 && t < c.NT; ++t) issue_bp(c, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < 2 && t < c.NT; ++t) {
-        if (t == 1 && c.d_q >= 2) break;   // (1, kk=1) is produced by step 0
+    {
         uint32_t o[8];
         if (c.d_q == 3) {
-            const DeqIn in = deq_load<true>(c, t);
+            const DeqIn in = deq_load<true>(c, 0);
             deq_math<true>(c, in, o);
         } else {
-            const DeqIn in = deq_load<false>(c, t);
+            const DeqIn in = deq_load<false>(c, 0);
             deq_math<false>(c, in, o);
         }
-        deq_store(c, t, o);
+        deq_store(c, 0, o);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
