@@ -15,14 +15,13 @@
 //     ends with a COUNTED s_waitcnt vmcnt(5) + raw s_barrier: the newest step's DMAs stay in
 //     flight across the barrier (cdna guide T3/T4).
 //   * the x tile is DMA'd 2 K-steps ahead (3 slots of [256 rows][64 ch], XOR-swizzled through
-//     the DMA source address, 8 full 128-B lines per DMA), the packed blocks 5 ahead (6 slots).
+//     the DMA source address, 8 full 128-B lines per DMA), the packed blocks 3 ahead (4 slots).
 //   * the MFMA schedule is shifted by HALF a K-step against the loop: step t runs the 16 MFMAs
 //     of (t-1, kk=1) and then those of (t, kk=0), with the fragments double-buffered in two
 //     32-VGPR register sets: while one batch runs, the other batch's fragments and the dequant
-//     operands are read.  The dequant itself is a 3-step register pipeline (store W16(t+1),
-//     compute chunk t+2, read operands of chunk t+3), so no LDS-read -> VALU -> LDS-write chain
-//     is left inside a step; nothing an MFMA batch needs is produced while it runs, and chunk t
-//     is only ever read during step t (hazards: DESIGN.md section 4).
+//     operands are read; W16(t+1) is dequantised during step t.  Nothing an MFMA batch needs
+//     is produced while it runs, so LDS latency and the dequant VALU chain hide under the
+//     matrix pipe, and chunk t is only ever read during step t (hazards: DESIGN.md section 4).
 //   * dequant is done ONCE per workgroup per K-step: every thread turns 16 packed weights
 //     (read from the LDS copy of the block) into fp16 with the LUT / v_perm_b32 helpers; the
 //     fp16 weight never exists outside LDS.  The K loop is specialised on the wave's dequant
@@ -53,14 +52,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 256, BN = 128, BK = 64, THREADS = 512;
 constexpr int A_STAGE = BM * BK * 2;            // one x slot: 256 rows x 64 channels = 32 KiB
 constexpr int A_SLOTS = 3;
-constexpr int BP_WAVE = MXQ_BLK_BYTES;          // one 36-lane DMA per wave copies one 576-B block
-constexpr int BP_STAGE = (BN / 16) * BP_WAVE;   // 4608 B
-constexpr int BP_SLOTS = 6;
+constexpr int BP_WAVE = 1024;                   // one 64-lane DMA per wave: 576-B block + 448 B padding
+constexpr int BP_STAGE = (BN / 16) * BP_WAVE;   // 8 KiB
+constexpr int BP_SLOTS = 4;
 constexpr int W_STAGE = BN * BK * 2;            // 16 KiB
 constexpr int OFF_A = 0;
 constexpr int OFF_BP = OFF_A + A_SLOTS * A_STAGE;
 constexpr int OFF_W = OFF_BP + BP_SLOTS * BP_STAGE;
-constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;   // 158,720 B of the CU's 160 KiB
+constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;   // 163,840 B = all of the CU's 160 KiB
 static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 
 // x and W16 tiles: [rows][8 slots of 16 B], slot' = slot ^ (row & 7) (conflict-free ds_read_b128
@@ -108,14 +107,19 @@ struct Ctx {
 };
 
 // x tile of K-step t: wave w's DMA i fills rows 8*(4w+i) .. +7 (8 full 128-B lines per DMA)
-__device__ __forceinline__ void issue_a(const Ctx& c, int t) {
+__device__ __forceinline__ void issue_a1(const Ctx& c, int t, int i) {
     char* dst = c.smem + OFF_A + (t % A_SLOTS) * A_STAGE + c.wave * 4096;
+    glds16(c.a_src[i] + t * BK, dst + i * 1024);
+}
+__device__ __forceinline__ void issue_a(const Ctx& c, int t) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(c.a_src[i] + t * BK, dst + i * 1024);
+    for (int i = 0; i < 4; ++i) issue_a1(c, t, i);
 }
 __device__ __forceinline__ void issue_bp(const Ctx& c, int t) {
+    // all 64 lanes take part (no exec-masked branch in the K loop): lanes >= 36 re-read the
+    // block's last 16 bytes and land in the slot's padding
     char* dst = c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.wave * BP_WAVE;
-    if (c.lane < 36) glds16(c.bp_src + (int64_t)t * MXQ_BLK_BYTES, dst);
+    glds16(c.bp_src + (int64_t)t * MXQ_BLK_BYTES, dst);
 }
 
 // packed operands of this thread's 16 weights of chunk t, from the LDS copy of the block
@@ -178,47 +182,54 @@ __device__ __forceinline__ void mfma_rows(f32x4 (&acc)[4][4], const Frag4& wf, c
         }
 }
 
-// One K-step t.
-//  * MFMAs, shifted by half a step against the loop: the 16 MFMAs of (t-1, kk=1) from (wf1, xf1)
-//    -- read at the end of step t-1 -- then the 16 MFMAs of (t, kk=0); while one batch runs the
-//    other batch's fragments are read.  Chunk t is therefore only read during step t.
-//  * dequant, a 3-step software pipeline carried in registers: store W16(t+1) (computed in
-//    step t-1), compute chunk t+2 (operands read in step t-1), read the operands of chunk t+3.
-//  No LDS-read -> VALU -> LDS-write chain is left inside a step, and nothing an MFMA batch
-//  needs is produced while it runs.  FIRST: step 0.  TAIL: pipeline drain, conditional issue.
+// One K-step t, shifted by half a step against the MFMAs: it runs the 16 MFMAs of (t-1, kk=1)
+// from (wf1, xf1) -- read at the end of step t-1 -- then the 16 MFMAs of (t, kk=0).  While the
+// first batch runs the (t, kk=0) fragments and the dequant operands of chunk t+1 are read;
+// while the second runs, the (t, kk=1) fragments.  So chunk t is only read during step t
+// (3 full x slots and 2 W16 buffers suffice) and nothing an MFMA batch needs is produced
+// while it runs.  FIRST: step 0 (no previous half).  TAIL: pipeline drain, conditional issue.
 template <bool IS4, bool FIRST, bool TAIL, int ABL>
 __device__ __forceinline__ void kstep(const Ctx& c, int t, f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1,
-                                      Frag4& xf1, DeqIn& din, uint32_t (&o)[8]) {
-    if constexpr (!(ABL & 1)) {
-        if (!TAIL || t + 2 < c.NT) issue_a(c, t + 2);
-    }
-    if (!TAIL || t + 5 < c.NT) issue_bp(c, t + 5);
-    if constexpr (!(ABL & 4)) {
-        if (!TAIL || t + 1 < c.NT) deq_store(c, t + 1, o);
-    }
+                                      Frag4& xf1) {
+    // The 5 LDS-DMAs of the step (x tile t+2: 4, packed block t+3: 1) are spread between the
+    // MFMA groups: a DMA costs the issuing wave tens of cycles, more when several are queued
+    // back to back (MI355X_MICROARCH.md, "LDS-DMA piece issue cost").
+    const bool do_a = (!TAIL || t + 2 < c.NT) && !(ABL & 1);
+    const bool do_bp = (!TAIL || t + 3 < c.NT);
     // 4 MFMAs go out before any LDS read of this step is queued (operands were waited for at
     // the end of the previous step)
     if constexpr (!FIRST) mfma_rows<ABL, 0, 1>(acc, wf1, xf1);
     __builtin_amdgcn_sched_barrier(0);
 
-    DeqIn din_next = {};
-    if constexpr (!(ABL & 4)) {
-        if (!TAIL || t + 3 < c.NT) din_next = deq_load<IS4>(c, t + 3);
-    }
+    const bool do_deq = (!TAIL || t + 1 < c.NT) && !(ABL & 4);
+    DeqIn din = {};
+    if (do_deq) din = deq_load<IS4>(c, t + 1);
     if constexpr (!(ABL & 8)) load_frags(c, t, 0, wf0, xf0);
     __builtin_amdgcn_sched_barrier(0);
 
-    if constexpr (!FIRST) mfma_rows<ABL, 1, 4>(acc, wf1, xf1);
-    if constexpr (!(ABL & 4)) {
-        if (!TAIL || t + 2 < c.NT) deq_math<IS4>(c, din, o);
-    }
+    if constexpr (!FIRST) mfma_rows<ABL, 1, 2>(acc, wf1, xf1);
+    if (do_a) issue_a1(c, t + 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!FIRST) mfma_rows<ABL, 2, 3>(acc, wf1, xf1);
+    if (do_a) issue_a1(c, t + 2, 1);
+    uint32_t o[8];
+    if (do_deq) deq_math<IS4>(c, din, o);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!FIRST) mfma_rows<ABL, 3, 4>(acc, wf1, xf1);
+    if (do_a) issue_a1(c, t + 2, 2);
     __builtin_amdgcn_sched_barrier(0);
 
     if constexpr (!(ABL & 8)) load_frags(c, t, 1, wf1, xf1);   // (wf1, xf1) are free now
     __builtin_amdgcn_sched_barrier(0);
 
-    mfma_rows<ABL, 0, 4>(acc, wf0, xf0);
-    din = din_next;
+    mfma_rows<ABL, 0, 1>(acc, wf0, xf0);
+    if (do_a) issue_a1(c, t + 2, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_rows<ABL, 1, 2>(acc, wf0, xf0);
+    if (do_bp) issue_bp(c, t + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_rows<ABL, 2, 4>(acc, wf0, xf0);
+    if (do_deq) deq_store(c, t + 1, o);
     __builtin_amdgcn_sched_barrier(0);
 
     if (!TAIL) {
@@ -237,19 +248,11 @@ __device__ __forceinline__ void kloop(const Ctx& c, f32x4 (&acc)[4][4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) wf0[i] = xf0[i] = wf1[i] = xf1[i] = (half8){1, 2, 3, 4, 5, 6, 7, 8};
     }
-    // dequant pipeline state: o = fp16 words of chunk 1, din = packed operands of chunk 2
-    DeqIn din = {};
-    uint32_t o[8] = {};
-    if (c.NT > 1) {
-        const DeqIn d1 = deq_load<IS4>(c, 1);
-        deq_math<IS4>(c, d1, o);
-    }
-    if (c.NT > 2) din = deq_load<IS4>(c, 2);
     int t = 0;
-    if (c.NT > 5) kstep<IS4, true, false, ABL>(c, 0, acc, wf0, xf0, wf1, xf1, din, o);
-    else kstep<IS4, true, true, ABL>(c, 0, acc, wf0, xf0, wf1, xf1, din, o);
-    for (t = 1; t + 5 < c.NT; ++t) kstep<IS4, false, false, ABL>(c, t, acc, wf0, xf0, wf1, xf1, din, o);
-    for (; t < c.NT; ++t) kstep<IS4, false, true, ABL>(c, t, acc, wf0, xf0, wf1, xf1, din, o);
+    if (c.NT > 3) kstep<IS4, true, false, ABL>(c, 0, acc, wf0, xf0, wf1, xf1);
+    else kstep<IS4, true, true, ABL>(c, 0, acc, wf0, xf0, wf1, xf1);
+    for (t = 1; t + 3 < c.NT; ++t) kstep<IS4, false, false, ABL>(c, t, acc, wf0, xf0, wf1, xf1);
+    for (; t < c.NT; ++t) kstep<IS4, false, true, ABL>(c, t, acc, wf0, xf0, wf1, xf1);
     mfma_rows<ABL, 0, 4>(acc, wf1, xf1);   // (NT-1, kk=1)
 }
 
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
     // packed W: wave w copies the 576-B block of 16-row block (n0/16 + w)
     int rb = (n0 >> 4) + c.wave;
     rb = rb < (N >> 4) ? rb : (N >> 4) - 1;
-    c.bp_src = (const char*)(qweight + (int64_t)rb * c.NT * MXQ_BLK_DW) + c.lane * 16;
+    c.bp_src = (const char*)(qweight + (int64_t)rb * c.NT * MXQ_BLK_DW) + (c.lane < 36 ? c.lane : 35) * 16;
 
     // ---- dequant role: thread -> (W row = 64*(wave&1) + lane, chunk quarter = wave>>1) ---
     c.d_row = (c.wave & 1) * 64 + c.lane;
@@ -312,9 +315,9 @@ __global__ __launch_bounds__(THREADS, 2) void mxq_gemm2_f16_kernel(const uint16_
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: x tiles 0,1, packed blocks 0..4; W16(0) ------------------------------------
+    // ---- prologue: x tiles 0,1, packed blocks 0..2; W16(0) ------------------------------------
     for (int t = 0; t < 2 && t < c.NT; ++t) issue_a(c, t);
-    for (int t = 0; t < 5 && t < c.NT; ++t) issue_bp(c, t);
+    for (int t = 0; t < 3 && t < c.NT; ++t) issue_bp(c, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {

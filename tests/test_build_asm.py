@@ -32,24 +32,20 @@ def test_gemm2_main_loop_keeps_dma_in_flight():
     body = s[m.end():]
     body = body[:body.index(".Lfunc_end")]
     lines = body.splitlines()
-    # every counted wait closes a pipelined K-step (one per wave role, plus the peeled first step):
-    # between the previous s_barrier and the counted wait there must be no draining vmcnt(0)
+    # one steady-state K-step per wave role (2-bit dequant waves, 4-bit dequant waves): the code
+    # between the previous s_barrier and the counted wait
     idx = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(5) lgkmcnt(0)" in l]
-    assert len(idx) >= 2, "expected a counted steady-state wait per wave role"
+    assert len(idx) == 2, "expected one counted steady-state wait per wave role"
     for end in idx:
         start = max(i for i, l in enumerate(lines[:end]) if "s_barrier" in l)
         step = lines[start:end + 1]
         drains = [l for l in step if re.search(r"s_waitcnt.*vmcnt\(0\)", l)]
         assert not drains, f"compiler-inserted drain inside the K loop: {drains}"
+        # hipcc may sink register-only MFMAs below the wait/barrier (legal, they touch no memory):
+        # count them up to the loop's backward branch
+        tail_end = end + next(i for i, l in enumerate(lines[end:]) if "s_cbranch_scc" in l)
+        assert sum("v_mfma_f32_16x16x32_f16" in l for l in lines[start:tail_end]) == 32
         assert sum("ds_read_b128" in l for l in step) == 16
-    # 32 MFMAs per K-step in the two steady-state loop bodies (hipcc may sink register-only MFMAs
-    # below the wait / barrier, so count per loop)
-    hdrs = [i for i, l in enumerate(lines) if "Loop Header" in l]
-    per_loop = []
-    for h in hdrs:
-        end = h + next(i for i, l in enumerate(lines[h:]) if re.search(r"s_cbranch_scc\d", l))
-        per_loop.append(sum("v_mfma_f32_16x16x32_f16" in l for l in lines[h:end]))
-    assert per_loop.count(32) >= 2, per_loop
 
 
 @pytest.mark.parametrize("src", ["gemm.hip", "gemm2.hip", "gemv.hip", "fakequant.hip", "pack.hip"])
