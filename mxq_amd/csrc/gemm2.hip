@@ -15,7 +15,7 @@
 //     ends with a COUNTED s_waitcnt vmcnt(5) + raw s_barrier: the newest step's DMAs stay in
 //     flight across the barrier (cdna guide T3/T4).
 //   * the x tile is DMA'd 2 K-steps ahead (3 slots of [256 rows][64 ch], XOR-swizzled through
-//     the DMA source address, 8 full 128-B lines per DMA), the packed blocks 3 ahead (4 slots).
+//     the DMA source address, 8 full 128-B lines per DMA), the packed blocks 3 ahead (3 slots).
 //   * the MFMA schedule is shifted by HALF a K-step against the loop: step t runs the 16 MFMAs
 //     of (t-1, kk=1) and then those of (t, kk=0), with the fragments double-buffered in two
 //     32-VGPR register sets: while one batch runs, the other batch's fragments and the dequant
@@ -52,14 +52,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 256, BN = 128, BK = 64, THREADS = 512;
 constexpr int A_STAGE = BM * BK * 2;            // one x slot: 256 rows x 64 channels = 32 KiB
 constexpr int A_SLOTS = 3;
-constexpr int BP_WAVE = 1024;                   // one 64-lane DMA per wave: 576-B block + 448 B padding
-constexpr int BP_STAGE = (BN / 16) * BP_WAVE;   // 8 KiB
-constexpr int BP_SLOTS = 4;
+constexpr int BP_WAVE = 1088;                   // one 64-lane DMA per wave: 576-B block + padding; 1088 B = 272
+                                                // dwords keeps the 4 blocks a wave reads on distinct banks
+constexpr int BP_STAGE = (BN / 16) * BP_WAVE;   // 8704 B
+constexpr int BP_SLOTS = 3;
 constexpr int W_STAGE = BN * BK * 2;            // 16 KiB
 constexpr int OFF_A = 0;
 constexpr int OFF_BP = OFF_A + A_SLOTS * A_STAGE;
 constexpr int OFF_W = OFF_BP + BP_SLOTS * BP_STAGE;
-constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;   // 163,840 B = all of the CU's 160 KiB
+constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;   // 157,184 B of the CU's 160 KiB
 static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 
 // x and W16 tiles: [rows][8 slots of 16 B], slot' = slot ^ (row & 7) (conflict-free ds_read_b128

@@ -32,20 +32,18 @@ def test_gemm2_main_loop_keeps_dma_in_flight():
     body = s[m.end():]
     body = body[:body.index(".Lfunc_end")]
     lines = body.splitlines()
-    # one steady-state K-step per wave role (2-bit dequant waves, 4-bit dequant waves): the code
-    # between the previous s_barrier and the counted wait
+    # every counted wait closes a pipelined K-step (one per wave role): between the previous
+    # s_barrier and the counted wait there must be no draining vmcnt(0), and all 16 fragment reads
     idx = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(5) lgkmcnt(0)" in l]
-    assert len(idx) == 2, "expected one counted steady-state wait per wave role"
+    assert len(idx) >= 2, "expected a counted steady-state wait per wave role"
     for end in idx:
         start = max(i for i, l in enumerate(lines[:end]) if "s_barrier" in l)
         step = lines[start:end + 1]
         drains = [l for l in step if re.search(r"s_waitcnt.*vmcnt\(0\)", l)]
         assert not drains, f"compiler-inserted drain inside the K loop: {drains}"
-        # hipcc may sink register-only MFMAs below the wait/barrier (legal, they touch no memory):
-        # count them up to the loop's backward branch
-        tail_end = end + next(i for i, l in enumerate(lines[end:]) if "s_cbranch_scc" in l)
-        assert sum("v_mfma_f32_16x16x32_f16" in l for l in lines[start:tail_end]) == 32
         assert sum("ds_read_b128" in l for l in step) == 16
+        assert sum("v_mfma_f32_16x16x32_f16" in l for l in step) in (16, 32)   # 16: the peeled first step
+        assert sum("global_load_lds_dwordx4" in l for l in step) == 5
 
 
 @pytest.mark.parametrize("src", ["gemm.hip", "gemm2.hip", "gemv.hip", "fakequant.hip", "pack.hip"])
