@@ -14,6 +14,7 @@
 // The second read of the row hits L2 (a row is 8-44 KB).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <string.h>
 
 #include "mxq_kernels.h"
 
@@ -22,6 +23,8 @@ namespace {
 struct F32 {
     static constexpr int VEC = 4;
     __device__ static __forceinline__ float rnd(float x) { return x; }
+    __device__ static __forceinline__ bool near_boundary(float) { return true; }
+    static constexpr bool HAS_FAST_DIV = false;   // fp32 results are not re-rounded: always the IEEE divide
     __device__ static __forceinline__ void load(const void* p, int64_t e, float v[4]) {
         const float4 a = *(const float4*)((const float*)p + e);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
@@ -33,13 +36,16 @@ struct F32 {
 
 struct BF16 {
     static constexpr int VEC = 8;
-    // round-to-nearest-even to 8 significant bits, NaN preserved
-    __device__ static __forceinline__ float rnd(float x) {
-        uint32_t u = __float_as_uint(x);
-        if ((u & 0x7FFFFFFFu) > 0x7F800000u) return x;
-        u += 0x7FFFu + ((u >> 16) & 1u);
-        return __uint_as_float(u & 0xFFFF0000u);
+    // round-to-nearest-even to 8 significant bits: the plain cast compiles to
+    // v_cvt_pk_bf16_f32 on gfx950 and keeps NaNs (MI355X_MICROARCH.md, correctness boundaries)
+    __device__ static __forceinline__ float rnd(float x) { return (float)(__bf16)x; }
+    // fast-division screen: fl32(x * rcp(e)) rounds to the same bf16 as the correctly rounded
+    // fl32(x / e) unless it lies within a few fp32 ulps of a bf16 rounding boundary
+    __device__ static __forceinline__ bool near_boundary(float a) {
+        const uint32_t u = __float_as_uint(a);
+        return ((u & 0xFFFFu) - 0x7FFCu) < 8u || !(a == 0.0f || (a > 1e-30f && a < 1e30f));
     }
+    static constexpr bool HAS_FAST_DIV = true;
     __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) {
         const uint4 a = *(const uint4*)((const uint16_t*)p + e);
         const uint32_t w[4] = {a.x, a.y, a.z, a.w};
@@ -61,6 +67,11 @@ struct BF16 {
 struct F16 {
     static constexpr int VEC = 8;
     __device__ static __forceinline__ float rnd(float x) { return (float)(_Float16)x; }
+    __device__ static __forceinline__ bool near_boundary(float a) {   // 11 significant bits; no shortcut in the
+        const uint32_t u = __float_as_uint(a);                          // fp16-subnormal range
+        return ((u & 0x1FFFu) - 0x0FFCu) < 8u || !(a == 0.0f || (a > 6.2e-5f && a < 6.0e4f));
+    }
+    static constexpr bool HAS_FAST_DIV = true;
     __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) {
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
         const h8 a = *(const h8*)((const uint16_t*)p + e);
@@ -76,7 +87,9 @@ struct F16 {
     }
 };
 
-template <typename T>
+// FASTQ: q / L may be computed as q * (1/L) -- the launcher has checked on the host that this
+// rounds to the same T value for every integer 0 <= q <= L of both arms.
+template <typename T, bool FASTQ>
 __global__ __launch_bounds__(256) void mxq_fakequant_fwd_kernel(const void* __restrict__ w, void* __restrict__ out,
                                                                 int rows, int cols, float L2) {
     constexpr int VEC = T::VEC;
@@ -117,13 +130,33 @@ __global__ __launch_bounds__(256) void mxq_fakequant_fwd_kernel(const void* __re
         const float alpha = is4 ? alpha4 : T::rnd(mx - mn);
         const float beta = is4 ? mn4 : mn;
         const float L = is4 ? 15.0f : L2;
+        const float invL = 1.0f / L;
         const float e = T::rnd(alpha + 1e-8f);
-        float o[VEC];
+        float xs[VEC], xn[VEC], o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) xs[j] = T::rnd(v[j] - beta);
+        // (w - beta) / e must be the correctly rounded fp32 quotient re-rounded to T.  Fast path:
+        // multiply by v_rcp_f32(e) and screen; any lane near a rounding boundary (or out of the
+        // normal range) sends the wave through the IEEE divide (~5 % of the iterations).
+        bool slow = !T::HAS_FAST_DIV;
+        if constexpr (T::HAS_FAST_DIV) {
+            const float r = __builtin_amdgcn_rcpf(e);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                xn[j] = xs[j] * r;
+                slow |= T::near_boundary(xn[j]);
+            }
+            slow = __any(slow);
+        }
+        if (slow) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) xn[j] = xs[j] / e;
+        }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float xn = T::rnd(T::rnd(v[j] - beta) / e);
-            const float q = rintf(T::rnd(xn * L));
-            o[j] = T::rnd(T::rnd(T::rnd(q / L) * e) + beta);
+            const float q = rintf(T::rnd(T::rnd(xn[j]) * L));
+            const float ql = FASTQ ? q * invL : q / L;
+            o[j] = T::rnd(T::rnd(T::rnd(ql) * e) + beta);
         }
         T::store(out, base + e0, o);
     }
@@ -145,10 +178,35 @@ __global__ __launch_bounds__(256) void mxq_fakequant_bwd_kernel(const void* __re
     }
 }
 
+// host copies of the roundings, used only to validate the q * (1/L) shortcut
+inline float host_rnd(float x, int dtype) {
+    if (dtype == MXQ_DTYPE_F16) return (float)(_Float16)x;
+    if (dtype == MXQ_DTYPE_BF16) {
+        uint32_t u;
+        memcpy(&u, &x, 4);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        u &= 0xFFFF0000u;
+        memcpy(&x, &u, 4);
+    }
+    return x;
+}
+inline bool mul_matches_div(float L, int dtype) {
+    if (dtype == MXQ_DTYPE_F32 || L > 4096.0f) return false;
+    volatile float inv = 1.0f / L;
+    for (float q = 0.0f; q <= L; q += 1.0f) {
+        volatile float a = q / L, b = q * inv;
+        if (host_rnd(a, dtype) != host_rnd(b, dtype)) return false;
+    }
+    return true;
+}
+
 template <typename T>
-int launch_fwd(const void* w, void* out, int rows, int cols, int num_bits, hipStream_t stream) {
-    const float L2 = (float)(exp2((double)num_bits) - 1.0);
-    mxq_fakequant_fwd_kernel<T><<<(rows + 3) / 4, 256, 0, stream>>>(w, out, rows, cols, L2);
+int launch_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype, hipStream_t stream) {
+    // the reference stores s = 2**num_bits - 1 in a tensor of the weight dtype (utils_quant.py:342,366)
+    const float L2 = host_rnd((float)(exp2((double)num_bits) - 1.0), dtype);
+    const bool fastq = mul_matches_div(L2, dtype) && mul_matches_div(15.0f, dtype);
+    if (fastq) mxq_fakequant_fwd_kernel<T, true><<<(rows + 3) / 4, 256, 0, stream>>>(w, out, rows, cols, L2);
+    else mxq_fakequant_fwd_kernel<T, false><<<(rows + 3) / 4, 256, 0, stream>>>(w, out, rows, cols, L2);
     return (int)hipGetLastError();
 }
 
@@ -167,9 +225,9 @@ int launch_bwd(const void* gout, const void* w, void* gin, int64_t n, float lo, 
 int mxq_launch_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype,
                              hipStream_t stream) {
     switch (dtype) {
-        case MXQ_DTYPE_F32: return launch_fwd<F32>(w, out, rows, cols, num_bits, stream);
-        case MXQ_DTYPE_F16: return launch_fwd<F16>(w, out, rows, cols, num_bits, stream);
-        case MXQ_DTYPE_BF16: return launch_fwd<BF16>(w, out, rows, cols, num_bits, stream);
+        case MXQ_DTYPE_F32: return launch_fwd<F32>(w, out, rows, cols, num_bits, dtype, stream);
+        case MXQ_DTYPE_F16: return launch_fwd<F16>(w, out, rows, cols, num_bits, dtype, stream);
+        case MXQ_DTYPE_BF16: return launch_fwd<BF16>(w, out, rows, cols, num_bits, dtype, stream);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -7,11 +7,11 @@
 //   * HBM-bound: every packed byte is read exactly once; a wave consumes 4 consecutive
 //     16x64 blocks (2304 contiguous bytes) per iteration, straight to VGPRs
 //     (no LDS round trip for weights; cdna guide section 5, "GEMV / M <= 16" row).
-//   * one workgroup per 16-row block (N/16 >= 256 workgroups for Llama shapes), 8 waves
+//   * one workgroup per 16-row block (N/16 >= 256 workgroups for Llama shapes), 16 waves
 //     split K; lane -> (row r = lane & 15, chunk slot cs = lane >> 4).
 //   * activations are staged once per workgroup in LDS as fp16 and read as broadcast
 //     ds_read_b128; products use v_dot2_f32_f16 on the LUT-selected fp16 pairs.
-//   * wave64 reduction: 2 xor-shuffles over the 4 chunk slots, then 8 waves through LDS.
+//   * wave64 reduction: 2 xor-shuffles over the 4 chunk slots, then 16 waves through LDS.
 #include <hip/hip_runtime.h>
 
 #include "mxq_dequant.h"
@@ -22,7 +22,7 @@ namespace {
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
-constexpr int GEMV_THREADS = 512;
+constexpr int GEMV_THREADS = 1024;   // 16 waves: one 16x256 tile each at K = 4096, all loads in flight at once
 constexpr int GEMV_WAVES = GEMV_THREADS / 64;
 
 __device__ __forceinline__ float dot8(const uint32_t* w, const uint4 xa, float acc) {
@@ -44,6 +44,37 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     const int rb = blockIdx.x;
     const int NC = K / 64, NC4 = (NC + 3) / 4;
 
+    // packed operands of one (row, chunk): 13 registers, loaded straight from HBM
+    struct Tile {
+        uint32_t c2w[3], z2w[3], c4w[2], scw;
+        uint2 qq[3];
+    };
+    const uint32_t* tiles = qweight + (int64_t)rb * NC * MXQ_BLK_DW;
+    auto load_tile = [&](int c4) {
+        Tile t = {};
+        const int chunk = c4 * 4 + cs;
+        if (chunk < NC) {   // ragged tail: K/64 not a multiple of 4
+            // the wave reads 4 consecutive blocks = 2304 contiguous bytes; each load touches
+            // four 64-B segments (one per chunk slot)
+            const uint32_t* tile = tiles + (int64_t)chunk * MXQ_BLK_DW;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                t.c2w[g] = tile[mxq_c2(g, r)];
+                t.z2w[g] = tile[mxq_z2(g, r)];
+                t.qq[g] = *(const uint2*)(tile + mxq_qq(g));
+            }
+            t.c4w[0] = tile[mxq_c4(0, r)];
+            t.c4w[1] = tile[mxq_c4(1, r)];
+            t.scw = ((const uint16_t*)tile)[mxq_sc_u16(r)];
+        }
+        return t;
+    };
+
+    // the weight stream is started BEFORE the activations are staged, so the HBM latency of
+    // the first tile overlaps the x copy and the barrier
+    Tile cur = load_tile(wave);
+    const float4 rm = rowmeta[rb * 16 + r];
+
     // stage x[0..MB) in LDS (rows beyond M are zero)
     {
         const int vec_per_row = K / 8;
@@ -54,7 +85,6 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
             *(uint4*)(smem + (size_t)i * 16) = val;
         }
     }
-    const float4 rm = rowmeta[rb * 16 + r];
     const float s4 = mxq_scale(rm.z, rm.w, (uint32_t)rm.y), z4 = rm.x;
     __syncthreads();
 
@@ -62,47 +92,38 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = 0.f;
 
-    const uint32_t* tiles = qweight + (int64_t)rb * NC * MXQ_BLK_DW;
     for (int c4 = wave; c4 < NC4; c4 += GEMV_WAVES) {
+        Tile nxt = {};
+        if (c4 + GEMV_WAVES < NC4) nxt = load_tile(c4 + GEMV_WAVES);   // next tile in flight during the math
         const int chunk = c4 * 4 + cs;
-        if (chunk >= NC) continue;   // ragged tail: K/64 not a multiple of 4
-        const uint32_t* tile = tiles + (int64_t)chunk * MXQ_BLK_DW;
-        // the wave reads 4 consecutive blocks = 2304 contiguous bytes; each load touches four
-        // 64-B segments (one per chunk slot)
-        uint32_t c2w[3], z2w[3], c4w[2];
-        uint2 qq[3];
+        if (chunk < NC) {
+            const char* xk = smem + (size_t)chunk * 128;
+            uint32_t o[8];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            c2w[g] = tile[mxq_c2(g, r)];
-            z2w[g] = tile[mxq_z2(g, r)];
-            qq[g] = *(const uint2*)(tile + mxq_qq(g));
-        }
-        c4w[0] = tile[mxq_c4(0, r)];
-        c4w[1] = tile[mxq_c4(1, r)];
-        const uint32_t scw = ((const uint16_t*)tile)[mxq_sc_u16(r)];
-        const char* xk = smem + (size_t)chunk * 128;
-        uint32_t o[8];
+            for (int g = 0; g < 3; ++g) {
+                mxq_deq2x16(cur.c2w[g],
+                            mxq_scale(__uint_as_float(cur.qq[g].x), __uint_as_float(cur.qq[g].y),
+                                      (cur.scw >> (4 * g)) & 15u),
+                            __uint_as_float(cur.z2w[g]), o);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            mxq_deq2x16(c2w[g], mxq_scale(__uint_as_float(qq[g].x), __uint_as_float(qq[g].y), (scw >> (4 * g)) & 15u),
-                        __uint_as_float(z2w[g]), o);
+                for (int m = 0; m < MB; ++m) {
+                    const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + g * 32);
+                    const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + g * 32 + 16);
+                    acc[m] = dot8(o, xa, acc[m]);
+                    acc[m] = dot8(o + 4, xb, acc[m]);
+                }
+            }
+            mxq_deq4x8(cur.c4w[0], s4, z4, o);
+            mxq_deq4x8(cur.c4w[1], s4, z4, o + 4);
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
-                const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + g * 32);
-                const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + g * 32 + 16);
+                const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + 96);
+                const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + 112);
                 acc[m] = dot8(o, xa, acc[m]);
                 acc[m] = dot8(o + 4, xb, acc[m]);
             }
         }
-        mxq_deq4x8(c4w[0], s4, z4, o);
-        mxq_deq4x8(c4w[1], s4, z4, o + 4);
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + 96);
-            const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + 112);
-            acc[m] = dot8(o, xa, acc[m]);
-            acc[m] = dot8(o + 4, xb, acc[m]);
-        }
+        cur = nxt;
     }
 
     // reduce over the 4 chunk slots of the wave, then over waves
