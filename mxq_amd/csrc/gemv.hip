@@ -22,8 +22,6 @@ namespace {
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
-constexpr int GEMV_THREADS = 1024;   // 16 waves: one 16x256 tile each at K = 4096, all loads in flight at once
-constexpr int GEMV_WAVES = GEMV_THREADS / 64;
 
 __device__ __forceinline__ float dot8(const uint32_t* w, const uint4 xa, float acc) {
     acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[0]), __builtin_bit_cast(half2v, xa.x), acc, false);
@@ -33,11 +31,14 @@ __device__ __forceinline__ float dot8(const uint32_t* w, const uint4 xa, float a
     return acc;
 }
 
-template <int MB>
+// GEMV_THREADS: 1024 (16 waves: one 16x256 tile per wave at K = 4096, every load in flight at
+// once) when there are few row blocks, 512 when N/16 alone oversubscribes the chip.
+template <int MB, int GEMV_THREADS>
 __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16_t* __restrict__ x,
                                                                      const uint32_t* __restrict__ qweight,
                                                                      const float4* __restrict__ rowmeta,
                                                                      uint16_t* __restrict__ y, int M, int N, int K) {
+    constexpr int GEMV_WAVES = GEMV_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // MB*K halfs, then reduction scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, cs = lane >> 4;
@@ -148,17 +149,24 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     }
 }
 
-template <int MB>
-int launch(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream) {
-    const size_t smem = (size_t)MB * K * 2 + (size_t)GEMV_WAVES * MB * 16 * 4;
+template <int MB, int THREADS>
+int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+             hipStream_t stream) {
+    const size_t smem = (size_t)MB * K * 2 + (size_t)(THREADS / 64) * MB * 16 * 4;
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB>,
+        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB, THREADS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    mxq_gemv_f16_kernel<MB><<<N / 16, GEMV_THREADS, smem, stream>>>((const uint16_t*)x, (const uint32_t*)qweight,
-                                                                    (const float4*)rowmeta, (uint16_t*)y, M, N, K);
+    mxq_gemv_f16_kernel<MB, THREADS><<<N / 16, THREADS, smem, stream>>>(
+        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K);
     return (int)hipGetLastError();
+}
+
+template <int MB>
+int launch(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream) {
+    if (N / 16 <= 384) return launch_t<MB, 1024>(x, qweight, rowmeta, y, M, N, K, stream);
+    return launch_t<MB, 512>(x, qweight, rowmeta, y, M, N, K, stream);
 }
 
 }   // namespace

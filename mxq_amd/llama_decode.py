@@ -1,0 +1,131 @@
+"""Llama-2-7B-shaped greedy-decode stage on packed MXQ weights (BASELINE config 3).
+
+Only the quantised Linears are this repo's kernels (``packing.linear`` -> mxq_gemv_f16 for one
+token); attention over the KV cache, RMSNorm and RoPE are plain PyTorch-ROCm ops -- plumbing
+around the hot path, not part of it.  q/k/v and gate/up share their input,
+so their packed weights are concatenated along the output dimension (format v1 blocks are
+independent per 16 rows): 4 GEMV launches per layer instead of 7.
+
+Weights are synthetic (no checkpoint offline): ``randn * 0.02`` seeded per (layer, linear) as in
+bench.py.  Everything in ``step`` is stream-ordered with device-resident position / token
+tensors, so a whole stage step can be captured in a hipGraph (``capture()``).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import llama_shapes as LS
+from . import packing
+
+
+def _concat_packed(ps: List[packing.PackedMXQ]) -> packing.PackedMXQ:
+    K = ps[0].K
+    return packing.PackedMXQ(torch.cat([p.qweight for p in ps]), torch.cat([p.rowmeta for p in ps]),
+                             sum(p.N for p in ps), K)
+
+
+class DecodeStage:
+    def __init__(self, layers, dev, max_ctx: int = 512, hidden: int = LS.HIDDEN, inter: int = LS.INTERMEDIATE,
+                 heads: int = 32, first: bool = True, last: bool = True, vocab: int = 32000):
+        self.layers, self.dev, self.max_ctx = list(layers), dev, max_ctx
+        self.hidden, self.inter, self.heads, self.hd = hidden, inter, heads, hidden // heads
+        self.first, self.last = first, last
+        self.w = []
+        for li in self.layers:
+            def mk(idx, N, K):
+                g = torch.Generator(device=dev).manual_seed(1000 * li + idx)
+                W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
+                return packing.quantize_pack(W)
+            qkv = _concat_packed([mk(0, hidden, hidden), mk(1, hidden, hidden), mk(2, hidden, hidden)])
+            o = mk(3, hidden, hidden)
+            gu = _concat_packed([mk(4, inter, hidden), mk(5, inter, hidden)])
+            down = mk(6, hidden, inter)
+            self.w.append((qkv, o, gu, down))
+        n = len(self.layers)
+        self.k_cache = torch.zeros(n, heads, max_ctx, self.hd, device=dev, dtype=torch.float16)
+        self.v_cache = torch.zeros_like(self.k_cache)
+        self.norm_w = torch.ones(hidden, device=dev, dtype=torch.float16)
+        inv = 1.0 / (10000 ** (torch.arange(0, self.hd, 2, device=dev).float() / self.hd))
+        ang = torch.arange(max_ctx, device=dev).float()[:, None] * inv[None, :]
+        self.cos, self.sin = ang.cos(), ang.sin()                     # [max_ctx, hd/2]
+        self.pos = torch.zeros(1, dtype=torch.int64, device=dev)      # device-resident position
+        self.ctx_ids = torch.arange(max_ctx, device=dev)
+        g = torch.Generator(device=dev).manual_seed(99)
+        if first:
+            self.embed = (torch.randn(vocab, hidden, generator=g, device=dev) * 0.02).half()
+        if last:
+            self.lm_head = (torch.randn(vocab, hidden, generator=g, device=dev) * 0.02).half()   # plain fp16 Linear
+        self._graph = None
+        self._h_in = torch.zeros(1, hidden, device=dev, dtype=torch.float16)
+        self._h_out = torch.zeros(1, hidden, device=dev, dtype=torch.float16)
+
+    def packed_bytes(self) -> int:
+        return sum(p.nbytes() for ws in self.w for p in ws)
+
+    def _rms(self, x):
+        xf = x.float()
+        return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).half() * self.norm_w
+
+    def _rope(self, t):                      # t [heads, hd], rotate-half convention
+        c = self.cos.index_select(0, self.pos)[0]
+        s = self.sin.index_select(0, self.pos)[0]
+        t1, t2 = t[:, : self.hd // 2].float(), t[:, self.hd // 2:].float()
+        return torch.cat([t1 * c - t2 * s, t2 * c + t1 * s], dim=-1).half()
+
+    def embed_token(self, tok):
+        return self.embed.index_select(0, tok)
+
+    def head(self, h):
+        logits = torch.nn.functional.linear(self._rms(h), self.lm_head)
+        return logits.argmax(dim=-1)
+
+    def step(self, h):
+        """One token through this stage's layers.  h [1, hidden] fp16."""
+        scale = 1.0 / math.sqrt(self.hd)
+        mask = (self.ctx_ids <= self.pos)[None, None, :]              # [1, 1, max_ctx]
+        for i, (qkv, o, gu, down) in enumerate(self.w):
+            x = self._rms(h)
+            y = packing.linear(x, qkv)                                # GEMV kernel (1 token)
+            q, k, v = (y[0, j * self.hidden:(j + 1) * self.hidden].view(self.heads, self.hd) for j in range(3))
+            q, k = self._rope(q), self._rope(k)
+            self.k_cache[i].index_copy_(1, self.pos, k[:, None, :])
+            self.v_cache[i].index_copy_(1, self.pos, v[:, None, :])
+            att = torch.baddbmm(torch.zeros(1, device=self.dev, dtype=torch.float16), q[:, None, :],
+                                self.k_cache[i].transpose(1, 2), alpha=scale)          # [heads, 1, ctx]
+            att = att.float().masked_fill(~mask, float("-inf")).softmax(-1).half()
+            a = torch.bmm(att, self.v_cache[i]).reshape(1, self.hidden)
+            h = h + packing.linear(a, o)
+            x = self._rms(h)
+            gu_y = packing.linear(x, gu)
+            act = torch.nn.functional.silu(gu_y[:, : self.inter].float()).half() * gu_y[:, self.inter:]
+            h = h + packing.linear(act, down)
+        return h
+
+    def advance(self):
+        self.pos += 1
+
+    # -- hipGraph capture of one stage step --------------------------------------------------------
+    def capture(self):
+        for _ in range(2):                                            # warm-up outside capture
+            self._h_out.copy_(self.step(self._h_in))
+        self.pos.zero_()
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._h_out.copy_(self.step(self._h_in))
+            self.pos += 1
+        self.pos.zero_()
+        return self
+
+    def step_graph(self, h):
+        self._h_in.copy_(h)
+        self._graph.replay()
+        return self._h_out
+
+    def reset(self):
+        self.pos.zero_()
+        self.k_cache.zero_()
+        self.v_cache.zero_()

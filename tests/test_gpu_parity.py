@@ -352,3 +352,47 @@ def test_g4_quantizelinear_fwd_bwd(dev, g4, dt):
         ref = conv(g4[f"{dt}_{name}"])
         err = np.abs(got.detach().float().cpu().numpy() - ref).max() / np.abs(ref).max()
         assert err <= tol, (name, err)
+
+
+# ----------------------------------------------------------------------------------------
+# decode stage (config 3 harness): fused q/k/v and gate/up GEMVs vs a dense fp32 restatement
+# ----------------------------------------------------------------------------------------
+def test_decode_stage_matches_dense_reference(dev):
+    from mxq_amd import packing
+    from mxq_amd.llama_decode import DecodeStage
+    hidden, inter, heads, ctx = 256, 704, 4, 32
+    st = DecodeStage(range(2), dev, max_ctx=ctx, hidden=hidden, inter=inter, heads=heads, vocab=64)
+    Wd = [[packing.dequant(p).float() for p in ws] for ws in st.w]
+    hd = hidden // heads
+    kc = torch.zeros(2, heads, ctx, hd, device=dev)
+    vc = torch.zeros_like(kc)
+
+    def rms(x):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5)
+
+    def rope(t, pos):
+        c, s = st.cos[pos], st.sin[pos]
+        t1, t2 = t[:, : hd // 2], t[:, hd // 2:]
+        return torch.cat([t1 * c - t2 * s, t2 * c + t1 * s], -1)
+
+    def ref_step(h, pos):
+        for i, (qkv, o, gu, down) in enumerate(Wd):
+            y = rms(h) @ qkv.t()
+            q, k, v = (y[0, j * hidden:(j + 1) * hidden].view(heads, hd) for j in range(3))
+            q, k = rope(q, pos), rope(k, pos)
+            kc[i][:, pos], vc[i][:, pos] = k, v
+            att = (q[:, None, :] @ kc[i][:, : pos + 1].transpose(1, 2) / hd ** 0.5).softmax(-1)
+            h = h + (att @ vc[i][:, : pos + 1]).reshape(1, hidden) @ o.t()
+            g = rms(h) @ gu.t()
+            h = h + (torch.nn.functional.silu(g[:, :inter]) * g[:, inter:]) @ down.t()
+        return h
+
+    g = torch.Generator(device=dev).manual_seed(4)
+    st.capture()
+    st.reset()
+    for pos in range(5):
+        h0 = torch.randn(1, hidden, generator=g, device=dev).half()
+        got = st.step_graph(h0).float().clone()
+        want = ref_step(h0.float(), pos)
+        assert ((got - want).abs().max() / want.abs().max()).item() < 2e-2, pos     # fp16 activations end to end
+    assert int(st.pos.item()) == 5

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""BASELINE config 3: Llama-2-7B W2/4A16 greedy decode, batch 1, layers pipeline-sharded.
+
+    python tools/decode_bench.py [--tokens 64] [--ctx 512] [--layers 32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 tools/decode_bench.py
+
+Prints one JSON line on rank 0: tokens/s, ms/token, packed weight bytes streamed per token and
+the implied HBM GB/s.  A batch-1 pipeline is sequential, so G GPUs are expected to be ~flat."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mxq_amd import llama_shapes as LS  # noqa: E402
+from mxq_amd.llama_decode import DecodeStage  # noqa: E402
+from mxq_amd.pipeline import LayerPipeline, layer_range  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tokens", type=int, default=64)
+    ap.add_argument("--ctx", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=LS.N_LAYERS)
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    pipe = LayerPipeline(rank, world)
+    stage = DecodeStage(layer_range(rank, world, args.layers), dev, max_ctx=args.ctx, first=pipe.is_first,
+                        last=pipe.is_last)
+    if not args.no_graph:
+        stage.capture()
+    hbuf = torch.zeros(1, LS.HIDDEN, device=dev, dtype=torch.float16)
+    tbuf = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def stage_fn(h, step):
+        if args.no_graph:
+            out = stage.step(h)
+            stage.advance()
+            return out
+        return stage.step_graph(h)
+
+    def run(n):
+        stage.reset()
+        return pipe.decode(1, n, stage.embed_token if pipe.is_first else None, stage_fn,
+                           stage.head if pipe.is_last else None, hbuf, tbuf)
+
+    run(8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    toks = run(args.tokens)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    bytes_tok = torch.tensor([stage.packed_bytes()], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(bytes_tok)
+    if rank == 0:
+        print(json.dumps({"config": "Llama-2-7B W2/4A16 greedy decode, batch 1", "n_gpus": world,
+                          "layers": args.layers, "tokens": args.tokens, "ctx": args.ctx,
+                          "tokens_per_s": round(args.tokens / dt, 1), "ms_per_token": round(dt / args.tokens * 1e3, 3),
+                          "packed_weight_GB_per_token": round(bytes_tok.item() / 1e9, 3),
+                          "weight_stream_GBps": round(bytes_tok.item() / (dt / args.tokens) / 1e9, 1),
+                          "hipgraph": not args.no_graph, "first_tokens": toks[:8]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
