@@ -84,6 +84,7 @@ int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, voi
         case 1: return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
         case 2: return mxq_launch_gemm2_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
         case 3: return mxq_launch_gemm3_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+        case 4: return mxq_launch_gemm4_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
     }
     if (variant >= 16 && variant < 32)   // profiling-only ablation builds of variant 2 (wrong results)
         return mxq_launch_gemm2_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 16, (hipStream_t)stream);
