@@ -88,6 +88,8 @@ int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, voi
     }
     if (variant >= 16 && variant < 32)   // profiling-only ablation builds of variant 2 (wrong results)
         return mxq_launch_gemm2_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 16, (hipStream_t)stream);
+    if (variant >= 32 && variant < 48)   // profiling-only ablation builds of variant 4 (wrong results)
+        return mxq_launch_gemm4_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 32, (hipStream_t)stream);
     return MXQ_E_SHAPE;
 }
 

@@ -90,15 +90,18 @@ __device__ __forceinline__ void load_frags(const char* smem, int t, int kk, int 
     for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz(wm * 64 + j * 16 + fr, kk * 4 + fq));
 }
 
-template <int I0, int I1>
+template <int I0, int I1, int ABL = 0>
 __device__ __forceinline__ void mfma_rows(f32x4 (&acc)[4][4], const Frag4& wf, const Frag4& xf) {
 #pragma unroll
     for (int i = I0; i < I1; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (ABL & 2) asm volatile("" ::"v"(wf[i]), "v"(xf[j]));
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
 }
 
+template <int ABL>
 __device__ __forceinline__ void consumer(char* smem, int wave, int lane, int NT, uint16_t* __restrict__ y, int M, int N,
                                          int m0, int n0) {
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
@@ -115,26 +118,26 @@ __device__ __forceinline__ void consumer(char* smem, int wave, int lane, int NT,
     // step 0: no previous half
     load_frags(smem, 0, 0, wm, wn, fr, fq, wf0, xf0);
     load_frags(smem, 0, 1, wm, wn, fr, fq, wf1, xf1);
-    mfma_rows<0, 4>(acc, wf0, xf0);
+    mfma_rows<0, 4, ABL>(acc, wf0, xf0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     for (int t = 1; t < NT; ++t) {
         // (wf1, xf1) = fragments of (t-1, kk=1), waited for at the end of the previous step
-        mfma_rows<0, 1>(acc, wf1, xf1);
+        mfma_rows<0, 1, ABL>(acc, wf1, xf1);
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
+        if constexpr (!(ABL & 8)) load_frags(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_rows<1, 4>(acc, wf1, xf1);
+        mfma_rows<1, 4, ABL>(acc, wf1, xf1);
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
+        if constexpr (!(ABL & 8)) load_frags(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_rows<0, 4>(acc, wf0, xf0);
+        mfma_rows<0, 4, ABL>(acc, wf0, xf0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    mfma_rows<0, 4>(acc, wf1, xf1);   // (NT-1, kk=1)
+    mfma_rows<0, 4, ABL>(acc, wf1, xf1);   // (NT-1, kk=1)
 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -203,6 +206,7 @@ __device__ __forceinline__ void dequant(const Prod& c, int t) {
         *(u32x4*)(wt + swz(c.d_row, c.d_qp * 4 + s)) = (u32x4){o[4 * s], o[4 * s + 1], o[4 * s + 2], o[4 * s + 3]};
 }
 
+template <int ABL>
 __device__ __forceinline__ void producer(const Prod& c) {
     // prologue: x tiles 0,1; packed blocks 0..2; W16(0)
     for (int t = 0; t < 2 && t < c.NT; ++t) issue_a(c, t);
@@ -215,10 +219,11 @@ __device__ __forceinline__ void producer(const Prod& c) {
 
     int t = 0;
     for (; t + 3 < c.NT; ++t) {   // steady state: everything unconditional
-        issue_a(c, t + 2);
+        if constexpr (!(ABL & 1)) issue_a(c, t + 2);
         issue_bp(c, t + 3);
-        dequant(c, t + 1);
-        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // this step's 10 DMAs stay in flight
+        if constexpr (!(ABL & 4)) dequant(c, t + 1);
+        if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // this step's 10 DMAs stay in flight
         __builtin_amdgcn_s_barrier();
     }
     for (; t < c.NT; ++t) {
@@ -230,6 +235,7 @@ __device__ __forceinline__ void producer(const Prod& c) {
     }
 }
 
+template <int ABL>
 __global__ __launch_bounds__(THREADS) void mxq_gemm4_f16_kernel(const uint16_t* __restrict__ x,
                                                                const uint32_t* __restrict__ qweight,
                                                                const float4* __restrict__ rowmeta,
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm4_f16_kernel(const uint16_t* 
     const int m0 = tm * BM, n0 = tn * BN;
 
     if (wave < N_CONS) {
-        consumer(smem, wave, lane, NT, y, M, N, m0, n0);
+        consumer<ABL>(smem, wave, lane, NT, y, M, N, m0, n0);
         return;
     }
     Prod c;
@@ -279,18 +285,41 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm4_f16_kernel(const uint16_t* 
         c.s4 = mxq_scale(m.z, m.w, (uint32_t)m.y);
         c.z4 = m.x;
     }
-    producer(c);
+    producer<ABL>(c);
+}
+
+template <int ABL>
+static int launch4(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                   hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm4_f16_kernel<ABL>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    mxq_gemm4_f16_kernel<ABL><<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
+        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n);
+    return (int)hipGetLastError();
 }
 
 }   // namespace
 
 int mxq_launch_gemm4_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm4_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       SMEM_BYTES);
-    if (e != hipSuccess) return (int)e;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    mxq_gemm4_f16_kernel<<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
-        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n);
-    return (int)hipGetLastError();
+    return launch4<0>(x, qweight, rowmeta, y, M, N, K, stream);
+}
+
+// profiling-only ablation builds (wrong results): 1 no x DMA, 2 no MFMA, 4 no dequant, 8 no fragment reads
+int mxq_launch_gemm4_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                int abl, hipStream_t stream) {
+    switch (abl) {
+        case 1: return launch4<1>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 2: return launch4<2>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 4: return launch4<4>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 8: return launch4<8>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 10: return launch4<10>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 5: return launch4<5>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 13: return launch4<13>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 7: return launch4<7>(x, qweight, rowmeta, y, M, N, K, stream);
+        case 15: return launch4<15>(x, qweight, rowmeta, y, M, N, K, stream);
+    }
+    return (int)hipErrorInvalidValue;
 }
