@@ -167,6 +167,10 @@ def main():
     kern_ms = dev_ms / args.steps / launches_rank_step
     achieved = flops_rank_step / (dev_ms / args.steps * 1e-3) / 1e12
 
+    traffic = None       # HBM bytes per launch from rocprofv3 PMC counters (collected offline, see the file)
+    tpath = os.path.join(ROOT, "profiles", "r01_gemm4_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        traffic = json.load(open(tpath))["avg_hbm_bytes_per_launch"]
     if rank == 0:
         bpw = sum(p.nbytes() for lin in layers for _, p in lin) * 8.0 / (LS.PARAMS_PER_LAYER * len(my_layers))
         out = {
@@ -184,7 +188,7 @@ def main():
                        f"pp{world}: whole layers sharded, {world} sequences in flight, RCCL send/recv of the "
                        f"[2048,4096] fp16 hidden state"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                          "kernel": "mxq_gemm4_f16_kernel", "avg_launch_ms": round(kern_ms, 5),
                          "launches_per_step": launches_rank_step,
                          "algorithmic_flop_per_launch": flops_rank_step / launches_rank_step},
