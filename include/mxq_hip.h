@@ -99,6 +99,20 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
 int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* stream);
 
+/* Decode-time variant of mxq_gemv_f16 for ONE token with the neighbouring elementwise ops of a
+ * Llama decoder layer fused into the activation staging / the store (no reference counterpart:
+ * the reference's decode is HF transformers on fake-quant weights):
+ *   prologue 0: none; 1: x <- RMSNorm(x) * norm_w (fp16 norm_w[K], eps); 2: x[2K] = (gate, up),
+ *   x <- silu(gate) * up.  residual (nullable, fp16 [N]): y <- residual + W.x. */
+int mxq_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K, int prologue,
+                       const void* norm_w, float eps, const void* residual, void* stream);
+/* Decode-harness glue (BASELINE config 3), not part of the reference's hot path: rotary embedding
+ * of q/k, KV-cache append at *pos and single-query attention for one token; one workgroup per
+ * head, head_dim 128.  qkv fp16 [3*heads*128]; caches fp16 [heads][max_ctx][128]; pos int64[1]
+ * (device); cos/sin f32 [max_ctx][64]; out fp16 [heads*128]. */
+int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
+                        const void* sin_t, void* out, int heads, int head_dim, int max_ctx, void* stream);
+
 /* MXAsymQuantizer.forward (utils_quant.py:316-462; 2-D, layerwise=False branch):
  * fake-quantise w[rows, cols] of `dtype` into out (same shape/dtype), bit-identical to
  * the reference in fp32 / bf16 / fp16.  cols % 64 == 0. */

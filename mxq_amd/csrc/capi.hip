@@ -100,6 +100,23 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
     return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
 }
 
+int mxq_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K, int prologue,
+                       const void* norm_w, float eps, const void* residual, void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, 1, N, K)) return e;
+    if (prologue < 0 || prologue > 2) return MXQ_E_SHAPE;
+    if (prologue == 1 && !norm_w) return MXQ_E_NULL;
+    return mxq_launch_gemv_fused_f16(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual,
+                                     (hipStream_t)stream);
+}
+
+int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
+                        const void* sin_t, void* out, int heads, int head_dim, int max_ctx, void* stream) {
+    if (!qkv || !k_cache || !v_cache || !pos || !cos_t || !sin_t || !out) return MXQ_E_NULL;
+    if (heads <= 0 || head_dim != 128 || max_ctx <= 0 || max_ctx > 32768) return MXQ_E_SHAPE;
+    return mxq_launch_attn_decode_f16(qkv, k_cache, v_cache, pos, cos_t, sin_t, out, heads, head_dim, max_ctx,
+                                      (hipStream_t)stream);
+}
+
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;

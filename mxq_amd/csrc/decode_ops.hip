@@ -1,0 +1,127 @@
+// Decode-harness glue for BASELINE config 3 (not part of the reference's hot path; the
+// reference leaves attention / RoPE to HF transformers): one fused kernel per decoder layer
+// and token that applies rotary embedding to q/k, appends k/v to the cache and runs
+// single-query attention.  One workgroup per head; position is read from device memory so
+// the launch is hipGraph-replayable.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "mxq_kernels.h"
+
+namespace {
+
+constexpr int HD = 128;        // head dim (Llama-2-7B)
+constexpr int ATT_THREADS = 256;
+
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f2h(float f) {
+    const _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+// qkv: [3 * heads * HD] fp16 (q | k | v); caches: [heads][max_ctx][HD] fp16; cos/sin: [max_ctx][HD/2] f32;
+// out: [heads * HD] fp16.  Rotate-half convention, as mxq_amd/llama_decode.py.
+__global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t* __restrict__ qkv,
+                                                                  uint16_t* __restrict__ k_cache,
+                                                                  uint16_t* __restrict__ v_cache,
+                                                                  const int64_t* __restrict__ pos_p,
+                                                                  const float* __restrict__ cos_t,
+                                                                  const float* __restrict__ sin_t,
+                                                                  uint16_t* __restrict__ out, int heads, int max_ctx) {
+    extern __shared__ float sm[];          // q[HD], scores[max_ctx], red[8], o2[2*HD]
+    float* q_s = sm;
+    float* sc = sm + HD;
+    float* red = sc + max_ctx;
+    float* o2 = red + 8;
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = (int)*pos_p;
+    const int hidden = heads * HD;
+    uint16_t* kc = k_cache + (int64_t)h * max_ctx * HD;
+    uint16_t* vc = v_cache + (int64_t)h * max_ctx * HD;
+
+    // RoPE on q and k of this head; append k, v at `pos`
+    if (tid < HD) {
+        const int d = tid, d2 = d & (HD / 2 - 1);
+        const float c = cos_t[(int64_t)pos * (HD / 2) + d2], s = sin_t[(int64_t)pos * (HD / 2) + d2];
+        const uint16_t* qh = qkv + h * HD;
+        const uint16_t* kh = qkv + hidden + h * HD;
+        const float q1 = h2f(qh[d2]), q2 = h2f(qh[d2 + HD / 2]);
+        const float k1 = h2f(kh[d2]), k2 = h2f(kh[d2 + HD / 2]);
+        const float qr = d < HD / 2 ? q1 * c - q2 * s : q2 * c + q1 * s;
+        const float kr = d < HD / 2 ? k1 * c - k2 * s : k2 * c + k1 * s;
+        q_s[d] = h2f(f2h(qr));                       // the fp16 rounding the torch path applies
+        kc[(int64_t)pos * HD + d] = f2h(kr);
+        vc[(int64_t)pos * HD + d] = qkv[2 * hidden + h * HD + d];
+    }
+    __syncthreads();
+
+    // scores: 4 lanes per key (32 dims each)
+    const float scale = rsqrtf((float)HD);
+    const int part = tid & 3;
+    for (int j = tid >> 2; j <= pos; j += ATT_THREADS / 4) {
+        const uint4* kr = (const uint4*)(kc + (int64_t)j * HD + part * 32);
+        float acc = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const uint4 w = kr[v];
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc += q_s[part * 32 + v * 8 + 2 * e] * h2f((uint16_t)(ws[e] & 0xFFFF));
+                acc += q_s[part * 32 + v * 8 + 2 * e + 1] * h2f((uint16_t)(ws[e] >> 16));
+            }
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (part == 0) sc[j] = h2f(f2h(acc * scale));   // fp16 scores as baddbmm produces them
+    }
+    __syncthreads();
+
+    // softmax over [0, pos]
+    float mx = -INFINITY;
+    for (int j = tid; j <= pos; j += ATT_THREADS) mx = fmaxf(mx, sc[j]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j <= pos; j += ATT_THREADS) {
+        const float p = __expf(sc[j] - mx);
+        sc[j] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __syncthreads();          // everyone has read red[] (max) before it is reused
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+
+    // out[d] = sum_j p_j * V[j][d]; two halves of the key range per dim
+    const int d = tid & (HD - 1), half = tid >> 7;
+    float o = 0.f;
+    for (int j = half; j <= pos; j += 2) o += h2f(f2h(sc[j] * inv)) * h2f(vc[(int64_t)j * HD + d]);
+    o2[tid] = o;
+    __syncthreads();
+    if (tid < HD) out[h * HD + tid] = f2h(o2[tid] + o2[tid + HD]);
+}
+
+}   // namespace
+
+int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
+                               const void* sin_t, void* out, int heads, int head_dim, int max_ctx,
+                               hipStream_t stream) {
+    if (head_dim != HD) return (int)hipErrorInvalidValue;
+    const size_t smem = (size_t)(HD + max_ctx + 8 + 2 * HD) * 4;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    attn_decode_kernel<<<heads, ATT_THREADS, smem, stream>>>((const uint16_t*)qkv, (uint16_t*)k_cache,
+                                                             (uint16_t*)v_cache, (const int64_t*)pos,
+                                                             (const float*)cos_t, (const float*)sin_t, (uint16_t*)out,
+                                                             heads, max_ctx);
+    return (int)hipGetLastError();
+}

@@ -33,11 +33,18 @@ __device__ __forceinline__ float dot8(const uint32_t* w, const uint4 xa, float a
 
 // GEMV_THREADS: 1024 (16 waves: one 16x256 tile per wave at K = 4096, every load in flight at
 // once) when there are few row blocks, 512 when N/16 alone oversubscribes the chip.
-template <int MB, int GEMV_THREADS>
+// PRO: prologue fused into the activation staging (decode, M = 1 only):
+//   0 = none; 1 = RMSNorm: x <- fp16(x * rsqrt(mean(x^2) + eps)) * norm_w (every workgroup
+//   recomputes the 4096-element reduction -- cheaper than a separate launch);
+//   2 = SwiGLU gate: the input row is [2K] = (gate, up) and x <- fp16(silu(gate)) * up.
+// residual (nullable): y <- residual + W.x (the decoder layer's skip connection).
+template <int MB, int GEMV_THREADS, int PRO>
 __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16_t* __restrict__ x,
                                                                      const uint32_t* __restrict__ qweight,
                                                                      const float4* __restrict__ rowmeta,
-                                                                     uint16_t* __restrict__ y, int M, int N, int K) {
+                                                                     uint16_t* __restrict__ y, int M, int N, int K,
+                                                                     const uint16_t* __restrict__ norm_w, float eps,
+                                                                     const uint16_t* __restrict__ residual) {
     constexpr int GEMV_WAVES = GEMV_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // MB*K halfs, then reduction scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -77,13 +84,49 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     const float4 rm = rowmeta[rb * 16 + r];
 
     // stage x[0..MB) in LDS (rows beyond M are zero)
-    {
+    if constexpr (PRO == 0) {
         const int vec_per_row = K / 8;
         for (int i = tid; i < MB * vec_per_row; i += GEMV_THREADS) {
             const int m = i / vec_per_row, v = i % vec_per_row;
             uint4 val = make_uint4(0, 0, 0, 0);
             if (m < M) val = *(const uint4*)(x + (int64_t)m * K + v * 8);
             *(uint4*)(smem + (size_t)i * 16) = val;
+        }
+    } else {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        float* wsum = (float*)(smem + (size_t)K * 2);   // reduction scratch (reused by the final reduce)
+        float ss = 0.f;
+        for (int v = tid; v < K / 8; v += GEMV_THREADS) {
+            h8 a = *(const h8*)(x + v * 8);
+            if constexpr (PRO == 2) {
+                const h8 u = *(const h8*)(x + K + v * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g = (float)a[j];
+                    a[j] = (_Float16)(g / (1.0f + __expf(-g))) * u[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += (float)a[j] * (float)a[j];
+            }
+            *(h8*)(smem + (size_t)v * 16) = a;
+        }
+        if constexpr (PRO == 1) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            if (lane == 0) wsum[wave] = ss;
+            __syncthreads();
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < GEMV_WAVES; ++w) tot += wsum[w];
+            const float inv = rsqrtf(tot / (float)K + eps);
+            for (int v = tid; v < K / 8; v += GEMV_THREADS) {
+                h8 a = *(h8*)(smem + (size_t)v * 16);
+                const h8 g = *(const h8*)(norm_w + v * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = (_Float16)((float)a[j] * inv) * g[j];
+                *(h8*)(smem + (size_t)v * 16) = a;
+            }
         }
     }
     const float s4 = mxq_scale(rm.z, rm.w, (uint32_t)rm.y), z4 = rm.x;
@@ -143,30 +186,32 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
 #pragma unroll
         for (int w = 0; w < GEMV_WAVES; ++w) v += red[(w * MB + m) * 16 + rr];
         if (m < M) {
-            const _Float16 h = (_Float16)v;
+            _Float16 h = (_Float16)v;
+            if (residual) h = __builtin_bit_cast(_Float16, residual[(int64_t)m * N + rb * 16 + rr]) + h;
             y[(int64_t)m * N + rb * 16 + rr] = __builtin_bit_cast(uint16_t, h);
         }
     }
 }
 
-template <int MB, int THREADS>
+template <int MB, int THREADS, int PRO>
 int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-             hipStream_t stream) {
+             const void* norm_w, float eps, const void* residual, hipStream_t stream) {
     const size_t smem = (size_t)MB * K * 2 + (size_t)(THREADS / 64) * MB * 16 * 4;
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB, THREADS>,
+        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB, THREADS, PRO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    mxq_gemv_f16_kernel<MB, THREADS><<<N / 16, THREADS, smem, stream>>>(
-        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K);
+    mxq_gemv_f16_kernel<MB, THREADS, PRO><<<N / 16, THREADS, smem, stream>>>(
+        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K,
+        (const uint16_t*)norm_w, eps, (const uint16_t*)residual);
     return (int)hipGetLastError();
 }
 
 template <int MB>
 int launch(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream) {
-    if (N / 16 <= 384) return launch_t<MB, 1024>(x, qweight, rowmeta, y, M, N, K, stream);
-    return launch_t<MB, 512>(x, qweight, rowmeta, y, M, N, K, stream);
+    if (N / 16 <= 384) return launch_t<MB, 1024, 0>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
+    return launch_t<MB, 512, 0>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
 }
 
 }   // namespace
@@ -176,5 +221,23 @@ int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta,
     if (M == 1) return launch<1>(x, qweight, rowmeta, y, M, N, K, stream);
     if (M == 2) return launch<2>(x, qweight, rowmeta, y, M, N, K, stream);
     if (M <= 4) return launch<4>(x, qweight, rowmeta, y, M, N, K, stream);
+    return (int)hipErrorInvalidValue;
+}
+
+int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                              int prologue, const void* norm_w, float eps, const void* residual,
+                              hipStream_t stream) {
+    const bool big = N / 16 > 384;
+    switch (prologue) {
+        case 0:
+            return big ? launch_t<1, 512, 0>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
+                       : launch_t<1, 1024, 0>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
+        case 1:
+            return big ? launch_t<1, 512, 1>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
+                       : launch_t<1, 1024, 1>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
+        case 2:
+            return big ? launch_t<1, 512, 2>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
+                       : launch_t<1, 1024, 2>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
+    }
     return (int)hipErrorInvalidValue;
 }

@@ -35,6 +35,12 @@ int mxq_launch_gemm4_ablate_f16(const void* x, const void* qweight, const void* 
                                 int K, int abl, hipStream_t stream);   // profiling only
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream);
+int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                              int prologue, const void* norm_w, float eps, const void* residual,
+                              hipStream_t stream);
+int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
+                               const void* sin_t, void* out, int heads, int head_dim, int max_ctx,
+                               hipStream_t stream);
 int mxq_launch_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype,
                              hipStream_t stream);
 int mxq_launch_fakequant_bwd(const void* grad_out, const void* w, void* grad_in, int64_t n, float lo, float hi,

@@ -17,6 +17,7 @@ from typing import List, Optional
 
 import torch
 
+from . import _lib
 from . import llama_shapes as LS
 from . import packing
 
@@ -29,10 +30,13 @@ def _concat_packed(ps: List[packing.PackedMXQ]) -> packing.PackedMXQ:
 
 class DecodeStage:
     def __init__(self, layers, dev, max_ctx: int = 512, hidden: int = LS.HIDDEN, inter: int = LS.INTERMEDIATE,
-                 heads: int = 32, first: bool = True, last: bool = True, vocab: int = 32000):
+                 heads: int = 32, first: bool = True, last: bool = True, vocab: int = 32000, fused: bool = True):
         self.layers, self.dev, self.max_ctx = list(layers), dev, max_ctx
         self.hidden, self.inter, self.heads, self.hd = hidden, inter, heads, hidden // heads
         self.first, self.last = first, last
+        # fused: RMSNorm / SwiGLU / residual folded into the GEMV launches and one RoPE + cache-append
+        # + attention kernel per layer (5 launches per layer); otherwise plain torch ops around 4 GEMVs
+        self.fused = fused and self.hd == 128
         self.w = []
         for li in self.layers:
             def mk(idx, N, K):
@@ -82,8 +86,25 @@ class DecodeStage:
         logits = torch.nn.functional.linear(self._rms(h), self.lm_head)
         return logits.argmax(dim=-1)
 
+    def _attn(self, qkv, i):
+        out = torch.empty((1, self.hidden), dtype=torch.float16, device=self.dev)
+        lib = _lib.load()
+        _lib.check(lib.mxq_attn_decode_f16(qkv.data_ptr(), self.k_cache[i].data_ptr(), self.v_cache[i].data_ptr(),
+                                           self.pos.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(),
+                                           out.data_ptr(), self.heads, self.hd, self.max_ctx,
+                                           torch.cuda.current_stream(self.dev).cuda_stream), "mxq_attn_decode_f16")
+        return out
+
     def step(self, h):
         """One token through this stage's layers.  h [1, hidden] fp16."""
+        if self.fused:
+            for i, (qkv, o, gu, down) in enumerate(self.w):
+                y = packing.linear_fused(h, qkv, 1, self.norm_w)                  # RMSNorm -> q|k|v
+                a = self._attn(y, i)                                              # RoPE + cache + attention
+                h = packing.linear_fused(a, o, 0, residual=h)                     # o_proj + skip
+                g = packing.linear_fused(h, gu, 1, self.norm_w)                   # RMSNorm -> gate|up
+                h = packing.linear_fused(g, down, 2, residual=h)                  # SwiGLU -> down_proj + skip
+            return h
         scale = 1.0 / math.sqrt(self.hd)
         mask = (self.ctx_ids <= self.pos)[None, None, :]              # [1, 1, max_ctx]
         for i, (qkv, o, gu, down) in enumerate(self.w):

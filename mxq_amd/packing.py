@@ -176,3 +176,27 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
             rc = fn(*args, _stream(x2))
         _lib.check(rc, f"mxq_linear_f16[{path}]")
     return out.reshape(*x.shape[:-1], p.N)
+
+
+def linear_fused(x: torch.Tensor, p: PackedMXQ, prologue: int = 0, norm_w: Optional[torch.Tensor] = None,
+                 eps: float = 1e-5, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One-token quantised Linear with the neighbouring decoder-layer ops fused in (decode harness):
+    prologue 0 none, 1 RMSNorm(x) * norm_w, 2 SwiGLU gate (x is [1, 2K] = gate | up);
+    ``residual`` [1, N] is added to the result.  fp16 in / out, GEMV kernel."""
+    _need_gpu(x, p.qweight, norm_w, residual)
+    k_in = 2 * p.K if prologue == 2 else p.K
+    if x.dtype != torch.float16 or x.numel() != k_in:
+        raise ValueError(f"expected one fp16 token with {k_in} features")
+    if prologue == 1 and (norm_w is None or norm_w.dtype != torch.float16 or norm_w.numel() != p.K):
+        raise ValueError("RMSNorm prologue needs an fp16 weight of in_features elements")
+    if residual is not None and (residual.dtype != torch.float16 or residual.numel() != p.N):
+        raise ValueError("residual must be fp16 [1, out_features]")
+    x = x.contiguous()
+    out = torch.empty((1, p.N), dtype=torch.float16, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mxq_gemv_fused_f16(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(),
+                                          p.N, p.K, int(prologue), norm_w.data_ptr() if norm_w is not None else None,
+                                          float(eps), residual.contiguous().data_ptr() if residual is not None else None,
+                                          _stream(x)), "mxq_gemv_fused_f16")
+    return out

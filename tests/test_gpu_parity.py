@@ -357,11 +357,15 @@ def test_g4_quantizelinear_fwd_bwd(dev, g4, dt):
 # ----------------------------------------------------------------------------------------
 # decode stage (config 3 harness): fused q/k/v and gate/up GEMVs vs a dense fp32 restatement
 # ----------------------------------------------------------------------------------------
-def test_decode_stage_matches_dense_reference(dev):
+@pytest.mark.parametrize("heads,fused", [(4, False), (2, True), (2, False)])
+def test_decode_stage_matches_dense_reference(dev, heads, fused):
+    """fused = RMSNorm / SwiGLU / residual folded into the GEMV launches + the RoPE / cache /
+    attention kernel (head_dim 128); unfused = torch ops around plain GEMVs."""
     from mxq_amd import packing
     from mxq_amd.llama_decode import DecodeStage
-    hidden, inter, heads, ctx = 256, 704, 4, 32
-    st = DecodeStage(range(2), dev, max_ctx=ctx, hidden=hidden, inter=inter, heads=heads, vocab=64)
+    hidden, inter, ctx = 256, 704, 32
+    st = DecodeStage(range(2), dev, max_ctx=ctx, hidden=hidden, inter=inter, heads=heads, vocab=64, fused=fused)
+    assert st.fused == (fused and hidden // heads == 128)
     Wd = [[packing.dequant(p).float() for p in ws] for ws in st.w]
     hd = hidden // heads
     kc = torch.zeros(2, heads, ctx, hd, device=dev)
