@@ -11,7 +11,8 @@
 //           (16-bit dtypes) or 4 (fp32) adjacent lanes -> xor-shuffle min/max; every
 //           reference op is done in fp32 and rounded to the tensor dtype T, which is what
 //           PyTorch does for bf16/fp16 tensors -> bit-identical output.
-// The second read of the row hits L2 (a row is 8-44 KB).
+// The second read of the row hits L2 (a row is 8-44 KB).  For 16-bit dtypes and rows of up to
+// 12288 columns (every Llama shape) a register-resident single-pass variant is used instead.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
@@ -25,10 +26,11 @@ struct F32 {
     __device__ static __forceinline__ float rnd(float x) { return x; }
     __device__ static __forceinline__ bool near_boundary(float) { return true; }
     static constexpr bool HAS_FAST_DIV = false;   // fp32 results are not re-rounded: always the IEEE divide
-    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[4]) {
-        const float4 a = *(const float4*)((const float*)p + e);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const float*)p + e); }
+    __device__ static __forceinline__ void unpack(const uint4 a, float v[4]) {
+        v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.y); v[2] = __uint_as_float(a.z); v[3] = __uint_as_float(a.w);
     }
+    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[4]) { unpack(load_raw(p, e), v); }
     __device__ static __forceinline__ void store(void* p, int64_t e, const float v[4]) {
         *(float4*)((float*)p + e) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -46,8 +48,8 @@ struct BF16 {
         return ((u & 0xFFFFu) - 0x7FFCu) < 8u || !(a == 0.0f || (a > 1e-30f && a < 1e30f));
     }
     static constexpr bool HAS_FAST_DIV = true;
-    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) {
-        const uint4 a = *(const uint4*)((const uint16_t*)p + e);
+    __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const uint16_t*)p + e); }
+    __device__ static __forceinline__ void unpack(const uint4 a, float v[8]) {
         const uint32_t w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -55,6 +57,7 @@ struct BF16 {
             v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
         }
     }
+    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) { unpack(load_raw(p, e), v); }
     __device__ static __forceinline__ void store(void* p, int64_t e, const float v[8]) {
         uint32_t w[4];
 #pragma unroll
@@ -72,12 +75,14 @@ struct F16 {
         return ((u & 0x1FFFu) - 0x0FFCu) < 8u || !(a == 0.0f || (a > 6.2e-5f && a < 6.0e4f));
     }
     static constexpr bool HAS_FAST_DIV = true;
-    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) {
+    __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const uint16_t*)p + e); }
+    __device__ static __forceinline__ void unpack(const uint4 r, float v[8]) {
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-        const h8 a = *(const h8*)((const uint16_t*)p + e);
+        const h8 a = __builtin_bit_cast(h8, r);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
     }
+    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) { unpack(load_raw(p, e), v); }
     __device__ static __forceinline__ void store(void* p, int64_t e, const float v[8]) {
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
         h8 a;
@@ -86,6 +91,102 @@ struct F16 {
         *(h8*)((uint16_t*)p + e) = a;
     }
 };
+
+// Shared per-group math of pass 2: v[] (VEC values of one lane) -> o[].  mn/mx are the group
+// min/max (already reduced over the lanes of the group).
+template <typename T, bool FASTQ>
+__device__ __forceinline__ void quant_vec(const float (&v)[T::VEC], float alpha, float beta, float L,
+                                          float (&o)[T::VEC]) {
+    constexpr int VEC = T::VEC;
+    const float invL = 1.0f / L;
+    const float e = T::rnd(alpha + 1e-8f);
+    float xs[VEC], xn[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) xs[j] = T::rnd(v[j] - beta);
+    // (w - beta) / e must be the correctly rounded fp32 quotient re-rounded to T.  Fast path:
+    // multiply by v_rcp_f32(e) and screen; any lane near a rounding boundary (or out of the
+    // normal range) sends the wave through the IEEE divide (~5 % of the iterations).
+    bool slow = !T::HAS_FAST_DIV;
+    if constexpr (T::HAS_FAST_DIV) {
+        const float r = __builtin_amdgcn_rcpf(e);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            xn[j] = xs[j] * r;
+            slow |= T::near_boundary(xn[j]);
+        }
+        slow = __any(slow);
+    }
+    if (slow) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) xn[j] = xs[j] / e;
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float q = rintf(T::rnd(T::rnd(xn[j]) * L));
+        const float ql = FASTQ ? q * invL : q / L;
+        o[j] = T::rnd(T::rnd(T::rnd(ql) * e) + beta);
+    }
+}
+
+// Register-resident variant for rows of up to NI * 64 * VEC elements (16-bit dtypes, cols <=
+// 12288): the row is loaded ONCE with all its 16-B loads in flight, the 4-bit-arm min/max and
+// the group min/max come from registers, then everything is quantised and stored.  HBM sees
+// exactly one read and one write per element and no second pass exists.
+template <typename T, bool FASTQ, int NI>
+__global__ __launch_bounds__(256) void mxq_fakequant_fwd_reg_kernel(const void* __restrict__ w,
+                                                                    void* __restrict__ out, int rows, int cols,
+                                                                    float L2) {
+    constexpr int VEC = T::VEC;
+    constexpr int LPG = 16 / VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;   // wave-uniform
+    const int64_t base = (int64_t)row * cols;
+    uint4 raw[NI];   // the row stays in its storage format: 4 VGPRs per 16-B load
+    const bool is4 = ((lane * VEC) & 63) >= 48;   // 64 * VEC elements per iteration keep the chunk phase
+    float mn4 = INFINITY, mx4 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e0 = (i * 64 + lane) * VEC;
+        raw[i] = make_uint4(0, 0, 0, 0);
+        if (e0 < cols) raw[i] = T::load_raw(w, base + e0);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e0 = (i * 64 + lane) * VEC;
+        if (e0 < cols && is4) {
+            float t[VEC];
+            T::unpack(raw[i], t);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { mn4 = fminf(mn4, t[j]); mx4 = fmaxf(mx4, t[j]); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        mn4 = fminf(mn4, __shfl_xor(mn4, o, 64));
+        mx4 = fmaxf(mx4, __shfl_xor(mx4, o, 64));
+    }
+    const float alpha4 = T::rnd(mx4 - mn4);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e0 = (i * 64 + lane) * VEC;
+        if (e0 < cols) {   // a 16-column group is never split by the row end (cols % 64 == 0)
+            float vi[VEC];
+            T::unpack(raw[i], vi);
+            float mn = vi[0], mx = vi[0];
+#pragma unroll
+            for (int j = 1; j < VEC; ++j) { mn = fminf(mn, vi[j]); mx = fmaxf(mx, vi[j]); }
+#pragma unroll
+            for (int o = 1; o < LPG; o <<= 1) {
+                mn = fminf(mn, __shfl_xor(mn, o, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            }
+            float o[VEC];
+            quant_vec<T, FASTQ>(vi, is4 ? alpha4 : T::rnd(mx - mn), is4 ? mn4 : mn, is4 ? 15.0f : L2, o);
+            T::store(out, base + e0, o);
+        }
+    }
+}
 
 // FASTQ: q / L may be computed as q * (1/L) -- the launcher has checked on the host that this
 // rounds to the same T value for every integer 0 <= q <= L of both arms.
@@ -129,35 +230,8 @@ __global__ __launch_bounds__(256) void mxq_fakequant_fwd_kernel(const void* __re
         const bool is4 = (e0 & 63) >= 48;
         const float alpha = is4 ? alpha4 : T::rnd(mx - mn);
         const float beta = is4 ? mn4 : mn;
-        const float L = is4 ? 15.0f : L2;
-        const float invL = 1.0f / L;
-        const float e = T::rnd(alpha + 1e-8f);
-        float xs[VEC], xn[VEC], o[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) xs[j] = T::rnd(v[j] - beta);
-        // (w - beta) / e must be the correctly rounded fp32 quotient re-rounded to T.  Fast path:
-        // multiply by v_rcp_f32(e) and screen; any lane near a rounding boundary (or out of the
-        // normal range) sends the wave through the IEEE divide (~5 % of the iterations).
-        bool slow = !T::HAS_FAST_DIV;
-        if constexpr (T::HAS_FAST_DIV) {
-            const float r = __builtin_amdgcn_rcpf(e);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                xn[j] = xs[j] * r;
-                slow |= T::near_boundary(xn[j]);
-            }
-            slow = __any(slow);
-        }
-        if (slow) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) xn[j] = xs[j] / e;
-        }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const float q = rintf(T::rnd(T::rnd(xn[j]) * L));
-            const float ql = FASTQ ? q * invL : q / L;
-            o[j] = T::rnd(T::rnd(T::rnd(ql) * e) + beta);
-        }
+        float o[VEC];
+        quant_vec<T, FASTQ>(v, alpha, beta, is4 ? 15.0f : L2, o);
         T::store(out, base + e0, o);
     }
 }
@@ -205,8 +279,13 @@ int launch_fwd(const void* w, void* out, int rows, int cols, int num_bits, int d
     // the reference stores s = 2**num_bits - 1 in a tensor of the weight dtype (utils_quant.py:342,366)
     const float L2 = host_rnd((float)(exp2((double)num_bits) - 1.0), dtype);
     const bool fastq = mul_matches_div(L2, dtype) && mul_matches_div(15.0f, dtype);
-    if (fastq) mxq_fakequant_fwd_kernel<T, true><<<(rows + 3) / 4, 256, 0, stream>>>(w, out, rows, cols, L2);
-    else mxq_fakequant_fwd_kernel<T, false><<<(rows + 3) / 4, 256, 0, stream>>>(w, out, rows, cols, L2);
+    const dim3 grid((rows + 3) / 4);
+    if (fastq && T::VEC == 8 && cols <= 8 * 512)
+        mxq_fakequant_fwd_reg_kernel<T, true, 8><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
+    else if (fastq && T::VEC == 8 && cols <= 24 * 512)
+        mxq_fakequant_fwd_reg_kernel<T, true, 24><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
+    else if (fastq) mxq_fakequant_fwd_kernel<T, true><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
+    else mxq_fakequant_fwd_kernel<T, false><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
     return (int)hipGetLastError();
 }
 
