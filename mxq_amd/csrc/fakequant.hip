@@ -43,9 +43,10 @@ struct BF16 {
     __device__ static __forceinline__ float rnd(float x) { return (float)(__bf16)x; }
     // fast-division screen: fl32(x * rcp(e)) rounds to the same bf16 as the correctly rounded
     // fl32(x / e) unless it lies within a few fp32 ulps of a bf16 rounding boundary
+    // (no range test needed: e = bf16(alpha + 1e-8) is a positive normal number, bf16 has fp32's
+    // exponent range, and for inf / NaN inputs product and quotient agree.)
     __device__ static __forceinline__ bool near_boundary(float a) {
-        const uint32_t u = __float_as_uint(a);
-        return ((u & 0xFFFFu) - 0x7FFCu) < 8u || !(a == 0.0f || (a > 1e-30f && a < 1e30f));
+        return ((__float_as_uint(a) + 0x8004u) & 0xFFF8u) == 0u;   // low 16 bits in [0x7FFC, 0x8003]
     }
     static constexpr bool HAS_FAST_DIV = true;
     __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const uint16_t*)p + e); }
