@@ -12,7 +12,7 @@
 //           reference op is done in fp32 and rounded to the tensor dtype T, which is what
 //           PyTorch does for bf16/fp16 tensors -> bit-identical output.
 // The second read of the row hits L2 (a row is 8-44 KB).  For 16-bit dtypes and rows of up to
-// 12288 columns (every Llama shape) a register-resident single-pass variant is used instead.
+// 4096 columns a register-resident single-pass variant is used instead.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
@@ -130,7 +130,7 @@ __device__ __forceinline__ void quant_vec(const float (&v)[T::VEC], float alpha,
 }
 
 // Register-resident variant for rows of up to NI * 64 * VEC elements (16-bit dtypes, cols <=
-// 12288): the row is loaded ONCE with all its 16-B loads in flight, the 4-bit-arm min/max and
+// 4096): the row is loaded ONCE with all its 16-B loads in flight, the 4-bit-arm min/max and
 // the group min/max come from registers, then everything is quantised and stored.  HBM sees
 // exactly one read and one write per element and no second pass exists.
 template <typename T, bool FASTQ, int NI>
@@ -283,8 +283,8 @@ int launch_fwd(const void* w, void* out, int rows, int cols, int num_bits, int d
     const dim3 grid((rows + 3) / 4);
     if (fastq && T::VEC == 8 && cols <= 8 * 512)
         mxq_fakequant_fwd_reg_kernel<T, true, 8><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
-    else if (fastq && T::VEC == 8 && cols <= 24 * 512)
-        mxq_fakequant_fwd_reg_kernel<T, true, 24><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
+    // (a 24-iteration instance for rows up to 12288 columns was measured slower than the two-pass
+    // kernel: hipcc keeps the unpacked row live, 231 VGPRs, 2 waves/SIMD)
     else if (fastq) mxq_fakequant_fwd_kernel<T, true><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
     else mxq_fakequant_fwd_kernel<T, false><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
     return (int)hipGetLastError();
