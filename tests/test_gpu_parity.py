@@ -400,3 +400,63 @@ def test_decode_stage_matches_dense_reference(dev, heads, fused):
         want = ref_step(h0.float(), pos)
         assert ((got - want).abs().max() / want.abs().max()).item() < 2e-2, pos     # fp16 activations end to end
     assert int(st.pos.item()) == 5
+
+
+def test_g5_decoder_block_fwd_bwd(dev, g5):
+    """A Llama decoder layer built from this repo's QuantizeLinear (w_bits=2, a_bits=16) must
+    reproduce the reference's LlamaDecoderLayer (LLM-QAT/models/modeling_llama_quant.py:414-469)
+    output, input gradient and all seven weight gradients on the golden block G5.  The layer
+    scaffolding (RMSNorm, rotary, attention) is restated here with plain torch ops; only the
+    quantised Linears are the product code."""
+    from mxq_amd.utils_quant import QuantizeLinear
+    H, I, heads = 256, 704, 4
+    hd = H // heads
+    names = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj",
+             "mlp.up_proj", "mlp.down_proj"]
+    lin = {}
+    for n in names:
+        w = torch.from_numpy(g5[f"sd_{n}.weight"]).to(dev)
+        m = QuantizeLinear(w.shape[1], w.shape[0], w_bits=2, a_bits=16).to(dev)
+        m.weight.data = w.clone()
+        lin[n] = m
+    ln1 = torch.from_numpy(g5["sd_input_layernorm.weight"]).to(dev)
+    ln2 = torch.from_numpy(g5["sd_post_attention_layernorm.weight"]).to(dev)
+    inv_freq = torch.from_numpy(g5["sd_self_attn.rotary_emb.inv_freq"]).to(dev)
+    x = torch.from_numpy(g5["x"]).to(dev).requires_grad_()
+    pos = torch.from_numpy(g5["pos"]).to(dev)
+    B, S, _ = x.shape
+
+    def rms(h, w, eps=1e-6):
+        return w * (h * torch.rsqrt(h.float().pow(2).mean(-1, keepdim=True) + eps))
+
+    def rot_half(t):
+        return torch.cat((-t[..., hd // 2:], t[..., : hd // 2]), dim=-1)
+
+    freqs = torch.einsum("i,j->ij", torch.arange(64, device=dev).float(), inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos, sin = emb.cos()[pos].unsqueeze(1), emb.sin()[pos].unsqueeze(1)          # [B, 1, S, hd]
+    mask = torch.full((S, S), torch.finfo(torch.float32).min, device=dev).triu(1)[None, None]
+
+    h = rms(x, ln1)
+    q = lin["self_attn.q_proj"](h).view(B, S, heads, hd).transpose(1, 2)
+    k = lin["self_attn.k_proj"](h).view(B, S, heads, hd).transpose(1, 2)
+    v = lin["self_attn.v_proj"](h).view(B, S, heads, hd).transpose(1, 2)
+    q, k = q * cos + rot_half(q) * sin, k * cos + rot_half(k) * sin
+    att = torch.matmul(q, k.transpose(2, 3)) / hd ** 0.5 + mask
+    att = torch.max(att, torch.tensor(torch.finfo(att.dtype).min, device=dev))
+    att = torch.softmax(att, dim=-1, dtype=torch.float32)
+    a = torch.matmul(att, v).transpose(1, 2).reshape(B, S, H)
+    h1 = x + lin["self_attn.o_proj"](a)
+    h2 = rms(h1, ln2)
+    y = h1 + lin["mlp.down_proj"](torch.nn.functional.silu(lin["mlp.gate_proj"](h2)) * lin["mlp.up_proj"](h2))
+    y.backward(torch.from_numpy(g5["gy"]).to(dev))
+
+    def close(got, ref, what, tol=2e-4):
+        ref = torch.from_numpy(ref).to(dev)
+        err = ((got - ref).abs().max() / ref.abs().max()).item()
+        assert err <= tol, (what, err)
+
+    close(y.detach(), g5["y"], "y")
+    close(x.grad, g5["dx"], "dx")
+    for n in names:
+        close(lin[n].weight.grad, g5[f"grad_{n}.weight"], n)
