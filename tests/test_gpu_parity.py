@@ -408,7 +408,7 @@ def test_g5_decoder_block_fwd_bwd(dev, g5):
     output, input gradient and all seven weight gradients on the golden block G5.  The layer
     scaffolding (RMSNorm, rotary, attention) is restated here with plain torch ops; only the
     quantised Linears are the product code."""
-    from mxq_amd.utils_quant import QuantizeLinear
+    from mxq_amd.utils_quant import QuantizeLinear, SymQuantizer
     H, I, heads = 256, 704, 4
     hd = H // heads
     names = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj",
@@ -439,8 +439,10 @@ def test_g5_decoder_block_fwd_bwd(dev, g5):
 
     h = rms(x, ln1)
     q = lin["self_attn.q_proj"](h).view(B, S, heads, hd).transpose(1, 2)
-    k = lin["self_attn.k_proj"](h).view(B, S, heads, hd).transpose(1, 2)
-    v = lin["self_attn.v_proj"](h).view(B, S, heads, hd).transpose(1, 2)
+    # KV fake-quant (kv_bits = 16 in G5): SymQuantizer with clip [-2, 2] (modeling_llama_quant.py:322-329)
+    kv_clip = torch.tensor([-2.0, 2.0])
+    k = SymQuantizer.apply(lin["self_attn.k_proj"](h), kv_clip, 16, False).view(B, S, heads, hd).transpose(1, 2)
+    v = SymQuantizer.apply(lin["self_attn.v_proj"](h), kv_clip, 16, False).view(B, S, heads, hd).transpose(1, 2)
     q, k = q * cos + rot_half(q) * sin, k * cos + rot_half(k) * sin
     att = torch.matmul(q, k.transpose(2, 3)) / hd ** 0.5 + mask
     att = torch.max(att, torch.tensor(torch.finfo(att.dtype).min, device=dev))
