@@ -99,6 +99,25 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
 int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* stream);
 
+/* Uniform-bit-width layouts for the W2A16 / W4A16 / mixed sweep (BASELINE config 5); the mixed
+ * layout is layout 0.  1 = W2G16: Quantizer(bits=2, qq_scale_bits=4) on every 16-column group
+ * (quantizer.py:61-147), 4.5 bit/weight; 2 = W4ROW: Quantizer(bits=4, qq_scale_bits=4) per row
+ * (the mixed layout's 4-bit arm on all columns), 4 bit/weight.  Same block grid / bit order. */
+#define MXQ_LAYOUT_MIXED 0
+#define MXQ_LAYOUT_W2G16 1
+#define MXQ_LAYOUT_W4ROW 2
+size_t mxq_qweight_bytes_layout(int N, int K, int layout);
+int mxq_quantize_pack_layout(const void* W, int w_dtype, void* qweight, void* rowmeta, int N, int K, int layout,
+                             void* stream);
+/* Uniform layouts only: dequantise to fp16 [N, K] (w16, nullable) and / or integer-unpack (codes u8
+ * [N, K], nullable, with sc u8 / zero f32 [N, K/16] and qs / qz f32 [N/16, K/16] for W2G16, or sc / zero
+ * [N] and qs / qz [N/16] for W4ROW). */
+int mxq_expand_layout(const void* qweight, const void* rowmeta, void* w16, uint8_t* codes, uint8_t* sc, float* zero,
+                      float* qs, float* qz, int N, int K, int layout, void* stream);
+/* MFMA dequant-GEMM (the wave-specialised kernel) on any layout. */
+int mxq_gemm_f16_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                        int layout, void* stream);
+
 /* Decode-time variant of mxq_gemv_f16 for ONE token with the neighbouring elementwise ops of a
  * Llama decoder layer fused into the activation staging / the store (no reference counterpart:
  * the reference's decode is HF transformers on fake-quant weights):

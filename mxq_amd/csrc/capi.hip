@@ -117,6 +117,42 @@ int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const voi
                                       (hipStream_t)stream);
 }
 
+// ---- uniform layouts of the config-5 sweep ---------------------------------------------------
+static bool layout_ok(int l) { return l == MXQ_LAYOUT_MIXED || l == MXQ_LAYOUT_W2G16 || l == MXQ_LAYOUT_W4ROW; }
+
+size_t mxq_qweight_bytes_layout(int N, int K, int layout) {
+    if (!shape_ok(N, K) || !layout_ok(layout)) return 0;
+    return (size_t)(N / 16) * (K / 64) * mxq_layout_blk_dw(layout) * 4;
+}
+
+int mxq_quantize_pack_layout(const void* W, int w_dtype, void* qweight, void* rowmeta, int N, int K, int layout,
+                             void* stream) {
+    if (!W || !qweight || !rowmeta) return MXQ_E_NULL;
+    if (!shape_ok(N, K) || !layout_ok(layout)) return MXQ_E_SHAPE;
+    if (!dtype_ok(w_dtype)) return MXQ_E_DTYPE;
+    if (!aligned16(W) || !aligned16(qweight) || !aligned16(rowmeta)) return MXQ_E_ALIGN;
+    if (layout == MXQ_LAYOUT_MIXED)
+        return mxq_launch_quantize_pack(W, w_dtype, nullptr, qweight, rowmeta, N, K, (hipStream_t)stream);
+    return mxq_launch_quantize_uniform(W, w_dtype, qweight, rowmeta, N, K, layout, (hipStream_t)stream);
+}
+
+int mxq_expand_layout(const void* qweight, const void* rowmeta, void* w16, uint8_t* codes, uint8_t* sc, float* zero,
+                      float* qs, float* qz, int N, int K, int layout, void* stream) {
+    if (!qweight || !rowmeta || (!w16 && !codes)) return MXQ_E_NULL;
+    if (codes && (!sc || !zero || !qs || !qz)) return MXQ_E_NULL;
+    if (!shape_ok(N, K) || (layout != MXQ_LAYOUT_W2G16 && layout != MXQ_LAYOUT_W4ROW)) return MXQ_E_SHAPE;
+    if (!aligned16(qweight) || !aligned16(rowmeta) || (w16 && !aligned16(w16))) return MXQ_E_ALIGN;
+    return mxq_launch_uniform_expand(qweight, rowmeta, w16, codes, sc, zero, qs, qz, N, K, layout,
+                                     (hipStream_t)stream);
+}
+
+int mxq_gemm_f16_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                        int layout, void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    if (!layout_ok(layout)) return MXQ_E_SHAPE;
+    return mxq_launch_gemm4_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
+}
+
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;

@@ -172,19 +172,40 @@ __device__ __forceinline__ void issue_a(const Prod& c, int t) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) glds16(c.a_src[i] + t * BK, dst + i * 1024);
 }
+template <int LAYOUT>
 __device__ __forceinline__ void issue_bp(const Prod& c, int t) {
-    // producer p copies packed blocks 2p, 2p+1 (rows 32p .. 32p+31), 36 lanes each
+    // producer p copies packed blocks 2p, 2p+1 (rows 32p .. 32p+31), 36 lanes each (32 for W4ROW);
+    // the LDS stride stays 576 B for every layout (bank-conflict-free block spacing)
+    constexpr int BYTES = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : MXQ_BLK_BYTES;
     char* dst = c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.p * 2 * BP_BLK;
-    if (c.lane < 36) {
-        glds16(c.bp_src[0] + (int64_t)t * MXQ_BLK_BYTES, dst);
-        glds16(c.bp_src[1] + (int64_t)t * MXQ_BLK_BYTES, dst + BP_BLK);
+    if (c.lane < BYTES / 16) {
+        glds16(c.bp_src[0] + (int64_t)t * BYTES, dst);
+        glds16(c.bp_src[1] + (int64_t)t * BYTES, dst + BP_BLK);
     }
 }
 
 // thread -> (W row d_row, quarter pair d_qp): chunk t's 32 weights of that row -> W16[t & 1]
+template <int LAYOUT>
 __device__ __forceinline__ void dequant(const Prod& c, int t) {
     const uint32_t* blk = (const uint32_t*)(c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.d_blk * BP_BLK);
     uint32_t o[16];
+    if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            mxq_deq4x8(blk[mxq_w4_c4(c.d_qp * 2 + q, 0, c.d_r)], c.s4, c.z4, o + 8 * q);
+            mxq_deq4x8(blk[mxq_w4_c4(c.d_qp * 2 + q, 1, c.d_r)], c.s4, c.z4, o + 8 * q + 4);
+        }
+    } else if constexpr (LAYOUT == MXQ_LAYOUT_W2G16) {
+        const uint32_t scw = ((const uint16_t*)blk)[mxq_sc_u16(c.d_r)];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int g = c.d_qp * 2 + q;
+            mxq_deq2x16(blk[mxq_w2_c2(g, c.d_r)],
+                        mxq_scale(__uint_as_float(blk[mxq_qq(g)]), __uint_as_float(blk[mxq_qq(g) + 1]),
+                                  (scw >> (4 * g)) & 15u),
+                        __uint_as_float(blk[mxq_w2_z2(g, c.d_r)]), o + 8 * q);
+        }
+    } else {
     const uint32_t scw = ((const uint16_t*)blk)[mxq_sc_u16(c.d_r)];
     if (c.d_qp == 0) {
         mxq_deq2x16(blk[mxq_c2(0, c.d_r)],
@@ -200,42 +221,43 @@ __device__ __forceinline__ void dequant(const Prod& c, int t) {
         mxq_deq4x8(blk[mxq_c4(0, c.d_r)], c.s4, c.z4, o + 8);
         mxq_deq4x8(blk[mxq_c4(1, c.d_r)], c.s4, c.z4, o + 12);
     }
+    }
     char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
         *(u32x4*)(wt + swz(c.d_row, c.d_qp * 4 + s)) = (u32x4){o[4 * s], o[4 * s + 1], o[4 * s + 2], o[4 * s + 3]};
 }
 
-template <int ABL>
+template <int ABL, int LAYOUT>
 __device__ __forceinline__ void producer(const Prod& c) {
     // prologue: x tiles 0,1; packed blocks 0..2; W16(0)
     for (int t = 0; t < 2 && t < c.NT; ++t) issue_a(c, t);
-    for (int t = 0; t < 3 && t < c.NT; ++t) issue_bp(c, t);
+    for (int t = 0; t < 3 && t < c.NT; ++t) issue_bp<LAYOUT>(c, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    dequant(c, 0);
+    dequant<LAYOUT>(c, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     int t = 0;
     for (; t + 3 < c.NT; ++t) {   // steady state: everything unconditional
         if constexpr (!(ABL & 1)) issue_a(c, t + 2);
-        issue_bp(c, t + 3);
-        if constexpr (!(ABL & 4)) dequant(c, t + 1);
+        issue_bp<LAYOUT>(c, t + 3);
+        if constexpr (!(ABL & 4)) dequant<LAYOUT>(c, t + 1);
         if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // this step's 10 DMAs stay in flight
         __builtin_amdgcn_s_barrier();
     }
     for (; t < c.NT; ++t) {
         if (t + 2 < c.NT) issue_a(c, t + 2);
-        if (t + 3 < c.NT) issue_bp(c, t + 3);
-        if (t + 1 < c.NT) dequant(c, t + 1);
+        if (t + 3 < c.NT) issue_bp<LAYOUT>(c, t + 3);
+        if (t + 1 < c.NT) dequant<LAYOUT>(c, t + 1);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 }
 
-template <int ABL>
+template <int ABL, int LAYOUT>
 __global__ __launch_bounds__(THREADS) void mxq_gemm4_f16_kernel(const uint16_t* __restrict__ x,
                                                                const uint32_t* __restrict__ qweight,
                                                                const float4* __restrict__ rowmeta,
@@ -269,7 +291,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm4_f16_kernel(const uint16_t* 
     for (int b = 0; b < 2; ++b) {
         int rb = (n0 >> 4) + c.p * 2 + b;
         rb = rb < (N >> 4) ? rb : (N >> 4) - 1;
-        c.bp_src[b] = (const char*)(qweight + (int64_t)rb * NT * MXQ_BLK_DW) + lane * 16;
+        c.bp_src[b] = (const char*)(qweight + (int64_t)rb * NT * (LAYOUT == MXQ_LAYOUT_W4ROW ? 128 : 144)) + lane * 16;
     }
     const int ptid = tid - N_CONS * 64;   // 0..255
     c.d_row = ptid & 127;
@@ -278,24 +300,24 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm4_f16_kernel(const uint16_t* 
     c.d_r = c.d_row & 15;
     c.s4 = 0.f;
     c.z4 = 0.f;
-    if (c.d_qp == 1) {
+    if (c.d_qp == 1 || LAYOUT == MXQ_LAYOUT_W4ROW) {
         int gn = n0 + c.d_row;
         gn = gn < N ? gn : N - 1;
         const float4 m = rowmeta[gn];
         c.s4 = mxq_scale(m.z, m.w, (uint32_t)m.y);
         c.z4 = m.x;
     }
-    producer<ABL>(c);
+    producer<ABL, LAYOUT>(c);
 }
 
-template <int ABL>
+template <int ABL, int LAYOUT = MXQ_LAYOUT_MIXED>
 static int launch4(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm4_f16_kernel<ABL>,
+    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm4_f16_kernel<ABL, LAYOUT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    mxq_gemm4_f16_kernel<ABL><<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
+    mxq_gemm4_f16_kernel<ABL, LAYOUT><<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n);
     return (int)hipGetLastError();
 }
@@ -305,6 +327,17 @@ static int launch4(const void* x, const void* qweight, const void* rowmeta, void
 int mxq_launch_gemm4_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          hipStream_t stream) {
     return launch4<0>(x, qweight, rowmeta, y, M, N, K, stream);
+}
+
+// uniform layouts of the config-5 sweep (mxq_format.h): same kernel, different producer dequant
+int mxq_launch_gemm4_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                int layout, hipStream_t stream) {
+    switch (layout) {
+        case MXQ_LAYOUT_MIXED: return launch4<0, MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_W2G16: return launch4<0, MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_W4ROW: return launch4<0, MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, stream);
+    }
+    return (int)hipErrorInvalidValue;
 }
 
 // profiling-only ablation builds (wrong results): 1 no x DMA, 2 no MFMA, 4 no dequant, 8 no fragment reads

@@ -28,6 +28,13 @@
 //   2-bit word: code of element k (0..15) sits at bit 8*(k&3) + 2*(k>>2)
 //   4-bit word: code of element k (0..7)  sits at bit 8*(k&3) + 4*(k>>2)
 //
+// Two uniform layouts exist for the W2 / W4 / mixed sweep of BASELINE config 5 (same [N/16][K/64]
+// block grid, same code-word bit order, same second-order scale coding):
+//   W2G16: every 16-column quarter is a 2-bit group:  C2 [g:4][r:16] @0, Z2 [g:4][r:16] @64,
+//          SC [r:16] u16 (4 nibbles) @128, QQ [g:4][2] @136 -- 144 dwords, 4.5 bit/weight.
+//   W4ROW: 4-bit codes with ONE scale/zero per row (the mixed layout's 4-bit arm applied to all
+//          columns): C4 [q:4][h:2][r:16] @0 -- 128 dwords, 4.0 bit/weight + rowmeta.
+//
 // rowmeta = [N] float4 {zero4, (float)scale_code4, qs4, qz4} (qs4/qz4 replicated over
 // the 16 rows of a block).
 #pragma once
@@ -62,3 +69,11 @@ MXQ_HD int mxq_c4(int h, int r) { return MXQ_OFF_C4 + h * 16 + r; }
 MXQ_HD int mxq_z2(int g, int r) { return MXQ_OFF_Z2 + g * 16 + r; }
 MXQ_HD int mxq_sc_u16(int r) { return MXQ_OFF_SC * 2 + r; }   // u16 index
 MXQ_HD int mxq_qq(int g) { return MXQ_OFF_QQ + g * 2; }
+
+#define MXQ_LAYOUT_MIXED 0
+#define MXQ_LAYOUT_W2G16 1
+#define MXQ_LAYOUT_W4ROW 2
+MXQ_HD int mxq_layout_blk_dw(int layout) { return layout == MXQ_LAYOUT_W4ROW ? 128 : 144; }
+MXQ_HD int mxq_w2_c2(int g, int r) { return g * 16 + r; }
+MXQ_HD int mxq_w2_z2(int g, int r) { return 64 + g * 16 + r; }
+MXQ_HD int mxq_w4_c4(int q, int h, int r) { return (q * 2 + h) * 16 + r; }

@@ -251,6 +251,137 @@ __global__ __launch_bounds__(256) void mxq_quantize_pack_kernel(const void* __re
 }
 
 // ------------------------------------------------------------------------------------ //
+// Uniform layouts (BASELINE config 5 sweep arms): W2G16 = Quantizer(bits=2, qq_scale_bits=4) on
+// every 16-column group; W4ROW = Quantizer(bits=4, qq_scale_bits=4) on whole rows
+// (reference lib/quantizer.py:61-147; same arithmetic as the mixed layout's two arms).
+// Same workgroup shape as mxq_quantize_pack_kernel: 16 rows x (4 waves over the chunks).
+// ------------------------------------------------------------------------------------ //
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void mxq_quantize_uniform_kernel(const void* __restrict__ W, int dtype,
+                                                                   uint32_t* __restrict__ qweight,
+                                                                   float4* __restrict__ rowmeta, int N, int K) {
+    const int NC = K / 64;
+    const int rb = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, qt = lane >> 4;
+    const int n = rb * 16 + r;
+    constexpr int BLK = LAYOUT == MXQ_LAYOUT_W4ROW ? 128 : 144;
+    float v[16];
+    if constexpr (LAYOUT == MXQ_LAYOUT_W2G16) {
+        for (int c = wave; c < NC; c += 4) {
+            load16(W, dtype, (int64_t)n * K + c * 64 + qt * 16, v);
+            float lo = v[0], hi = v[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) { lo = fminf(lo, v[j]); hi = fmaxf(hi, v[j]); }
+            float z, scode, s, qs, qz;
+            find_params16(lo, hi, 3.0f, z, scode, s, qs, qz);
+            const float sd = fmaxf(s, 1e-9f);
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                word |= (uint32_t)fminf(fmaxf(rintf(v[j] / sd + z), 0.0f), 3.0f) << mxq_bit2(j);
+            const uint32_t sci = (uint32_t)scode;
+            const uint32_t s1 = __shfl(sci, r + 16, 64), s2 = __shfl(sci, r + 32, 64), s3 = __shfl(sci, r + 48, 64);
+            uint32_t* blk = qweight + ((int64_t)rb * NC + c) * BLK;
+            blk[mxq_w2_c2(qt, r)] = word;
+            blk[mxq_w2_z2(qt, r)] = __float_as_uint(z);
+            if (r == 0) {
+                blk[mxq_qq(qt)] = __float_as_uint(qs);
+                blk[mxq_qq(qt) + 1] = __float_as_uint(qz);
+            }
+            if (qt == 0) ((uint16_t*)blk)[mxq_sc_u16(r)] = (uint16_t)(sci | (s1 << 4) | (s2 << 8) | (s3 << 12));
+        }
+        if (wave == 0 && qt == 0) rowmeta[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        __shared__ float red[2][4][16];
+        float mn = INFINITY, mx = -INFINITY;
+        for (int c = wave; c < NC; c += 4) {
+            load16(W, dtype, (int64_t)n * K + c * 64 + qt * 16, v);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { mn = fminf(mn, v[j]); mx = fmaxf(mx, v[j]); }
+        }
+        mn = fminf(mn, __shfl_xor(mn, 16, 64)); mn = fminf(mn, __shfl_xor(mn, 32, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (qt == 0) { red[0][wave][r] = mn; red[1][wave][r] = mx; }
+        __syncthreads();
+        const float lo = fminf(fminf(red[0][0][r], red[0][1][r]), fminf(red[0][2][r], red[0][3][r]));
+        const float hi = fmaxf(fmaxf(red[1][0][r], red[1][1][r]), fmaxf(red[1][2][r], red[1][3][r]));
+        float z4, sc4, s4, qs4, qz4;
+        find_params16(lo, hi, 15.0f, z4, sc4, s4, qs4, qz4);
+        if (wave == 0 && qt == 0) rowmeta[n] = make_float4(z4, sc4, qs4, qz4);
+        const float sd4 = fmaxf(s4, 1e-9f);
+        for (int c = wave; c < NC; c += 4) {
+            load16(W, dtype, (int64_t)n * K + c * 64 + qt * 16, v);
+            uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                w0 |= (uint32_t)fminf(fmaxf(rintf(v[j] / sd4 + z4), 0.0f), 15.0f) << mxq_bit4(j);
+                w1 |= (uint32_t)fminf(fmaxf(rintf(v[j + 8] / sd4 + z4), 0.0f), 15.0f) << mxq_bit4(j);
+            }
+            uint32_t* blk = qweight + ((int64_t)rb * NC + c) * BLK;
+            blk[mxq_w4_c4(qt, 0, r)] = w0;
+            blk[mxq_w4_c4(qt, 1, r)] = w1;
+        }
+    }
+}
+
+// one thread per (row, chunk quarter): fp16 dequant (dense [N, K]) and / or integer unpack
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void mxq_uniform_expand_kernel(const uint32_t* __restrict__ qweight,
+                                                                 const float4* __restrict__ rowmeta,
+                                                                 uint16_t* __restrict__ w16, uint8_t* __restrict__ codes,
+                                                                 uint8_t* __restrict__ sc, float* __restrict__ zero,
+                                                                 float* __restrict__ qs, float* __restrict__ qz, int N,
+                                                                 int K) {
+    const int NC = K / 64, NC4 = (NC + 3) / 4;
+    const int rb = blockIdx.x / NC4, c4 = blockIdx.x % NC4;
+    const int t = threadIdx.x;
+    const int r = t & 15, cs = (t >> 4) & 3, qt = t >> 6;
+    const int n = rb * 16 + r, c = c4 * 4 + cs;
+    if (c >= NC) return;
+    constexpr int BLK = LAYOUT == MXQ_LAYOUT_W4ROW ? 128 : 144;
+    const uint32_t* blk = qweight + ((int64_t)rb * NC + c) * BLK;
+    uint32_t o[8];
+    const int64_t col0 = (int64_t)c * 64 + qt * 16;
+    if constexpr (LAYOUT == MXQ_LAYOUT_W2G16) {
+        const uint32_t d = blk[mxq_w2_c2(qt, r)];
+        const float z = __uint_as_float(blk[mxq_w2_z2(qt, r)]);
+        const uint32_t code = (((const uint16_t*)blk)[mxq_sc_u16(r)] >> (4 * qt)) & 15u;
+        const float a = __uint_as_float(blk[mxq_qq(qt)]), b = __uint_as_float(blk[mxq_qq(qt) + 1]);
+        mxq_deq2x16(d, mxq_scale(a, b, code), z, o);
+        if (codes) {
+            for (int k = 0; k < 16; ++k) codes[(int64_t)n * K + col0 + k] = (uint8_t)mxq_code2(d, k);
+            const int64_t g = (int64_t)c * 4 + qt;
+            sc[(int64_t)n * (K / 16) + g] = (uint8_t)code;
+            zero[(int64_t)n * (K / 16) + g] = z;
+            if (r == 0) { qs[(int64_t)rb * (K / 16) + g] = a; qz[(int64_t)rb * (K / 16) + g] = b; }
+        }
+    } else {
+        const float4 m = rowmeta[n];
+        const float s = mxq_scale(m.z, m.w, (uint32_t)m.y);
+        const uint32_t d0 = blk[mxq_w4_c4(qt, 0, r)], d1 = blk[mxq_w4_c4(qt, 1, r)];
+        mxq_deq4x8(d0, s, m.x, o);
+        mxq_deq4x8(d1, s, m.x, o + 4);
+        if (codes) {
+            for (int k = 0; k < 8; ++k) {
+                codes[(int64_t)n * K + col0 + k] = (uint8_t)mxq_code4(d0, k);
+                codes[(int64_t)n * K + col0 + 8 + k] = (uint8_t)mxq_code4(d1, k);
+            }
+            if (c == 0 && qt == 0) {
+                sc[n] = (uint8_t)m.y;
+                zero[n] = m.x;
+                if (r == 0) { qs[rb] = m.z; qz[rb] = m.w; }
+            }
+        }
+    }
+    if (w16) {
+        uint4* dst = (uint4*)(w16 + (int64_t)n * K + col0);
+        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ //
 // launchers
 // ------------------------------------------------------------------------------------ //
 int mxq_launch_pack_codes(const uint8_t* codes2, const uint8_t* sc2, const float* zero2, const float* qs2,
@@ -285,5 +416,28 @@ int mxq_launch_quantize_pack(const void* W, int dtype, const uint8_t* dead, void
                              int K, hipStream_t stream) {
     mxq_quantize_pack_kernel<<<(unsigned)(N / 16), 256, 0, stream>>>(W, dtype, dead, (uint32_t*)qweight,
                                                                       (float4*)rowmeta, N, K);
+    return (int)hipGetLastError();
+}
+
+int mxq_launch_quantize_uniform(const void* W, int dtype, void* qweight, void* rowmeta, int N, int K, int layout,
+                                hipStream_t stream) {
+    if (layout == MXQ_LAYOUT_W2G16)
+        mxq_quantize_uniform_kernel<MXQ_LAYOUT_W2G16><<<(unsigned)(N / 16), 256, 0, stream>>>(
+            W, dtype, (uint32_t*)qweight, (float4*)rowmeta, N, K);
+    else
+        mxq_quantize_uniform_kernel<MXQ_LAYOUT_W4ROW><<<(unsigned)(N / 16), 256, 0, stream>>>(
+            W, dtype, (uint32_t*)qweight, (float4*)rowmeta, N, K);
+    return (int)hipGetLastError();
+}
+
+int mxq_launch_uniform_expand(const void* qweight, const void* rowmeta, void* w16, uint8_t* codes, uint8_t* sc,
+                              float* zero, float* qs, float* qz, int N, int K, int layout, hipStream_t stream) {
+    const unsigned grid = (unsigned)((N / 16) * ((K / 64 + 3) / 4));
+    if (layout == MXQ_LAYOUT_W2G16)
+        mxq_uniform_expand_kernel<MXQ_LAYOUT_W2G16><<<grid, 256, 0, stream>>>(
+            (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)w16, codes, sc, zero, qs, qz, N, K);
+    else
+        mxq_uniform_expand_kernel<MXQ_LAYOUT_W4ROW><<<grid, 256, 0, stream>>>(
+            (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)w16, codes, sc, zero, qs, qz, N, K);
     return (int)hipGetLastError();
 }

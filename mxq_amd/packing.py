@@ -200,3 +200,85 @@ def linear_fused(x: torch.Tensor, p: PackedMXQ, prologue: int = 0, norm_w: Optio
                                           float(eps), residual.contiguous().data_ptr() if residual is not None else None,
                                           _stream(x)), "mxq_gemv_fused_f16")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# uniform layouts of the BASELINE config-5 sweep (W2A16 / W4A16 arms next to the mixed layout)
+# ------------------------------------------------------------------------------------------------
+LAYOUTS = {"mixed": 0, "w2g16": 1, "w4row": 2}
+
+
+@dataclass
+class PackedUniform:
+    """W2G16 / W4ROW packed weight (csrc/mxq_format.h); same [N/16][K/64] block grid as PackedMXQ."""
+    qweight: torch.Tensor
+    rowmeta: torch.Tensor
+    N: int
+    K: int
+    layout: str
+
+    def nbytes(self) -> int:
+        return self.qweight.numel() * 4 + self.rowmeta.numel() * 4
+
+    def bits_per_weight(self) -> float:
+        return 8.0 * self.nbytes() / (self.N * self.K)
+
+
+def quantize_pack_uniform(W: torch.Tensor, layout: str) -> PackedUniform:
+    """Quantise W [N, K] with ``Quantizer(bits=2, group 16)`` ("w2g16") or ``Quantizer(bits=4, per row)``
+    ("w4row"), both with the 4-bit second-order scale coding (reference lib/quantizer.py:61-147)."""
+    _need_gpu(W)
+    if layout not in ("w2g16", "w4row"):
+        raise ValueError("layout must be 'w2g16' or 'w4row'")
+    if W.dim() != 2 or W.dtype not in _TORCH2CODE:
+        raise ValueError("weight must be a 2-D fp16 / bf16 / fp32 tensor")
+    N, K = W.shape
+    check_shape(N, K)
+    W = W.contiguous()
+    lib = _lib.load()
+    nbytes = lib.mxq_qweight_bytes_layout(N, K, LAYOUTS[layout])
+    p = PackedUniform(torch.empty(nbytes // 4, dtype=torch.int32, device=W.device),
+                      torch.empty((N, 4), dtype=torch.float32, device=W.device), N, K, layout)
+    with torch.cuda.device(W.device):
+        _lib.check(lib.mxq_quantize_pack_layout(W.data_ptr(), _TORCH2CODE[W.dtype], p.qweight.data_ptr(),
+                                                p.rowmeta.data_ptr(), N, K, LAYOUTS[layout], _stream(W)),
+                   "mxq_quantize_pack_layout")
+    return p
+
+
+def expand_uniform(p: PackedUniform, codes: bool = True):
+    """(fp16 [N, K] dequantised weight, dict of integer codes / parameters or None)."""
+    N, K, dev = p.N, p.K, p.qweight.device
+    w16 = torch.empty((N, K), dtype=torch.float16, device=dev)
+    out = None
+    ptrs = [None] * 5
+    if codes:
+        G = K // 16 if p.layout == "w2g16" else 1
+        out = dict(codes=torch.empty((N, K), dtype=torch.uint8, device=dev),
+                   sc=torch.empty((N, G), dtype=torch.uint8, device=dev),
+                   zero=torch.empty((N, G), dtype=torch.float32, device=dev),
+                   qs=torch.empty((N // 16, G), dtype=torch.float32, device=dev),
+                   qz=torch.empty((N // 16, G), dtype=torch.float32, device=dev))
+        ptrs = [out[k].data_ptr() for k in ("codes", "sc", "zero", "qs", "qz")]
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.mxq_expand_layout(p.qweight.data_ptr(), p.rowmeta.data_ptr(), w16.data_ptr(), *ptrs, N, K,
+                                         LAYOUTS[p.layout], _stream(w16)), "mxq_expand_layout")
+    return w16, out
+
+
+def linear_layout(x: torch.Tensor, p, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MFMA dequant-GEMM on a PackedMXQ (mixed) or PackedUniform weight, any token count."""
+    layout = LAYOUTS[getattr(p, "layout", "mixed")]
+    _need_gpu(x, p.qweight)
+    if x.dtype != torch.float16 or x.shape[-1] != p.K:
+        raise ValueError("activations must be fp16 [..., in_features]")
+    x2 = x.reshape(-1, p.K).contiguous()
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty((M, p.N), dtype=torch.float16, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mxq_gemm_f16_layout(x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M,
+                                           p.N, p.K, layout, _stream(x2)), "mxq_gemm_f16_layout")
+    return out.reshape(*x.shape[:-1], p.N)

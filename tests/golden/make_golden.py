@@ -18,6 +18,7 @@ Reference entry points exercised:
   G5 block_small models.modeling_llama_quant.LlamaDecoderLayer fwd/bwd (w_bits=2).
   G6 kat         constants of cuda_kernel/test_correct_gemv.py (expected == 4096).
   G7 act         models.utils_quant.SymQuantizer / AsymQuantizer fwd/bwd (2-D, 3-D, 4-D).
+  G8 uniform     lib.quantizer.Quantizer as uniform W2 (group 16) / W4 (per row) quantiser.
 """
 import hashlib
 import os
@@ -269,6 +270,39 @@ def g7_act_quantizers():
     np.savez_compressed(os.path.join(OUT, "g7_act_quantizers.npz"), **out)
 
 
+def g8_uniform():
+    """Uniform W2 (group 16) / W4 (per row) arms of the config-5 sweep: the reference's Quantizer
+    (lib/quantizer.py) applied group by group / to whole rows."""
+    torch.manual_seed(8)
+    N, K = 32, 128
+    W = (torch.randn(N, K) * 0.02).half()
+    W[1, 16:32] = 0.01          # constant group
+    W[2, :] = -0.3              # constant row
+    Wf = W.float()
+    out = dict(W=W.numpy())
+    codes = torch.zeros(N, K); sc = torch.zeros(N, K // 16); zero = torch.zeros(N, K // 16)
+    qs = torch.zeros(N // 16, K // 16); qz = torch.zeros(N // 16, K // 16); wq = torch.zeros(N, K)
+    for g in range(K // 16):
+        blk = Wf[:, 16 * g:16 * g + 16].clone()
+        q = ref_quantizer.Quantizer()
+        q.configure(bits=2, perchannel=True, sym=False, qq_scale_bits=4)
+        q.find_params(blk, weight=True)
+        codes[:, 16 * g:16 * g + 16] = q.quantize(blk)
+        wq[:, 16 * g:16 * g + 16] = q.quantize_dequantize(blk)
+        sc[:, g], zero[:, g] = q.quant_scale.reshape(-1), q.zero.reshape(-1)
+        qs[:, g], qz[:, g] = q.qq_scale.scale.reshape(-1), q.qq_scale.zero.reshape(-1)
+    out.update(w2_codes=codes.numpy().astype(np.uint8), w2_sc=sc.numpy().astype(np.uint8), w2_zero=zero.numpy(),
+               w2_qs=qs.numpy(), w2_qz=qz.numpy(), w2_wdeq=wq.half().numpy())
+    q = ref_quantizer.Quantizer()
+    q.configure(bits=4, perchannel=True, sym=False, qq_scale_bits=4)
+    q.find_params(Wf.clone(), weight=True)
+    out.update(w4_codes=q.quantize(Wf).numpy().astype(np.uint8),
+               w4_sc=q.quant_scale.reshape(-1, 1).numpy().astype(np.uint8), w4_zero=q.zero.reshape(-1, 1).numpy(),
+               w4_qs=q.qq_scale.scale.reshape(-1, 1).numpy(), w4_qz=q.qq_scale.zero.reshape(-1, 1).numpy(),
+               w4_wdeq=q.quantize_dequantize(Wf).half().numpy())
+    np.savez_compressed(os.path.join(OUT, "g8_uniform.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     g1_ptq_small(); print("G1 ok")
@@ -278,3 +312,4 @@ if __name__ == "__main__":
     g5_block_small(); print("G5 ok")
     g6_kat(); print("G6 ok")
     g7_act_quantizers(); print("G7 ok")
+    g8_uniform(); print("G8 ok")

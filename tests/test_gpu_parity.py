@@ -462,3 +462,36 @@ def test_g5_decoder_block_fwd_bwd(dev, g5):
     close(x.grad, g5["dx"], "dx")
     for n in names:
         close(lin[n].weight.grad, g5[f"grad_{n}.weight"], n)
+
+
+# ----------------------------------------------------------------------------------------
+# uniform W2 / W4 layouts (config-5 sweep arms)
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout,pre", [("w2g16", "w2"), ("w4row", "w4")])
+def test_g8_uniform_quantize_unpack_dequant(dev, layout, pre):
+    from mxq_amd import packing
+    from tests.conftest import load_golden
+    g8 = load_golden("g8_uniform.npz")
+    p = packing.quantize_pack_uniform(torch.from_numpy(g8["W"]).to(dev), layout)
+    w16, got = packing.expand_uniform(p)
+    for k in ("codes", "sc", "zero", "qs", "qz"):
+        assert np.array_equal(got[k].cpu().numpy(), g8[f"{pre}_{k}"]), k
+    assert np.array_equal(w16.cpu().numpy().view(np.uint16), g8[f"{pre}_wdeq"].view(np.uint16))
+
+
+@pytest.mark.parametrize("layout", ["w2g16", "w4row"])
+@pytest.mark.parametrize("M,N,K", [(300, 144, 192), (512, 256, 1024), (64, 4096, 4096)])
+def test_uniform_gemm_vs_oracle(dev, layout, M, N, K):
+    from mxq_amd import packing
+    g = torch.Generator().manual_seed(M + N + K)
+    W = (torch.randn(N, K, generator=g) * 0.02).half()
+    x = torch.randn(M, K, generator=g).half()
+    ref = O.uniform_quantize(W.numpy(), layout)
+    p = packing.quantize_pack_uniform(W.to(dev), layout)
+    w16, got = packing.expand_uniform(p)
+    assert np.array_equal(got["codes"].cpu().numpy(), ref["codes"])
+    w_ref16 = ref["w_deq32"].astype(np.float16)
+    assert np.array_equal(w16.cpu().numpy().view(np.uint16), w_ref16.view(np.uint16))
+    y = packing.linear_layout(x.to(dev), p).cpu().numpy()
+    _check_gemm(y, O.linear_ref(x.numpy(), w_ref16), f"{layout} {M}x{N}x{K}")
+    assert abs(p.bits_per_weight() - (4.5 if layout == "w2g16" else 4.0)) < 0.2

@@ -97,3 +97,14 @@ def test_g6_kat_proto_format(g6):
         full((sub // 4, 32), g6["zeros_2nd"], np.uint32),
         full((sub,), g6["scales_4b"], np.float16), full((sub // 8,), g6["zeros_4b"], np.uint32))
     assert np.all(y.astype(np.int32) == int(g6["expected"]))
+
+
+@pytest.mark.parametrize("layout,pre", [("w2g16", "w2"), ("w4row", "w4")])
+def test_g8_uniform_arms(layout, pre):
+    """Uniform W2 (group 16) / W4 (per row) arms of the config-5 sweep vs the reference's Quantizer."""
+    from tests.conftest import load_golden
+    g8 = load_golden("g8_uniform.npz")
+    p = O.uniform_quantize(g8["W"], layout)
+    for k in ("codes", "sc", "zero", "qs", "qz"):
+        assert np.array_equal(p[k], g8[f"{pre}_{k}"]), k
+    assert np.array_equal(p["w_deq32"].astype(np.float16).view(np.uint16), g8[f"{pre}_wdeq"].view(np.uint16))
