@@ -494,4 +494,5 @@ def test_uniform_gemm_vs_oracle(dev, layout, M, N, K):
     assert np.array_equal(w16.cpu().numpy().view(np.uint16), w_ref16.view(np.uint16))
     y = packing.linear_layout(x.to(dev), p).cpu().numpy()
     _check_gemm(y, O.linear_ref(x.numpy(), w_ref16), f"{layout} {M}x{N}x{K}")
-    assert abs(p.bits_per_weight() - (4.5 if layout == "w2g16" else 4.0)) < 0.2
+    if K >= 1024:   # rowmeta (16 B/row) is amortised over the row
+        assert abs(p.bits_per_weight() - (4.5 if layout == "w2g16" else 4.0)) < 0.2
