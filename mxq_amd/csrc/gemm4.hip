@@ -20,8 +20,7 @@
 //
 // One raw s_barrier per K-step joins all 12 waves; producers end a step with a counted
 // s_waitcnt vmcnt(10) so their newest DMAs stay in flight.  Tile 256 (M) x 128 (N), K-step 64,
-// LDS: x ring 3 x 32 KiB, packed ring 6 x 4.5 KiB, W16 2 x 16 KiB.  The producers' dequant is a
-// 3-step register pipeline (store W16(t+1), compute chunk t+2, read the operands of chunk t+3).  Hazards as gemm2 (every
+// LDS: x ring 3 x 32 KiB, packed ring 3 x 4.5 KiB, W16 2 x 16 KiB.  Hazards as gemm2 (every
 // wave passes the same barrier every step): DESIGN.md section 4.
 #include <hip/hip_runtime.h>
 
@@ -40,7 +39,7 @@ constexpr int BM = 256, BN = 128, BK = 64;
 constexpr int N_CONS = 8, N_PROD = 4, THREADS = (N_CONS + N_PROD) * 64;
 constexpr int A_STAGE = BM * BK * 2, A_SLOTS = 3;
 constexpr int BP_BLK = MXQ_BLK_BYTES;            // 576 B: stride of 144 dwords keeps blocks on distinct banks
-constexpr int BP_STAGE = (BN / 16) * BP_BLK, BP_SLOTS = 6;
+constexpr int BP_STAGE = (BN / 16) * BP_BLK, BP_SLOTS = 3;
 constexpr int W_STAGE = BN * BK * 2;
 constexpr int OFF_A = 0;
 constexpr int OFF_BP = OFF_A + A_SLOTS * A_STAGE;
@@ -185,78 +184,44 @@ __device__ __forceinline__ void issue_bp(const Prod& c, int t) {
     }
 }
 
-// Producer dequant, thread -> (W row d_row, quarter pair d_qp): chunk t's 32 weights of that row.
-// Split into load (packed words from the LDS copy of the block) / math (LUT + v_perm, registers
-// only) / store (4 x ds_write_b128 into W16[t & 1]) so that the three can be software-pipelined
-// over three K-steps: no LDS-read -> VALU -> LDS-write chain is left inside a step.
-struct DeqRaw {
-    uint32_t w[9];
-};
+// thread -> (W row d_row, quarter pair d_qp): chunk t's 32 weights of that row -> W16[t & 1]
 template <int LAYOUT>
-__device__ __forceinline__ DeqRaw deq_load(const Prod& c, int t) {
+__device__ __forceinline__ void dequant(const Prod& c, int t) {
     const uint32_t* blk = (const uint32_t*)(c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.d_blk * BP_BLK);
-    DeqRaw r = {};
+    uint32_t o[16];
     if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            r.w[2 * q] = blk[mxq_w4_c4(c.d_qp * 2 + q, 0, c.d_r)];
-            r.w[2 * q + 1] = blk[mxq_w4_c4(c.d_qp * 2 + q, 1, c.d_r)];
+            mxq_deq4x8(blk[mxq_w4_c4(c.d_qp * 2 + q, 0, c.d_r)], c.s4, c.z4, o + 8 * q);
+            mxq_deq4x8(blk[mxq_w4_c4(c.d_qp * 2 + q, 1, c.d_r)], c.s4, c.z4, o + 8 * q + 4);
         }
     } else if constexpr (LAYOUT == MXQ_LAYOUT_W2G16) {
-        r.w[8] = ((const uint16_t*)blk)[mxq_sc_u16(c.d_r)];
+        const uint32_t scw = ((const uint16_t*)blk)[mxq_sc_u16(c.d_r)];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int g = c.d_qp * 2 + q;
-            r.w[4 * q] = blk[mxq_w2_c2(g, c.d_r)];
-            r.w[4 * q + 1] = blk[mxq_w2_z2(g, c.d_r)];
-            r.w[4 * q + 2] = blk[mxq_qq(g)];
-            r.w[4 * q + 3] = blk[mxq_qq(g) + 1];
+            mxq_deq2x16(blk[mxq_w2_c2(g, c.d_r)],
+                        mxq_scale(__uint_as_float(blk[mxq_qq(g)]), __uint_as_float(blk[mxq_qq(g) + 1]),
+                                  (scw >> (4 * g)) & 15u),
+                        __uint_as_float(blk[mxq_w2_z2(g, c.d_r)]), o + 8 * q);
         }
     } else {
-        r.w[8] = ((const uint16_t*)blk)[mxq_sc_u16(c.d_r)];
-        const int g0 = c.d_qp == 0 ? 0 : 2;
-        r.w[0] = blk[mxq_c2(g0, c.d_r)];
-        r.w[1] = blk[mxq_z2(g0, c.d_r)];
-        r.w[2] = blk[mxq_qq(g0)];
-        r.w[3] = blk[mxq_qq(g0) + 1];
-        if (c.d_qp == 0) {
-            r.w[4] = blk[mxq_c2(1, c.d_r)];
-            r.w[5] = blk[mxq_z2(1, c.d_r)];
-            r.w[6] = blk[mxq_qq(1)];
-            r.w[7] = blk[mxq_qq(1) + 1];
-        } else {
-            r.w[4] = blk[mxq_c4(0, c.d_r)];
-            r.w[5] = blk[mxq_c4(1, c.d_r)];
-        }
-    }
-    return r;
-}
-template <int LAYOUT>
-__device__ __forceinline__ void deq_math(const Prod& c, const DeqRaw& r, uint32_t (&o)[16]) {
-    if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mxq_deq4x8(r.w[q], c.s4, c.z4, o + 4 * q);
-    } else if constexpr (LAYOUT == MXQ_LAYOUT_W2G16) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            mxq_deq2x16(r.w[4 * q],
-                        mxq_scale(__uint_as_float(r.w[4 * q + 2]), __uint_as_float(r.w[4 * q + 3]),
-                                  (r.w[8] >> (4 * (c.d_qp * 2 + q))) & 15u),
-                        __uint_as_float(r.w[4 * q + 1]), o + 8 * q);
+    const uint32_t scw = ((const uint16_t*)blk)[mxq_sc_u16(c.d_r)];
+    if (c.d_qp == 0) {
+        mxq_deq2x16(blk[mxq_c2(0, c.d_r)],
+                    mxq_scale(__uint_as_float(blk[mxq_qq(0)]), __uint_as_float(blk[mxq_qq(0) + 1]), scw & 15u),
+                    __uint_as_float(blk[mxq_z2(0, c.d_r)]), o);
+        mxq_deq2x16(blk[mxq_c2(1, c.d_r)],
+                    mxq_scale(__uint_as_float(blk[mxq_qq(1)]), __uint_as_float(blk[mxq_qq(1) + 1]), (scw >> 4) & 15u),
+                    __uint_as_float(blk[mxq_z2(1, c.d_r)]), o + 8);
     } else {
-        const int g0 = c.d_qp == 0 ? 0 : 2;
-        mxq_deq2x16(r.w[0], mxq_scale(__uint_as_float(r.w[2]), __uint_as_float(r.w[3]), (r.w[8] >> (4 * g0)) & 15u),
-                    __uint_as_float(r.w[1]), o);
-        if (c.d_qp == 0) {
-            mxq_deq2x16(r.w[4], mxq_scale(__uint_as_float(r.w[6]), __uint_as_float(r.w[7]), (r.w[8] >> 4) & 15u),
-                        __uint_as_float(r.w[5]), o + 8);
-        } else {
-            mxq_deq4x8(r.w[4], c.s4, c.z4, o + 8);
-            mxq_deq4x8(r.w[5], c.s4, c.z4, o + 12);
-        }
+        mxq_deq2x16(blk[mxq_c2(2, c.d_r)],
+                    mxq_scale(__uint_as_float(blk[mxq_qq(2)]), __uint_as_float(blk[mxq_qq(2) + 1]), (scw >> 8) & 15u),
+                    __uint_as_float(blk[mxq_z2(2, c.d_r)]), o);
+        mxq_deq4x8(blk[mxq_c4(0, c.d_r)], c.s4, c.z4, o + 8);
+        mxq_deq4x8(blk[mxq_c4(1, c.d_r)], c.s4, c.z4, o + 12);
     }
-}
-__device__ __forceinline__ void deq_store(const Prod& c, int t, const uint32_t (&o)[16]) {
+    }
     char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -265,42 +230,28 @@ __device__ __forceinline__ void deq_store(const Prod& c, int t, const uint32_t (
 
 template <int ABL, int LAYOUT>
 __device__ __forceinline__ void producer(const Prod& c) {
-    // prologue: x tiles 0,1; packed blocks 0..4; W16(0); pipeline state: o = chunk 1, raw = chunk 2
+    // prologue: x tiles 0,1; packed blocks 0..2; W16(0)
     for (int t = 0; t < 2 && t < c.NT; ++t) issue_a(c, t);
-    for (int t = 0; t < 5 && t < c.NT; ++t) issue_bp<LAYOUT>(c, t);
+    for (int t = 0; t < 3 && t < c.NT; ++t) issue_bp<LAYOUT>(c, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    uint32_t o[16] = {};
-    DeqRaw raw = deq_load<LAYOUT>(c, 0);
-    deq_math<LAYOUT>(c, raw, o);
-    deq_store(c, 0, o);
-    if (c.NT > 1) {
-        raw = deq_load<LAYOUT>(c, 1);
-        deq_math<LAYOUT>(c, raw, o);
-    }
-    if (c.NT > 2) raw = deq_load<LAYOUT>(c, 2);
+    dequant<LAYOUT>(c, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     int t = 0;
-    for (; t + 5 < c.NT; ++t) {   // steady state: everything unconditional, one straight-line block
-        if constexpr (!(ABL & 4)) deq_store(c, t + 1, o);           // computed in step t-1
+    for (; t + 3 < c.NT; ++t) {   // steady state: everything unconditional
         if constexpr (!(ABL & 1)) issue_a(c, t + 2);
-        issue_bp<LAYOUT>(c, t + 5);
-        if constexpr (!(ABL & 4)) {
-            deq_math<LAYOUT>(c, raw, o);                              // chunk t+2 (operands read in step t-1)
-            raw = deq_load<LAYOUT>(c, t + 3);
-        }
+        issue_bp<LAYOUT>(c, t + 3);
+        if constexpr (!(ABL & 4)) dequant<LAYOUT>(c, t + 1);
         if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // this step's 10 DMAs stay in flight
         __builtin_amdgcn_s_barrier();
     }
     for (; t < c.NT; ++t) {
-        if (t + 1 < c.NT) deq_store(c, t + 1, o);
         if (t + 2 < c.NT) issue_a(c, t + 2);
-        if (t + 5 < c.NT) issue_bp<LAYOUT>(c, t + 5);
-        if (t + 2 < c.NT) deq_math<LAYOUT>(c, raw, o);
-        if (t + 3 < c.NT) raw = deq_load<LAYOUT>(c, t + 3);
+        if (t + 3 < c.NT) issue_bp<LAYOUT>(c, t + 3);
+        if (t + 1 < c.NT) dequant<LAYOUT>(c, t + 1);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
