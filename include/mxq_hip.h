@@ -94,7 +94,8 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
 /* mxq_gemm_f16 with an explicit kernel variant, for A/B benchmarking and tests:
  * 0 = auto, 1 = 128x128 two-stage kernel, 2 = 256x128 LDS-DMA-pipelined kernel,
  * 3 = 256x128 ping-pong kernel (two wave groups alternate MFMA and memory slots),
- * 4 = 256x128 wave-specialised kernel (8 MFMA waves + 4 DMA/dequant waves).
+ * 4 = 256x128 wave-specialised kernel (8 MFMA waves + 4 DMA/dequant waves),
+ * 5 = variant 4 with the 2-bit dequant moved to the MFMA waves.
  * Values 16..31 select profiling-only ablation builds of variant 2 (wrong results). */
 int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* stream);

@@ -85,9 +85,12 @@ int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, voi
         case 2: return mxq_launch_gemm2_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
         case 3: return mxq_launch_gemm3_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
         case 4: return mxq_launch_gemm4_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+        case 5: return mxq_launch_gemm5_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
     }
     if (variant >= 16 && variant < 32)   // profiling-only ablation builds of variant 2 (wrong results)
         return mxq_launch_gemm2_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 16, (hipStream_t)stream);
+    if (variant >= 48 && variant < 64)   // profiling-only ablation builds of variant 5 (wrong results)
+        return mxq_launch_gemm5_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 48, (hipStream_t)stream);
     if (variant >= 32 && variant < 48)   // profiling-only ablation builds of variant 4 (wrong results)
         return mxq_launch_gemm4_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 32, (hipStream_t)stream);
     return MXQ_E_SHAPE;

@@ -133,7 +133,7 @@ def _packed_case(dev, N, K, seed):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (128, 256, 512), (200, 192, 320), (5, 64, 128), (77, 16, 704),
                                    (256, 4096, 1024), (300, 144, 192), (512, 128, 128)])
-@pytest.mark.parametrize("path", ["gemm", "gemm1", "gemm2", "gemm3", "gemm4"])
+@pytest.mark.parametrize("path", ["gemm", "gemm1", "gemm2", "gemm3", "gemm4", "gemm5"])
 def test_gemm_vs_oracle(dev, M, N, K, path):
     """Ragged M (200, 5, 77), N below / not a multiple of the tile, ragged K; both kernel
     variants (128x128 two-stage, 256x128 LDS-DMA pipelined) and the automatic choice."""
@@ -162,7 +162,7 @@ def test_gemm_integer_exact_layout(dev):
     pk = packing.pack_codes(_to_dev(p, dev), N, K)
     yref = x.astype(np.float32) @ w.T
     assert np.abs(yref).max() < 2048
-    for path, rows in (("gemm1", M), ("gemm2", M), ("gemm3", M), ("gemm4", M), ("gemv", 3)):
+    for path, rows in (("gemm1", M), ("gemm2", M), ("gemm3", M), ("gemm4", M), ("gemm5", M), ("gemv", 3)):
         y = packing.linear(torch.from_numpy(x[:rows]).to(dev), pk, path=path).cpu().numpy().astype(np.float32)
         assert np.array_equal(y, yref[:rows]), path
 
