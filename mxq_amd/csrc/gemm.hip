@@ -204,8 +204,9 @@ __global__ __launch_bounds__(256, 2) void mxq_gemm_f16_kernel(const uint16_t* __
 int mxq_launch_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream) {
     // tokens <= 128 fit one 128-row tile; beyond that the 256 x 128 wave-specialised kernel wins
-    // (round-1 A/B on the Llama shapes at M = 2048: gemm1 750-890, gemm2 830-1000, gemm4 890-1040 TFLOP/s)
-    if (M > 128) return mxq_launch_gemm4_f16(x, qweight, rowmeta, y, M, N, K, stream);
+    // (round-1 A/B on the Llama shapes at M = 2048: gemm1 750-890, gemm2 830-1000, gemm4 890-1040,
+    // gemm5 930-1030 TFLOP/s)
+    if (M > 128) return mxq_launch_gemm5_f16(x, qweight, rowmeta, y, M, N, K, stream);
     return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, stream);
 }
 

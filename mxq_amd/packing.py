@@ -270,6 +270,8 @@ def expand_uniform(p: PackedUniform, codes: bool = True):
 def linear_layout(x: torch.Tensor, p, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """MFMA dequant-GEMM on a PackedMXQ (mixed) or PackedUniform weight, any token count."""
     layout = LAYOUTS[getattr(p, "layout", "mixed")]
+    if layout == 0:
+        return linear(x, p, out=out, path="gemm")      # the mixed layout's default (fastest) kernel
     _need_gpu(x, p.qweight)
     if x.dtype != torch.float16 or x.shape[-1] != p.K:
         raise ValueError("activations must be fp16 [..., in_features]")
