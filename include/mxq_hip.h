@@ -100,6 +100,24 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
 int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* stream);
 
+/* The same Linear with a caller-owned scratch buffer, which lets the prefill GEMM balance launches
+ * whose tile count is not a multiple of the CU count (stream-K tail, csrc/gemm6.hip): e.g. 512 tokens
+ * x 4096^2 is 64 tiles, a quarter of the 256 CUs, unless every CU takes a quarter of a tile's K range.
+ * `workspace` is device memory of at least mxq_gemm_workspace_bytes() bytes, 16-byte aligned, whose
+ * first 64 KiB the caller zeroes ONCE (hipMemset) before first use; the kernels leave it zeroed, so
+ * it can be reused by every later launch on the SAME stream (launches on different streams need
+ * different workspaces).  workspace == NULL selects the workspace-free schedule of mxq_linear_f16.
+ * The tail is only split where that pays (about 24 idle K-steps per CU; it does for 128 < M <= 1024 on
+ * the Llama shapes, not for gate/up at M = 2048).
+ * mxq_gemm_f16_ws: variant 0 = default dispatch, 6 = the stream-K kernel at any M, 7 = the same but
+ * splitting whenever it is structurally possible (tests), 1..5 as in mxq_gemm_f16_ex (workspace ignored).  Results of every variant agree to fp32-summation-order
+ * rounding and are run-to-run deterministic. */
+size_t mxq_gemm_workspace_bytes(void);
+int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                    int variant, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Uniform-bit-width layouts for the W2A16 / W4A16 / mixed sweep (BASELINE config 5); the mixed
  * layout is layout 0.  1 = W2G16: Quantizer(bits=2, qq_scale_bits=4) on every 16-column group
  * (quantizer.py:61-147), 4.5 bit/weight; 2 = W4ROW: Quantizer(bits=4, qq_scale_bits=4) per row

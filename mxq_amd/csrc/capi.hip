@@ -163,6 +163,36 @@ int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void
     return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
 }
 
+size_t mxq_gemm_workspace_bytes(void) { return mxq_gemm6_workspace_bytes(); }
+
+static int gemm_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                   void* workspace, size_t ws_bytes, hipStream_t stream) {
+    // with a workspace the wave-specialised kernel wins at every token count (its stream-K split keeps all
+    // CUs busy when there are few tiles: 64 tokens x 4096^2 34 us vs 57 us for the 128-row-tile kernel);
+    // without one, mxq_linear_f16's dispatch
+    if (!workspace) return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, stream);
+    return mxq_launch_gemm6_f16(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
+}
+
+int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
+    if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+    return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                    int variant, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
+    if (variant == 0) return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
+    if (variant == 6 || variant == 7)
+        return mxq_launch_gemm6_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 7,
+                                    (hipStream_t)stream);
+    return mxq_gemm_f16_ex(x, qweight, rowmeta, y, M, N, K, variant, stream);
+}
+
 int mxq_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype, void* stream) {
     if (!w || !out) return MXQ_E_NULL;
     if (rows <= 0 || cols <= 0 || cols % 64 != 0 || num_bits < 1 || num_bits > 31) return MXQ_E_SHAPE;

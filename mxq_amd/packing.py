@@ -29,6 +29,25 @@ def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+_WORKSPACES: Dict[tuple, torch.Tensor] = {}
+
+
+def gemm_workspace(device: torch.device) -> torch.Tensor:
+    """Scratch buffer of the stream-K prefill GEMM (include/mxq_hip.h: mxq_linear_f16_ws), one per
+    (device, stream): launches on one stream run in order and may share it, launches on different
+    streams may not.  Zeroed once here; the kernels leave its counters zeroed."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("run one prefill-sized mxq_amd.linear() on this stream before capturing a graph "
+                               "(the GEMM workspace cannot be allocated during capture)")
+        nbytes = _lib.load().mxq_gemm_workspace_bytes()
+        ws = _WORKSPACES[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
 def _need_gpu(*ts: torch.Tensor):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -150,7 +169,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
     """y = x @ dequant(p).T for x [..., K] fp16 -> [..., N] fp16 (fp32 accumulation).
 
     path: "auto" (GEMV kernel for <= 4 tokens, MFMA GEMM otherwise), "gemm", "gemv", or an
-    explicit GEMM kernel variant "gemm1" (128x128) / "gemm2" (256x128 pipelined)."""
+    explicit GEMM kernel variant "gemm1" (128x128) .. "gemm6" (wave-specialised + stream-K tail)."""
     _need_gpu(x, p.qweight)
     if x.dtype != torch.float16:
         raise ValueError(f"activations must be float16 (W2/4 x A16), got {x.dtype}")
@@ -169,11 +188,19 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
     lib = _lib.load()
     args = (x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K)
     with torch.cuda.device(x.device):
-        if path.startswith("gemm") and path[4:].isdigit():      # explicit kernel variant (benchmarks / tests)
-            rc = lib.mxq_gemm_f16_ex(*args, int(path[4:]), _stream(x2))
+        if path == "gemv":
+            rc = lib.mxq_gemv_f16(*args, _stream(x2))
+        elif path == "auto" and M <= 4:                          # GEMV: no workspace involved
+            rc = lib.mxq_linear_f16(*args, _stream(x2))
         else:
-            fn = {"auto": lib.mxq_linear_f16, "gemm": lib.mxq_gemm_f16, "gemv": lib.mxq_gemv_f16}[path]
-            rc = fn(*args, _stream(x2))
+            ws = gemm_workspace(x2.device) if path in ("auto", "gemm", "gemm6", "gemm7") else None
+            wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
+            if path == "auto":
+                rc = lib.mxq_linear_f16_ws(*args, wsp, wsn, _stream(x2))
+            elif path == "gemm" or (path[4:].isdigit() and path.startswith("gemm")):
+                rc = lib.mxq_gemm_f16_ws(*args, int(path[4:] or 0), wsp, wsn, _stream(x2))
+            else:
+                raise ValueError(f"unknown path {path!r}")
         _lib.check(rc, f"mxq_linear_f16[{path}]")
     return out.reshape(*x.shape[:-1], p.N)
 

@@ -46,7 +46,7 @@ def test_gemm2_main_loop_keeps_dma_in_flight():
         assert sum("global_load_lds_dwordx4" in l for l in step) == 5
 
 
-@pytest.mark.parametrize("src", ["gemm.hip", "gemm2.hip", "gemv.hip", "fakequant.hip", "pack.hip"])
+@pytest.mark.parametrize("src", ["gemm.hip", "gemm2.hip", "gemm5.hip", "gemm6.hip", "gemv.hip", "fakequant.hip", "pack.hip"])
 def test_no_spills_no_scratch(src):
     s = _asm(src)
     for m in re.finditer(r"\.vgpr_spill_count:\s+(\d+)", s):

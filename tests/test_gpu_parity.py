@@ -133,7 +133,7 @@ def _packed_case(dev, N, K, seed):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (128, 256, 512), (200, 192, 320), (5, 64, 128), (77, 16, 704),
                                    (256, 4096, 1024), (300, 144, 192), (512, 128, 128)])
-@pytest.mark.parametrize("path", ["gemm", "gemm1", "gemm2", "gemm3", "gemm4", "gemm5"])
+@pytest.mark.parametrize("path", ["gemm", "gemm1", "gemm2", "gemm3", "gemm4", "gemm5", "gemm6"])
 def test_gemm_vs_oracle(dev, M, N, K, path):
     """Ragged M (200, 5, 77), N below / not a multiple of the tile, ragged K; both kernel
     variants (128x128 two-stage, 256x128 LDS-DMA pipelined) and the automatic choice."""
@@ -162,9 +162,38 @@ def test_gemm_integer_exact_layout(dev):
     pk = packing.pack_codes(_to_dev(p, dev), N, K)
     yref = x.astype(np.float32) @ w.T
     assert np.abs(yref).max() < 2048
-    for path, rows in (("gemm1", M), ("gemm2", M), ("gemm3", M), ("gemm4", M), ("gemm5", M), ("gemv", 3)):
+    for path, rows in (("gemm1", M), ("gemm2", M), ("gemm3", M), ("gemm4", M), ("gemm5", M), ("gemm6", M), ("gemv", 3)):
         y = packing.linear(torch.from_numpy(x[:rows]).to(dev), pk, path=path).cpu().numpy().astype(np.float32)
         assert np.array_equal(y, yref[:rows]), path
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 2048, 4096),     # 16 tiles < 256 CUs: every K-step is stream-K, 16 contributors per tile
+                                   (300, 2048, 4096),     # ragged M edge in the partial slots
+                                   (512, 1024, 8192),     # units straddle two tiles
+                                   (1024, 4224, 2048),    # 132 tiles: XCDs 0-3 hold 17 tail tiles, 4-7 hold 16
+                                   (100, 1152, 8192),     # 9 tiles: XCD 0 holds two, the others one; half-empty 256-row tile
+                                   (2048, 5120, 1024)])   # 320 tiles = one full round + a 64-tile tail
+def test_gemm_stream_k_tail(dev, M, N, K):
+    """csrc/gemm6.hip: tiles beyond the last full round of CUs are split along K over all CUs and
+    reduced through the workspace.  Checks (1) against the oracle matmul, (2) that the workspace
+    counters are left zeroed, (3) run-to-run bit-determinism, (4) agreement with the workspace-free
+    kernel (gemm5) to summation-order rounding."""
+    from mxq_amd import packing
+    p, w16, g = _packed_case(dev, N, K, M + N + K)
+    x = torch.randn(M, K, generator=g).half()
+    xd = x.to(dev)
+    y = packing.linear(xd, p, path="gemm7")
+    _check_gemm(y.cpu().numpy(), O.linear_ref(x.numpy(), w16), f"gemm7 {M}x{N}x{K}")
+    ws = packing.gemm_workspace(xd.device)
+    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
+    for _ in range(3):
+        assert torch.equal(packing.linear(xd, p, path="gemm7"), y)
+    y5 = packing.linear(xd, p, path="gemm5")
+    assert ((y.float() - y5.float()).abs().max() / y5.float().abs().max()).item() <= 1e-3
+    # the default dispatch is the same kernel, splitting only where it pays: equal up to summation order
+    yd = packing.linear(xd, p, path="gemm")
+    assert ((y.float() - yd.float()).abs().max() / y5.float().abs().max()).item() <= 1e-3
+    assert torch.equal(packing.linear(xd, p, path="gemm6"), yd)
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 4])

@@ -20,10 +20,11 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--variants", default="gemm1,gemm2,gemm3")
+    ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008", help="NxK list")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     variants = args.variants.split(",")
-    shapes = [(4096, 4096), (11008, 4096), (4096, 11008)]
+    shapes = [tuple(int(v) for v in s.split("x")) for s in args.shapes.split(",")]
     M = args.m
     for N, K in shapes:
         g = torch.Generator(device=dev).manual_seed(N + K)
