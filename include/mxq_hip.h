@@ -161,6 +161,25 @@ int mxq_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits
 int mxq_fakequant_bwd(const void* grad_out, const void* w, void* grad_in, int64_t n, float lo, float hi, int dtype,
                       void* stream);
 
+/* SymQuantizer.forward (symmetric = 1; utils_quant.py:31-86) and AsymQuantizer.forward (symmetric = 0;
+ * utils_quant.py:105-182): the dynamic-range fake quantisers of activations / KV cache
+ * (utils_quant.py:716-724, modeling_llama_quant.py:323-329), bit-identical in fp32 / bf16 / fp16.
+ *   symmetric : s = (2^(bits-1) - 1) * (1 / (max|x| + 1e-6));  out = round(x * s) / (s + 1e-6)
+ *   asymmetric: e = (max - min) + 1e-8;  out = round((x - min) / e * L) / L * e + min,  L = 2^bits - 1
+ * mxq_actquant_group_fwd: x[rows, cols], one range per `group` consecutive columns (the reference's
+ *   2-D branch: group 128 symmetric, 8 asymmetric); columns beyond the last whole group get range 0,
+ *   as the reference leaves them.  cols % 8 == 0 (% 4 for fp32); group / (8 or 4) a power of two <= 32.
+ * mxq_actquant_fwd: x is n_seg contiguous segments of seg_len elements, one range per segment
+ *   (a token row of a 3-D activation, a (batch, head) slab of a 4-D tensor, the whole tensor for
+ *   layerwise = True); segment i is ranged iff i % period < live, the others get range 0 (3-D inputs:
+ *   the reference slices tokens by a group count taken from the hidden size).  seg_len % 8 == 0
+ *   (% 4 for fp32).  range_ws: 8 * n_seg bytes of device scratch (overwritten).
+ * The backward of both is mxq_fakequant_bwd (same straight-through clip, utils_quant.py:88-102). */
+int mxq_actquant_group_fwd(const void* x, void* out, int64_t rows, int cols, int group, int num_bits, int symmetric,
+                           int dtype, void* stream);
+int mxq_actquant_fwd(const void* x, void* out, void* range_ws, int64_t n_seg, int64_t seg_len, int64_t period,
+                     int64_t live, int num_bits, int symmetric, int dtype, void* stream);
+
 /* gemv_forward_cuda(in_feats, kernel, scaling_factors, zeros, group_size)
  * (gemv_cuda.h:4-9; operand layout gemv_cuda.cu:45-59): x f16[B, IC], kernel i32[OC, IC/8],
  * scales f16[OC, sf_w], zeros i32[OC, zeros_w], group_size in {32, 64, 128}; y f16[B, OC]. */

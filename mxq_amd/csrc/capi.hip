@@ -201,6 +201,33 @@ int mxq_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits
     return mxq_launch_fakequant_fwd(w, out, rows, cols, num_bits, dtype, (hipStream_t)stream);
 }
 
+int mxq_actquant_group_fwd(const void* x, void* out, int64_t rows, int cols, int group, int num_bits, int symmetric,
+                           int dtype, void* stream) {
+    if (!x || !out) return MXQ_E_NULL;
+    if (!dtype_ok(dtype)) return MXQ_E_DTYPE;
+    const int vec = dtype == MXQ_DTYPE_F32 ? 4 : 8;
+    const int lpg = group > 0 && group % vec == 0 ? group / vec : 0;
+    if (rows <= 0 || cols <= 0 || cols % vec != 0 || lpg == 0 || lpg > 32 || (lpg & (lpg - 1)) != 0 || num_bits < 1 ||
+        num_bits > 31 || rows * (int64_t)(cols / vec + lpg) >= ((int64_t)1 << 39))
+        return MXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(out)) return MXQ_E_ALIGN;
+    return mxq_launch_actquant_group(x, out, rows, cols, group, num_bits, symmetric, dtype, (hipStream_t)stream);
+}
+
+int mxq_actquant_fwd(const void* x, void* out, void* range_ws, int64_t n_seg, int64_t seg_len, int64_t period,
+                     int64_t live, int num_bits, int symmetric, int dtype, void* stream) {
+    if (!x || !out || !range_ws) return MXQ_E_NULL;
+    if (!dtype_ok(dtype)) return MXQ_E_DTYPE;
+    const int vec = dtype == MXQ_DTYPE_F32 ? 4 : 8;
+    if (n_seg <= 0 || seg_len <= 0 || seg_len % vec != 0 || period <= 0 || live < 0 || num_bits < 1 || num_bits > 31)
+        return MXQ_E_SHAPE;
+    const int64_t per_chunk = (int64_t)256 * vec * 4;
+    if (n_seg * ((seg_len + per_chunk - 1) / per_chunk) >= ((int64_t)1 << 31)) return MXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(out) || ((uintptr_t)range_ws & 7)) return MXQ_E_ALIGN;
+    return mxq_launch_actquant_seg(x, out, range_ws, n_seg, seg_len, period, live, num_bits, symmetric, dtype,
+                                   (hipStream_t)stream);
+}
+
 int mxq_fakequant_bwd(const void* grad_out, const void* w, void* grad_in, int64_t n, float lo, float hi, int dtype,
                       void* stream) {
     if (!grad_out || !w || !grad_in) return MXQ_E_NULL;

@@ -17,81 +17,12 @@
 #include <math.h>
 #include <string.h>
 
+#include "mxq_fq_types.h"
 #include "mxq_kernels.h"
 
 namespace {
 
-struct F32 {
-    static constexpr int VEC = 4;
-    __device__ static __forceinline__ float rnd(float x) { return x; }
-    __device__ static __forceinline__ bool near_boundary(float) { return true; }
-    static constexpr bool HAS_FAST_DIV = false;   // fp32 results are not re-rounded: always the IEEE divide
-    __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const float*)p + e); }
-    __device__ static __forceinline__ void unpack(const uint4 a, float v[4]) {
-        v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.y); v[2] = __uint_as_float(a.z); v[3] = __uint_as_float(a.w);
-    }
-    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[4]) { unpack(load_raw(p, e), v); }
-    __device__ static __forceinline__ void store(void* p, int64_t e, const float v[4]) {
-        *(float4*)((float*)p + e) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-};
-
-struct BF16 {
-    static constexpr int VEC = 8;
-    // round-to-nearest-even to 8 significant bits: the plain cast compiles to
-    // v_cvt_pk_bf16_f32 on gfx950 and keeps NaNs (MI355X_MICROARCH.md, correctness boundaries)
-    __device__ static __forceinline__ float rnd(float x) { return (float)(__bf16)x; }
-    // fast-division screen: fl32(x * rcp(e)) rounds to the same bf16 as the correctly rounded
-    // fl32(x / e) unless it lies within a few fp32 ulps of a bf16 rounding boundary
-    // (no range test needed: e = bf16(alpha + 1e-8) is a positive normal number, bf16 has fp32's
-    // exponent range, and for inf / NaN inputs product and quotient agree.)
-    __device__ static __forceinline__ bool near_boundary(float a) {
-        return ((__float_as_uint(a) + 0x8004u) & 0xFFF8u) == 0u;   // low 16 bits in [0x7FFC, 0x8003]
-    }
-    static constexpr bool HAS_FAST_DIV = true;
-    __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const uint16_t*)p + e); }
-    __device__ static __forceinline__ void unpack(const uint4 a, float v[8]) {
-        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __uint_as_float(w[i] << 16);
-            v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
-        }
-    }
-    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) { unpack(load_raw(p, e), v); }
-    __device__ static __forceinline__ void store(void* p, int64_t e, const float v[8]) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            w[i] = (__float_as_uint(v[2 * i]) >> 16) | (__float_as_uint(v[2 * i + 1]) & 0xFFFF0000u);
-        *(uint4*)((uint16_t*)p + e) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-};
-
-struct F16 {
-    static constexpr int VEC = 8;
-    __device__ static __forceinline__ float rnd(float x) { return (float)(_Float16)x; }
-    __device__ static __forceinline__ bool near_boundary(float a) {   // 11 significant bits; no shortcut in the
-        const uint32_t u = __float_as_uint(a);                          // fp16-subnormal range
-        return ((u & 0x1FFFu) - 0x0FFCu) < 8u || !(a == 0.0f || (a > 6.2e-5f && a < 6.0e4f));
-    }
-    static constexpr bool HAS_FAST_DIV = true;
-    __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const uint16_t*)p + e); }
-    __device__ static __forceinline__ void unpack(const uint4 r, float v[8]) {
-        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-        const h8 a = __builtin_bit_cast(h8, r);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
-    }
-    __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) { unpack(load_raw(p, e), v); }
-    __device__ static __forceinline__ void store(void* p, int64_t e, const float v[8]) {
-        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-        h8 a;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = (_Float16)v[i];
-        *(h8*)((uint16_t*)p + e) = a;
-    }
-};
+using namespace mxq_fq;
 
 // Shared per-group math of pass 2: v[] (VEC values of one lane) -> o[].  mn/mx are the group
 // min/max (already reduced over the lanes of the group).

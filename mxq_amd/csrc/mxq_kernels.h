@@ -59,6 +59,10 @@ int mxq_launch_fakequant_fwd(const void* w, void* out, int rows, int cols, int n
                              hipStream_t stream);
 int mxq_launch_fakequant_bwd(const void* grad_out, const void* w, void* grad_in, int64_t n, float lo, float hi,
                              int dtype, hipStream_t stream);
+int mxq_launch_actquant_group(const void* x, void* out, int64_t rows, int cols, int group, int num_bits, int symmetric,
+                              int dtype, hipStream_t stream);
+int mxq_launch_actquant_seg(const void* x, void* out, void* range_ws, int64_t n_seg, int64_t seg_len, int64_t period,
+                            int64_t live, int num_bits, int symmetric, int dtype, hipStream_t stream);
 int mxq_launch_gemv_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y,
                             int B, int IC, int OC, int group_size, hipStream_t stream);
 int mxq_launch_gemv_proto_f16(const void* x, const void* weight, const void* weight_last,

@@ -9,9 +9,9 @@
 * ``QuantizeLinear`` (utils_quant.py:601-727) -- same constructor, same ``state_dict``
   (``weight`` only), fake-quant weight then ``F.linear``.
 * ``SymQuantizer`` / ``AsymQuantizer`` (utils_quant.py:31-199) -- activation / KV
-  fake-quant; outside the hot path, kept as vectorised torch so the
-  reference's model file imports and runs; the README recipe (a_bits = kv_bits = 32)
-  never calls them.
+  fake-quant: HIP kernels (csrc/actquant.hip), bit-identical to the
+  reference in fp32 / bf16 / fp16 including its slicing quirks; the README recipe
+  (a_bits = kv_bits = 32) never calls them, ``kv_bits = 16`` runs do.
 """
 from __future__ import annotations
 
@@ -83,93 +83,85 @@ class MXAsymQuantizer(torch.autograd.Function):
         return ste_clip_backward(grad_output, input, lo, hi), None, None, None
 
 
-def _ste_clip_torch(grad_output, input, clip_val):
-    g = grad_output.clone()
-    g[input.ge(clip_val[1])] = 0
-    g[input.le(clip_val[0])] = 0
-    return g
+def _act_geometry(input, groupsize):
+    """How the reference's non-layerwise branches range a tensor (utils_quant.py:52-82, 129-179), as the
+    geometry the kernels take: ("group", rows, cols) for 2-D inputs, else ("seg", n_seg, seg_len, period,
+    live).  3-D inputs: the reference slices ``input[:, i1:i2]`` -- dimension 1, the tokens -- with a group
+    count derived from the LAST dimension, and takes the max over the last dimension: every token below
+    ``min(S, (H // groupsize) * groupsize)`` gets its own range over H, the tokens beyond get range 0."""
+    if input.dim() == 2:
+        return ("group", input.shape[0], input.shape[1])
+    if input.dim() == 3:
+        B, S, H = input.shape
+        return ("seg", B * S, H, S, min(S, (H // groupsize) * groupsize))
+    if input.dim() == 4:
+        return ("seg", input.shape[0] * input.shape[1], input.shape[2] * input.shape[3], 1, 1)
+    if input.dim() < 2:
+        raise IndexError("too many indices for tensor of dimension 1")      # what input[:, i1:i2] raises upstream
+    raise ValueError
 
 
-def _dim1_groups(input, groupsize):
-    """The reference's activation quantisers slice ``input[:, i1:i2]`` -- dimension 1 --
-    with a group count derived from the LAST dimension (utils_quant.py:57-66, 134-147).
-    Returns (group id per index of dim 1, number of covered indices)."""
-    n_groups = input.shape[-1] // groupsize
-    covered = min(input.shape[1], n_groups * groupsize)
-    return n_groups, covered
+def act_fake_quant(input: torch.Tensor, num_bits: int, layerwise: bool, symmetric: bool) -> torch.Tensor:
+    """SymQuantizer / AsymQuantizer forward arithmetic (HIP kernels, csrc/actquant.hip)."""
+    if not input.is_cuda:
+        raise ValueError("SymQuantizer / AsymQuantizer run on the GPU only (no CPU fallback): got a CPU tensor")
+    if input.dtype not in _CODE:
+        raise ValueError(f"unsupported dtype {input.dtype}")
+    x = input.contiguous()
+    out = torch.empty_like(x)
+    if x.numel() == 0:
+        return out
+    vec = 4 if x.dtype == torch.float32 else 8
+    groupsize = 128 if symmetric else 8
+    geo = ("seg", 1, x.numel(), 1, 1) if layerwise else _act_geometry(x, groupsize)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        if geo[0] == "group":
+            _, rows, cols = geo
+            if cols % vec != 0:
+                raise ValueError(f"the HIP fake quantiser needs the last dimension to be a multiple of {vec}, got {cols}")
+            _lib.check(lib.mxq_actquant_group_fwd(x.data_ptr(), out.data_ptr(), rows, cols, groupsize, int(num_bits),
+                                                  int(symmetric), _CODE[x.dtype], _stream(x)), "mxq_actquant_group_fwd")
+        else:
+            _, n_seg, seg_len, period, live = geo
+            if seg_len % vec != 0:
+                raise ValueError(f"the HIP fake quantiser needs segments of a multiple of {vec} elements, got {seg_len}")
+            ws = torch.empty(2 * n_seg, dtype=torch.int32, device=x.device)
+            _lib.check(lib.mxq_actquant_fwd(x.data_ptr(), out.data_ptr(), ws.data_ptr(), n_seg, seg_len, period, live,
+                                            int(num_bits), int(symmetric), _CODE[x.dtype], _stream(x)), "mxq_actquant_fwd")
+    return out
 
 
 class SymQuantizer(torch.autograd.Function):
-    """Symmetric group-128 fake quantiser for activations / KV (utils_quant.py:31-102)."""
+    """Symmetric dynamic-range fake quantiser for activations / KV (utils_quant.py:31-102): group 128
+    on 2-D inputs, per token on 3-D, per (batch, head) on 4-D, whole tensor when ``layerwise``."""
 
     @staticmethod
     def forward(ctx, input, clip_val, num_bits, layerwise):
-        ctx.save_for_backward(input, clip_val)
-        if layerwise:
-            max_input = input.abs().max().expand_as(input)
-        elif input.dim() <= 3:
-            _, covered = _dim1_groups(input, 128)
-            max_input = torch.zeros_like(input)
-            if covered > 0:
-                head = input[:, :covered].abs()
-                if input.dim() == 2:     # groups of 128 columns, per row
-                    g = head.reshape(input.shape[0], covered // 128, 128).amax(dim=-1, keepdim=True)
-                    max_input[:, :covered] = g.expand(-1, -1, 128).reshape(input.shape[0], covered)
-                else:                    # 3-D: the slice runs over dim 1, the max over the last dim
-                    max_input[:, :covered] = head.amax(dim=-1, keepdim=True).expand_as(head)
-        elif input.dim() == 4:
-            m = input.abs().flatten(2).amax(dim=-1)
-            max_input = m[:, :, None, None].expand_as(input)
-        else:
-            raise ValueError
-        s = (2 ** (num_bits - 1) - 1) / (max_input + 1e-6)
-        return torch.round(input * s).div(s + 1e-6)
+        ctx.save_for_backward(input)
+        ctx.clip = (float(clip_val[0]), float(clip_val[1]))
+        return act_fake_quant(input, num_bits, layerwise, symmetric=True)
 
     @staticmethod
     def backward(ctx, grad_output):
-        input, clip_val = ctx.saved_tensors
-        return _ste_clip_torch(grad_output, input, clip_val), None, None, None
+        (input,) = ctx.saved_tensors
+        return ste_clip_backward(grad_output, input, *ctx.clip), None, None, None
 
 
 class AsymQuantizer(torch.autograd.Function):
-    """Asymmetric group-8 min-max fake quantiser (utils_quant.py:105-199)."""
+    """Asymmetric min-max fake quantiser (utils_quant.py:105-199): group 8 on 2-D inputs, otherwise as
+    SymQuantizer."""
 
     @staticmethod
     def forward(ctx, input, clip_val, num_bits, layerwise):
-        ctx.save_for_backward(input, clip_val)
-        if layerwise:
-            beta = input.min()
-            alpha = input.max() - beta
-        elif input.dim() <= 3:
-            _, covered = _dim1_groups(input, 8)
-            alpha = torch.zeros_like(input)
-            beta = torch.zeros_like(input)
-            if covered > 0:
-                head = input[:, :covered]
-                if input.dim() == 2:
-                    g = head.reshape(input.shape[0], covered // 8, 8)
-                    lo, hi = g.amin(dim=-1, keepdim=True), g.amax(dim=-1, keepdim=True)
-                    alpha[:, :covered] = (hi - lo).expand(-1, -1, 8).reshape(input.shape[0], covered)
-                    beta[:, :covered] = lo.expand(-1, -1, 8).reshape(input.shape[0], covered)
-                else:
-                    lo, hi = head.amin(dim=-1, keepdim=True), head.amax(dim=-1, keepdim=True)
-                    alpha[:, :covered] = (hi - lo).expand_as(head)
-                    beta[:, :covered] = lo.expand_as(head)
-        elif input.dim() == 4:
-            flat = input.flatten(2)
-            lo, hi = flat.amin(dim=-1), flat.amax(dim=-1)
-            alpha = (hi - lo)[:, :, None, None].expand_as(input)
-            beta = lo[:, :, None, None].expand_as(input)
-        else:
-            raise ValueError
-        s = 2 ** num_bits - 1
-        normalized = (input - beta) / (alpha + 1e-8)
-        return torch.round(normalized * s).div(s) * (alpha + 1e-8) + beta
+        ctx.save_for_backward(input)
+        ctx.clip = (float(clip_val[0]), float(clip_val[1]))
+        return act_fake_quant(input, num_bits, layerwise, symmetric=False)
 
     @staticmethod
     def backward(ctx, grad_output):
-        input, clip_val = ctx.saved_tensors
-        return _ste_clip_torch(grad_output, input, clip_val), None, None, None
+        (input,) = ctx.saved_tensors
+        return ste_clip_backward(grad_output, input, *ctx.clip), None, None, None
 
 
 class QuantizeLinear(nn.Linear):

@@ -19,6 +19,9 @@ Reference entry points exercised:
   G6 kat         constants of cuda_kernel/test_correct_gemv.py (expected == 4096).
   G7 act         models.utils_quant.SymQuantizer / AsymQuantizer fwd/bwd (2-D, 3-D, 4-D).
   G8 uniform     lib.quantizer.Quantizer as uniform W2 (group 16) / W4 (per row) quantiser.
+  G9 act16       SymQuantizer / AsymQuantizer forward on bf16 / fp16 tensors (uint16 bit patterns).
+
+    python tests/golden/make_golden.py g9        # regenerate selected sets only
 """
 import hashlib
 import os
@@ -303,13 +306,36 @@ def g8_uniform():
     np.savez_compressed(os.path.join(OUT, "g8_uniform.npz"), **out)
 
 
+def g9_act_quantizers_16bit():
+    """SymQuantizer / AsymQuantizer forward on 16-bit tensors: PyTorch evaluates every op in fp32 and
+    rounds to the tensor dtype, which the HIP kernels reproduce op by op."""
+    out = {}
+    clip = torch.tensor([-2.0, 2.0])
+    cases = {"w2d": (16, 384), "w2d_ragged": (4, 200), "a3d": (2, 8, 256), "a3d_long": (1, 140, 128), "s4d": (1, 3, 4, 8)}
+    for dname, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        for cname, shape in cases.items():
+            for qname, Q in (("sym", SymQuantizer), ("asym", AsymQuantizer)):
+                for bits in (4, 8, 16):
+                    for layerwise in (False, True):
+                        torch.manual_seed(7 * len(cname) + bits + len(dname))
+                        x = (torch.randn(*shape) * 1.2).to(dt)
+                        if cname == "w2d":
+                            x[3, 128:256] = 0.5        # a constant group (asym: alpha == 0)
+                            x[5, :128] = 0             # an all-zero group (sym: max == 0)
+                        y = Q.apply(x, clip, bits, layerwise)
+                        assert y.dtype == dt
+                        key = f"{dname}_{cname}_{qname}_b{bits}_{int(layerwise)}"
+                        out[key + "_x"], out[key + "_y"] = bf16_bits(x), bf16_bits(y)
+    np.savez_compressed(os.path.join(OUT, "g9_act16.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    g1_ptq_small(); print("G1 ok")
-    g2_ptq_slices(); print("G2 ok")
-    g3_qat_small(); print("G3 ok")
-    g4_qlinear(); print("G4 ok")
-    g5_block_small(); print("G5 ok")
-    g6_kat(); print("G6 ok")
-    g7_act_quantizers(); print("G7 ok")
-    g8_uniform(); print("G8 ok")
+    gens = [("g1", g1_ptq_small), ("g2", g2_ptq_slices), ("g3", g3_qat_small), ("g4", g4_qlinear),
+            ("g5", g5_block_small), ("g6", g6_kat), ("g7", g7_act_quantizers), ("g8", g8_uniform),
+            ("g9", g9_act_quantizers_16bit)]
+    want = set(a.lower() for a in sys.argv[1:])
+    for name, fn in gens:
+        if not want or name in want:
+            fn()
+            print(name.upper(), "ok")

@@ -459,6 +459,82 @@ def test_g4_quantizelinear_fwd_bwd(dev, g4, dt):
 
 
 # ----------------------------------------------------------------------------------------
+# SymQuantizer / AsymQuantizer (activation / KV fake quant, csrc/actquant.hip)
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("q", ["sym", "asym"])
+def test_g7_activation_quantizers_hip(dev, q):
+    """fp32, forward and STE backward, every branch of the reference: 2-D groups, 3-D per token with the
+    uncovered tokens of the long sequence, 4-D per (batch, head), layerwise."""
+    from mxq_amd.utils_quant import AsymQuantizer, SymQuantizer
+    from tests.conftest import load_golden
+    g7 = load_golden("g7_act_quantizers.npz")
+    Q = SymQuantizer if q == "sym" else AsymQuantizer
+    clip = torch.tensor([-2.0, 2.0])
+    for case in ("w2d", "a3d", "a3d_long", "s4d"):
+        for bits in (4, 16):
+            for lw in (0, 1):
+                key = f"{case}_{q}_b{bits}_{lw}"
+                x = torch.from_numpy(g7[key + "_x"]).to(dev).requires_grad_()
+                y = Q.apply(x, clip, bits, bool(lw))
+                y.backward(torch.from_numpy(g7[key + "_gy"]).to(dev))
+                assert np.array_equal(y.detach().cpu().numpy(), g7[key + "_y"]), key
+                assert np.array_equal(x.grad.cpu().numpy(), g7[key + "_gx"]), key
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_g9_activation_quantizers_16bit_hip(dev, dt):
+    from mxq_amd.utils_quant import AsymQuantizer, SymQuantizer
+    from tests.conftest import load_golden
+    g9 = load_golden("g9_act16.npz")
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    clip = torch.tensor([-2.0, 2.0])
+    keys = sorted(k[:-2] for k in g9.files if k.startswith(dt) and k.endswith("_x"))
+    assert len(keys) == 60
+    for key in keys:
+        qn, bits, lw = key.split("_")[-3:]
+        Q = SymQuantizer if qn == "sym" else AsymQuantizer
+        x = torch.from_numpy(g9[key + "_x"].view(np.int16)).view(tdt).to(dev)
+        y = Q.apply(x, clip, int(bits[1:]), bool(int(lw)))
+        assert np.array_equal(y.cpu().view(torch.int16).numpy().view(np.uint16), g9[key + "_y"]), key
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape,lw", [((2, 512, 4096), False),      # activations of a Llama block: one range per token
+                                       ((1, 32, 256, 128), False),   # KV cache: one range per head, 32 K elements each
+                                       ((64, 11008), False),         # 2-D groups at Llama's MLP width
+                                       ((3, 100, 4096), True)])      # layerwise: a single 1.2 M-element segment
+def test_activation_quantizers_random_vs_oracle(dev, shape, lw, dt):
+    """Bit-exact against the CPU restatement (itself pinned to G7 / G9) at realistic sizes, with NaN / inf
+    free random data plus an all-zero token and a constant token."""
+    from mxq_amd.utils_quant import AsymQuantizer, SymQuantizer
+    from oracle import act_quant as OA
+    g = torch.Generator().manual_seed(len(shape) * 31 + shape[-1])
+    x = (torch.randn(*shape, generator=g) * 1.5).to(dt)
+    x.reshape(-1, shape[-1])[1] = 0
+    x.reshape(-1, shape[-1])[2] = 0.75
+    clip = torch.tensor([-2.0, 2.0])
+    for Qh, Qo, bits in ((SymQuantizer, OA.SymQuantizer, 16), (SymQuantizer, OA.SymQuantizer, 4),
+                         (AsymQuantizer, OA.AsymQuantizer, 8)):
+        y = Qh.apply(x.to(dev), clip, bits, lw).cpu()
+        ref = Qo.apply(x, clip, bits, lw)
+        it = torch.int32 if dt == torch.float32 else torch.int16
+        assert torch.equal(y.view(it), ref.view(it)), (Qh.__name__, bits)
+
+
+def test_activation_quantizer_backward_and_errors(dev):
+    from mxq_amd.utils_quant import SymQuantizer
+    x = (torch.randn(2, 16, 256, device=dev) * 1.5).requires_grad_()
+    go = torch.randn(2, 16, 256, device=dev)
+    SymQuantizer.apply(x, torch.tensor([-2.0, 2.0]), 8, False).backward(go)
+    ref = go.clone(); ref[x.ge(2.0)] = 0; ref[x.le(-2.0)] = 0
+    assert torch.equal(x.grad, ref)
+    with pytest.raises(IndexError):
+        SymQuantizer.apply(torch.zeros(64, device=dev), torch.tensor([-2.0, 2.0]), 8, False)
+    with pytest.raises(ValueError):
+        SymQuantizer.apply(torch.zeros(4, 30, device=dev), torch.tensor([-2.0, 2.0]), 8, False)
+
+
+# ----------------------------------------------------------------------------------------
 # decode stage (config 3 harness): fused q/k/v and gate/up GEMVs vs a dense fp32 restatement
 # ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("heads,fused", [(4, False), (2, True), (2, False)])

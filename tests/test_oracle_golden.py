@@ -108,3 +108,43 @@ def test_g8_uniform_arms(layout, pre):
     for k in ("codes", "sc", "zero", "qs", "qz"):
         assert np.array_equal(p[k], g8[f"{pre}_{k}"]), k
     assert np.array_equal(p["w_deq32"].astype(np.float16).view(np.uint16), g8[f"{pre}_wdeq"].view(np.uint16))
+
+
+# ----------------------------------------------------------------------------------------
+# activation / KV fake quantisers (oracle/act_quant.py) against the reference's outputs
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("q", ["sym", "asym"])
+@pytest.mark.parametrize("case", ["w2d", "a3d", "a3d_long", "s4d"])
+def test_g7_activation_quantizers(q, case):
+    import torch
+    from oracle.act_quant import AsymQuantizer, SymQuantizer
+    from tests.conftest import load_golden
+    g7 = load_golden("g7_act_quantizers.npz")
+    Q = SymQuantizer if q == "sym" else AsymQuantizer
+    clip = torch.tensor([-2.0, 2.0])
+    for bits in (4, 16):
+        for lw in (0, 1):
+            key = f"{case}_{q}_b{bits}_{lw}"
+            x = torch.from_numpy(g7[key + "_x"]).requires_grad_()
+            y = Q.apply(x, clip, bits, bool(lw))
+            y.backward(torch.from_numpy(g7[key + "_gy"]))
+            assert np.array_equal(y.detach().numpy(), g7[key + "_y"]), key
+            assert np.array_equal(x.grad.numpy(), g7[key + "_gx"]), key
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_g9_activation_quantizers_16bit(dt):
+    import torch
+    from oracle.act_quant import AsymQuantizer, SymQuantizer
+    from tests.conftest import load_golden
+    g9 = load_golden("g9_act16.npz")
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    clip = torch.tensor([-2.0, 2.0])
+    keys = sorted(k[:-2] for k in g9.files if k.startswith(dt) and k.endswith("_x"))
+    assert len(keys) == 60
+    for key in keys:
+        _, _, qn, bits, lw = key.rsplit("_", 4)[-5:] if False else (None, None, *key.split("_")[-3:])
+        Q = SymQuantizer if qn == "sym" else AsymQuantizer
+        x = torch.from_numpy(g9[key + "_x"].view(np.int16)).view(tdt)
+        y = Q.apply(x, clip, int(bits[1:]), bool(int(lw)))
+        assert np.array_equal(y.view(torch.int16).numpy().view(np.uint16), g9[key + "_y"]), key
