@@ -137,6 +137,97 @@ __device__ __forceinline__ f32x4 ld_agent(const float* slot, int f, int lane) {
 
 __device__ __forceinline__ int sk_bound(int u, int S, int units) { return (int)((uint32_t)u * (uint32_t)S / (uint32_t)units); }
 
+// The same dequant cut into stages of <= 6 VALU ops, so that consumer_step() can place one stage behind
+// every group of four MFMAs: a 16x16x32 MFMA keeps the SIMD's vector issue port for 8 of its 16 cycles,
+// the other 8 take two VALU ops for free, whereas the whole dequant issued in one piece after the MFMAs
+// (what hipcc emits for a plain call: ~45 VALU ops in a row) leaves the matrix pipe idle while both
+// consumer waves of a SIMD do it in lockstep.  Arithmetic and rounding are mxq_deq2x16's.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct DeqStage {
+    int off_c2, off_sc, off_qq, w_off0, w_off1, sh;   // per-thread constants
+    uint32_t d, scw, p01, p23, lut_lo, lut_hi, o[4];
+    float z, s;
+    f32x2 qq;
+};
+__device__ __forceinline__ void deq_init(DeqStage& q, int d_row, int g) {
+    const int blk = d_row >> 4, r = d_row & 15;
+    q.off_c2 = blk * BP_BLK + mxq_c2(g, r) * 4;            // Z2 sits (MXQ_OFF_Z2 - MXQ_OFF_C2) dwords further
+    q.off_sc = blk * BP_BLK + mxq_sc_u16(r) * 2;
+    q.off_qq = blk * BP_BLK + mxq_qq(g) * 4;
+    q.w_off0 = swz(d_row, g * 2);
+    q.w_off1 = swz(d_row, g * 2 + 1);
+    q.sh = 4 * g;
+}
+__device__ __forceinline__ void deq_load(DeqStage& q, const char* smem, int t) {
+    const char* b = smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE;
+    q.d = *(const uint32_t*)(b + q.off_c2);
+    q.z = *(const float*)(b + q.off_c2 + (MXQ_OFF_Z2 - MXQ_OFF_C2) * 4);
+    q.scw = *(const uint16_t*)(b + q.off_sc);
+    q.qq = *(const f32x2*)(b + q.off_qq);
+}
+__device__ __forceinline__ void deq_scale(DeqStage& q) { q.s = mxq_scale(q.qq[0], q.qq[1], (q.scw >> q.sh) & 15u); }
+__host__ __device__ __forceinline__ void deq_pair01(DeqStage& q) { q.p01 = mxq_pack_f16(q.s * (0.0f - q.z), q.s * (1.0f - q.z)); }
+__host__ __device__ __forceinline__ void deq_pair23(DeqStage& q) { q.p23 = mxq_pack_f16(q.s * (2.0f - q.z), q.s * (3.0f - q.z)); }
+__host__ __device__ __forceinline__ void deq_lut(DeqStage& q) {
+    q.lut_lo = MXQ_PERM(q.p23, q.p01, 0x06040200u);
+    q.lut_hi = MXQ_PERM(q.p23, q.p01, 0x07050301u);
+}
+template <int J>
+__host__ __device__ __forceinline__ void deq_select(DeqStage& q) {   // elements 4J .. 4J+3 -> o[2(J&1)], o[2(J&1)+1]
+    const uint32_t m = (q.d >> (2 * J)) & 0x03030303u;
+    const uint32_t lo = MXQ_PERM(0u, q.lut_lo, m), hi = MXQ_PERM(0u, q.lut_hi, m);
+    q.o[2 * (J & 1)] = MXQ_PERM(hi, lo, 0x05010400u);
+    q.o[2 * (J & 1) + 1] = MXQ_PERM(hi, lo, 0x07030602u);
+}
+template <int H>
+__device__ __forceinline__ void deq_store(const DeqStage& q, char* smem, int t) {   // half H: elements 8H .. 8H+7
+    char* wt = smem + OFF_W + (t & 1) * W_STAGE;
+    *(u32x4*)(wt + (H ? q.w_off1 : q.w_off0)) = (u32x4){q.o[0], q.o[1], q.o[2], q.o[3]};
+}
+
+// One K-step t >= 1 of a consumer wave: MFMAs of (t-1, kk=1) and (t, kk=0), fragment loads of step t, and --
+// DEQ -- the staged dequant of this thread's group of chunk t+1, one stage behind every four MFMAs.
+#define MXQ_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <int ABL>
+__device__ __forceinline__ void consumer_step(char* smem, int t, bool deq, int wm, int wn, int fr, int fq,
+                                              f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1, Frag4& xf1,
+                                              DeqStage& q) {
+    // `deq` is wave-uniform.  The packed words are read first (LDS returns in order: they are in before the
+    // fragments); the arithmetic runs after the step's last MFMA has been issued.
+    if (deq) deq_load(q, smem, t + 1);
+    MXQ_FENCE();
+    mfma_rows<0, 1, ABL>(acc, wf1, xf1);
+    MXQ_FENCE();
+    if constexpr (!(ABL & 8)) load_frags(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
+    MXQ_FENCE();
+    mfma_rows<1, 3, ABL>(acc, wf1, xf1);
+    MXQ_FENCE();
+    if (deq) { deq_scale(q); deq_pair01(q); }
+    MXQ_FENCE();
+    mfma_rows<3, 4, ABL>(acc, wf1, xf1);
+    MXQ_FENCE();
+    if (deq) { deq_pair23(q); deq_lut(q); }
+    if constexpr (!(ABL & 8)) load_frags(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
+    MXQ_FENCE();
+    mfma_rows<0, 1, ABL>(acc, wf0, xf0);
+    MXQ_FENCE();
+    if (deq) deq_select<0>(q);
+    MXQ_FENCE();
+    mfma_rows<1, 2, ABL>(acc, wf0, xf0);
+    MXQ_FENCE();
+    if (deq) { deq_select<1>(q); deq_store<0>(q, smem, t + 1); }
+    MXQ_FENCE();
+    mfma_rows<2, 3, ABL>(acc, wf0, xf0);
+    MXQ_FENCE();
+    if (deq) deq_select<2>(q);
+    MXQ_FENCE();
+    mfma_rows<3, 4, ABL>(acc, wf0, xf0);
+    MXQ_FENCE();
+    if (deq) { deq_select<3>(q); deq_store<1>(q, smem, t + 1); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 __device__ __forceinline__ void store_tile(const f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N, int m0,
                                            int n0, int wm, int wn, int fr, int fq) {
 #pragma unroll
@@ -180,24 +271,13 @@ __device__ __forceinline__ void consumer(char* smem, int wave, int lane, int NT,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    for (int t = 1; t < NT; ++t) {
-        // (wf1, xf1) = fragments of (t-1, kk=1), waited for at the end of the previous step
-        mfma_rows<0, 1, ABL>(acc, wf1, xf1);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(ABL & 8)) load_frags(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_rows<1, 4, ABL>(acc, wf1, xf1);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(ABL & 8)) load_frags(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_rows<0, 4, ABL>(acc, wf0, xf0);
-        if constexpr (!(ABL & 4)) {
-            if (has_deq && t + 1 < NT) cons_dequant(smem, t + 1, d_row, d_g);   // the compiler threads it between the MFMAs
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
+    // (wf1, xf1) = fragments of (t-1, kk=1), waited for at the end of the previous step.  Steps 1 .. NT-2
+    // dequantise chunk t+1 on the way; the last step has nothing left to dequantise.
+    DeqStage q;
+    deq_init(q, d_row, d_g);
+    const bool deq_wave = has_deq && !(ABL & 4);
+    for (int t = 1; t < NT; ++t)
+        consumer_step<ABL>(smem, t, deq_wave && t + 1 < NT, wm, wn, fr, fq, acc, wf0, xf0, wf1, xf1, q);
     mfma_rows<0, 4, ABL>(acc, wf1, xf1);   // (NT-1, kk=1)
 
     if (NT != NT_tile) {

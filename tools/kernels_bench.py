@@ -89,6 +89,15 @@ def main():
     print(f"  one decoder block (7 weights): fwd {tot_f:.1f} us = {4*n_blk/tot_f/1e3:.0f} GB/s, "
           f"bwd {tot_b:.1f} us = {6*n_blk/tot_b/1e3:.0f} GB/s  (floors at 6.3 TB/s: 128 / 193 us)")
 
+    print("== SymQuantizer / AsymQuantizer forward, bf16 (activation [2, 2048, 4096] per token; KV [2, 32, 2048, 128] per head) ==")
+    from mxq_amd.utils_quant import act_fake_quant
+    for shape, what in (((2, 2048, 4096), "activation"), ((2, 32, 2048, 128), "kv"), ((4096, 11008), "2-D groups")):
+        xa = (torch.randn(*shape, device=dev) * 1.5).bfloat16()
+        n = xa.numel()
+        for sym, bits in ((True, 16), (False, 8)):
+            us = timeit(lambda: act_fake_quant(xa, bits, False, sym), iters=20)
+            print(f"  {what:<11} {'sym' if sym else 'asym'} b{bits}: {us:7.1f} us  {4*n/us/1e3:7.1f} GB/s algorithmic (read + write)", flush=True)
+
     print("== quantise-and-pack (fp16 in) ==")
     for N, K in SHAPES:
         W = (torch.randn(N, K, device=dev) * 0.02).half()
