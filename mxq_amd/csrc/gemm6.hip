@@ -275,7 +275,7 @@ __device__ __forceinline__ void consumer(char* smem, int wave, int lane, int NT,
     // dequantise chunk t+1 on the way; the last step has nothing left to dequantise.
     DeqStage q;
     deq_init(q, d_row, d_g);
-    const bool deq_wave = has_deq && !(ABL & 4);
+    const bool deq_wave = has_deq && !(ABL & (4 | 32));
     for (int t = 1; t < NT; ++t)
         consumer_step<ABL>(smem, t, deq_wave && t + 1 < NT, wm, wn, fr, fq, acc, wf0, xf0, wf1, xf1, q);
     mfma_rows<0, 4, ABL>(acc, wf1, xf1);   // (NT-1, kk=1)
@@ -339,11 +339,12 @@ struct Prod {
     float s4, z4;
 };
 
+template <int ABL = 0>
 __device__ __forceinline__ void issue_a(const Prod& c, int t) {
     // producer p fills rows 64p .. 64p+63 of the x slot: DMA i covers rows 64p + 8i .. +7
     char* dst = c.smem + OFF_A + (t % A_SLOTS) * A_STAGE + c.p * 8192;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) glds16(c.a_src[i] + t * BK, dst + i * 1024);
+    for (int i = 0; i < ((ABL & 16) ? 4 : 8); ++i) glds16(c.a_src[i] + t * BK, dst + i * 1024);   // ABL 16: half the x DMAs (timing probe)
 }
 template <int LAYOUT>
 __device__ __forceinline__ void issue_bp(const Prod& c, int t) {
@@ -380,10 +381,11 @@ __device__ __forceinline__ void producer(const Prod& c) {
 
     int t = 0;
     for (; t + 3 < c.NT; ++t) {   // steady state: everything unconditional
-        if constexpr (!(ABL & 1)) issue_a(c, t + 2);
+        if constexpr (!(ABL & 1)) issue_a<ABL>(c, t + 2);
         issue_bp<LAYOUT>(c, t + 3);
-        if constexpr (!(ABL & 4)) dequant<LAYOUT>(c, t + 1);
+        if constexpr (!(ABL & (4 | 64))) dequant<LAYOUT>(c, t + 1);
         if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else if constexpr (ABL & 16) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // this step's 10 DMAs stay in flight
         __builtin_amdgcn_s_barrier();
     }
@@ -582,4 +584,20 @@ size_t mxq_gemm6_workspace_bytes() { return CNT_BYTES + (size_t)(cu_count() / 8 
 int mxq_launch_gemm6_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          void* workspace, size_t ws_bytes, int force, hipStream_t stream) {
     return launch6<0>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, force != 0, stream);
+}
+
+// profiling-only builds (wrong results): 1 = no x DMAs, 2 = no MFMA, 4 = no dequant at all, 16 = half the x DMAs,
+// 32 = no 2-bit (consumer-side) dequant, 64 = no 4-bit (producer-side) dequant
+int mxq_launch_gemm6_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                int abl, hipStream_t stream) {
+    switch (abl) {
+        case 1: return launch6<1>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 2: return launch6<2>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 4: return launch6<4>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 5: return launch6<5>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 16: return launch6<16>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 32: return launch6<32>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 64: return launch6<64>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+    }
+    return (int)hipErrorInvalidValue;
 }

@@ -37,6 +37,8 @@ size_t mxq_gemm6_workspace_bytes();
 int mxq_launch_gemm6_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          void* workspace, size_t ws_bytes, int force,
                          hipStream_t stream);   // gemm5 + stream-K tail (gemm6.hip); force: split even when it does not pay
+int mxq_launch_gemm6_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+                                int K, int abl, hipStream_t stream);   // profiling only
 int mxq_launch_gemm5_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
                                 int K, int abl, hipStream_t stream);   // profiling only
 int mxq_launch_gemm4_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
