@@ -168,7 +168,7 @@ def main():
     achieved = flops_rank_step / (dev_ms / args.steps * 1e-3) / 1e12
 
     traffic = None       # HBM bytes per launch from rocprofv3 PMC counters (collected offline, see the file)
-    tpath = os.path.join(ROOT, "profiles", "r01_gemm5_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_gemm6_traffic.json")
     if world == 1 and os.path.exists(tpath):
         traffic = json.load(open(tpath))["avg_hbm_bytes_per_launch"]
     if rank == 0:
