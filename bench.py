@@ -26,7 +26,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -34,6 +36,7 @@ if ROOT not in sys.path:
 
 from mxq_amd import llama_shapes as LS  # noqa: E402
 from mxq_amd import packing  # noqa: E402
+from mxq_amd.pipeline import LayerPipeline  # noqa: E402
 
 SEQ = 2048
 PEAK_F16_TFLOPS = 2500.0     # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
@@ -125,15 +128,19 @@ def main():
                 x = x_i if p.K == LS.INTERMEDIATE else x_hidden
                 packing.linear(x, p, out=(y_i if p.N == LS.INTERMEDIATE else y_h), path="gemm")
 
+    # N > 1: the schedule is mxq_amd.pipeline.LayerPipeline's (the same object the gloo tests drive on CPU):
+    # per micro-batch recv from rank-1 -> this rank's layers -> send to rank+1
+    pipe = LayerPipeline(rank, world) if world > 1 else None
+
+    def stage_fn(h):
+        stage(h)
+        return h          # the hidden state that hops on (synthetic run: its values do not matter, its size does)
+
     def step():
-        for _ in range(n_micro):
-            xin = x_h
-            if world > 1 and rank > 0:
-                dist.recv(recv_buf, src=rank - 1)
-                xin = recv_buf
-            stage(xin)
-            if world > 1 and rank < world - 1:
-                dist.send(xin, dst=rank + 1)      # the hidden state hops to the next pipeline stage
+        if pipe is None:
+            stage(x_h)
+        else:
+            pipe.run_microbatches(stage_fn, [x_h] * n_micro, recv_buf, collect=False)
 
     def sync():
         torch.cuda.synchronize()

@@ -59,18 +59,19 @@ class LayerPipeline:
 
     # -- prefill-style streaming of micro-batches -------------------------------------------------
     def run_microbatches(self, stage_fn: Callable[[torch.Tensor], torch.Tensor], inputs: List[torch.Tensor],
-                         recv_buf: torch.Tensor) -> List[torch.Tensor]:
+                         recv_buf: torch.Tensor, collect: bool = True) -> List[torch.Tensor]:
         """Stream ``inputs`` (used by the first stage; later stages only need their count and
         shape) through the pipeline.  Stage ``r`` works on micro-batch ``b`` while stage ``r+1``
-        works on ``b-1``.  Returns the last stage's outputs (empty list elsewhere)."""
+        works on ``b-1``.  Returns the last stage's outputs (empty list elsewhere, or when
+        ``collect`` is False: a throughput run that does not keep them)."""
         outs = []
         for x in inputs:
             h = x if self.is_first else self.recv_hidden(recv_buf)
             h = stage_fn(h)
-            if self.is_last:
-                outs.append(h.clone() if h is recv_buf else h)
-            else:
+            if not self.is_last:
                 self.send_hidden(h)
+            elif collect:
+                outs.append(h.clone() if h is recv_buf else h)
         return outs
 
     # -- greedy decode ------------------------------------------------------------------------------

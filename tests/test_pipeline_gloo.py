@@ -52,6 +52,8 @@ def _worker(rank, world, port, q):
         fn = _stage(Ws, layer_range(rank, world, N_LAYERS))
         xs = [torch.full((4, HID), float(b + 1)) / 7 for b in range(5)]
         outs = pipe.run_microbatches(fn, xs, torch.empty(4, HID))
+        # bench.py's N > 1 schedule: the stage hands its own input buffer on, nothing is collected
+        assert pipe.run_microbatches(lambda h: h, xs * 3, torch.empty(4, HID), collect=False) == []
         gen = pipe.decode(3, 6, lambda t: emb.index_select(0, t), fn, lambda h: (h @ head.t()).argmax(-1),
                           torch.empty(1, HID), torch.zeros(1, dtype=torch.int64))
         q.put((rank, [o.clone() for o in outs], gen))

@@ -19,8 +19,9 @@ PEAK = 2500.0
 
 
 def timed(fn, iters):
-    for _ in range(2):
+    for _ in range(4):      # warm-up: the first launches of a process run at a different clock / cold caches
         fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -33,7 +34,7 @@ def timed(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=32768)
-    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     M = args.m
