@@ -146,6 +146,35 @@ class DecodeStage:
         self._graph.replay()
         return self._h_out
 
+    def capture_token_loop(self, token_buf: torch.Tensor):
+        """Single-stage decode (this stage is first AND last): capture token -> embedding -> layers -> final
+        norm -> lm_head -> argmax -> token as ONE graph that updates ``token_buf`` [1] int64 in place, so a
+        decoded token costs one graph launch instead of ~20 small host-launched kernels around the layer graph."""
+        if getattr(self, "embed", None) is None or getattr(self, "lm_head", None) is None:
+            raise ValueError("capture_token_loop needs the first and the last stage in one process")
+
+        def one():
+            token_buf.copy_(self.head(self.step(self.embed_token(token_buf))).reshape(-1)[:1])
+        for _ in range(2):
+            one()
+        self.pos.zero_()
+        torch.cuda.synchronize()
+        self._tgraph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._tgraph):
+            one()
+            self.pos += 1
+        self.pos.zero_()
+        return self
+
+    def decode_tokens(self, token_buf: torch.Tensor, first_token: int, n_tokens: int):
+        """Greedy decode with the graph of ``capture_token_loop``; returns the generated ids."""
+        token_buf.fill_(int(first_token))
+        out = torch.zeros(n_tokens, dtype=token_buf.dtype, device=token_buf.device)
+        for i in range(n_tokens):
+            self._tgraph.replay()
+            out[i:i + 1].copy_(token_buf)
+        return out.tolist()
+
     def reset(self):
         self.pos.zero_()
         self.k_cache.zero_()

@@ -582,6 +582,29 @@ def test_decode_stage_matches_dense_reference(dev, heads, fused):
     assert int(st.pos.item()) == 5
 
 
+def test_decode_token_graph_matches_eager_loop(dev):
+    """The one-graph-per-token loop (embedding -> layers -> head -> argmax captured together) must generate
+    exactly the tokens of the step-by-step loop through LayerPipeline.decode on the same stage."""
+    from mxq_amd.llama_decode import DecodeStage
+    from mxq_amd.pipeline import LayerPipeline
+    st = DecodeStage(range(2), dev, max_ctx=64, first=True, last=True, hidden=256, inter=704, heads=2, vocab=512)
+    tbuf = torch.zeros(1, dtype=torch.int64, device=dev)
+    hbuf = torch.zeros(1, 256, device=dev, dtype=torch.float16)
+    pipe = LayerPipeline(0, 1)
+
+    def stage_fn(h, step):
+        out = st.step(h)
+        st.advance()
+        return out
+    st.reset()
+    eager = pipe.decode(3, 12, st.embed_token, stage_fn, st.head, hbuf, tbuf)
+    st.capture_token_loop(tbuf)
+    st.reset()
+    graphed = st.decode_tokens(tbuf, 3, 12)
+    assert graphed == eager and len(set(graphed)) > 1
+    assert int(st.pos.item()) == 12
+
+
 def test_g5_decoder_block_fwd_bwd(dev, g5):
     """A Llama decoder layer built from this repo's QuantizeLinear (w_bits=2, a_bits=16) must
     reproduce the reference's LlamaDecoderLayer (LLM-QAT/models/modeling_llama_quant.py:414-469)

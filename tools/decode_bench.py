@@ -51,8 +51,14 @@ def main():
             return out
         return stage.step_graph(h)
 
+    single = world == 1 and not args.no_graph
+    if single:
+        stage.capture_token_loop(tbuf)     # token -> token in one graph (embedding, layers, head, argmax)
+
     def run(n):
         stage.reset()
+        if single:
+            return stage.decode_tokens(tbuf, 1, n)
         return pipe.decode(1, n, stage.embed_token if pipe.is_first else None, stage_fn,
                            stage.head if pipe.is_last else None, hbuf, tbuf)
 
