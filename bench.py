@@ -104,13 +104,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback for the measured path)")
+    # (MXQ_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks: ranks then
+    # share devices and the hidden state hops through host memory; numbers from such a run mean nothing)
+    backend = os.environ.get("MXQ_BENCH_BACKEND", "nccl")
+    local_rank = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     my_layers = list(LS.layer_range(rank, world))
     layers = build_layers(my_layers, dev)
