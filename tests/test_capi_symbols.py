@@ -55,3 +55,41 @@ def test_argument_validation_without_gpu(lib):
     assert lib.mxq_gemv_awq_f16(16, 16, 16, 16, 16, 1, 4096, 4096, 16, None) == -1
     assert lib.mxq_gemv_proto_f16(*([16] * 9), 1, 2048, 4096, 16, None) == -1
     assert lib.mxq_quantize_pack(16, 9, None, 16, 16, 64, 64, None) == -3
+
+
+def test_argument_validation_rejects_before_any_launch(lib):
+    """Every entry point validates its arguments first and returns a negative MXQ_E_* code without
+    touching the (fake) pointers or the device -- what the Python wrappers turn into ValueError, like the
+    reference GEMM's std::invalid_argument (gemm_cuda_gen.cu:447-454).  No kernel is launched here."""
+    E_SHAPE, E_NULL, E_DTYPE, E_ALIGN = -1, -2, -3, -4
+    P, Q = 0x10000, 0x20008          # fake device addresses: 16-byte aligned / 8-byte aligned only
+    # the Linear family: x, qweight, rowmeta, y, M, N, K, stream
+    for fn in (lib.mxq_linear_f16, lib.mxq_gemm_f16, lib.mxq_gemv_f16):
+        assert fn(None, P, P, P, 8, 64, 256, None) == E_NULL
+        assert fn(P, P, P, P, 8, 60, 256, None) == E_SHAPE          # N % 16
+        assert fn(P, P, P, P, 8, 64, 200, None) == E_SHAPE          # K % 64
+        assert fn(P, P, P, P, 0, 64, 256, None) == E_SHAPE          # no tokens
+        assert fn(P, Q, P, P, 2, 64, 256, None) == E_ALIGN
+    assert lib.mxq_gemv_f16(P, P, P, P, 5, 64, 256, None) == E_SHAPE   # GEMV is for <= 4 tokens
+    assert lib.mxq_gemm_f16_ex(P, P, P, P, 8, 64, 256, 999, None) == E_SHAPE
+    assert lib.mxq_linear_f16_ws(P, P, P, P, 8, 64, 256, Q, 1 << 27, None) == E_ALIGN
+    assert lib.mxq_gemm_f16_ws(P, P, P, None, 8, 64, 256, 0, None, 0, None) == E_NULL
+    assert lib.mxq_gemv_fused_f16(P, P, P, P, 64, 256, 1, None, 1e-5, None, None) == E_NULL   # RMSNorm needs its weight
+    assert lib.mxq_gemv_fused_f16(P, P, P, P, 64, 256, 7, None, 1e-5, None, None) == E_SHAPE
+    # packing
+    assert lib.mxq_quantize_pack(P, 9, None, P, P, 64, 256, None) == E_DTYPE
+    assert lib.mxq_quantize_pack(P, 1, None, None, P, 64, 256, None) == E_NULL
+    assert lib.mxq_dequant_f16(P, P, Q, 64, 256, None) == E_ALIGN
+    assert lib.mxq_quantize_pack_layout(P, 1, P, P, 64, 256, 5, None) == E_SHAPE     # unknown layout
+    # fake quant
+    assert lib.mxq_fakequant_fwd(P, P, 16, 100, 2, 2, None) == E_SHAPE                # cols % 64
+    assert lib.mxq_fakequant_fwd(P, P, 16, 128, 2, 7, None) == E_DTYPE
+    assert lib.mxq_fakequant_fwd(P, None, 16, 128, 2, 2, None) == E_NULL
+    assert lib.mxq_actquant_group_fwd(P, P, 4, 200, 48, 8, 1, 2, None) == E_SHAPE     # group / 8 not a power of two
+    assert lib.mxq_actquant_group_fwd(P, P, 4, 204, 128, 8, 1, 2, None) == E_SHAPE    # cols % 8
+    assert lib.mxq_actquant_fwd(P, P, None, 4, 256, 1, 1, 8, 1, 2, None) == E_NULL
+    assert lib.mxq_actquant_fwd(P, P, P, 4, 250, 1, 1, 8, 1, 2, None) == E_SHAPE
+    # the reference extension's formats
+    assert lib.mxq_gemv_awq_f16(P, P, P, P, P, 1, 4096, 4096, 48, None) == E_SHAPE    # group size
+    assert lib.mxq_gemv_proto_f16(P, P, P, P, P, P, P, P, P, 1, 2048, 4096, 16, None) == E_SHAPE   # IC must be 4096
+    assert lib.mxq_gemm_workspace_bytes() == 64 * 1024 + 256 * 2 * 256 * 128 * 4 or lib.mxq_gemm_workspace_bytes() > 64 * 1024

@@ -196,6 +196,26 @@ def test_gemm_stream_k_tail(dev, M, N, K):
     assert torch.equal(packing.linear(xd, p, path="gemm6"), yd)
 
 
+def test_linear_empty_and_nonfinite_inputs(dev):
+    """Empty token dimension returns an empty result without a launch; a NaN / inf activation poisons exactly
+    its own token row, on the GEMV, the single-tile GEMM and the stream-K GEMM alike (no cross-row leakage
+    through the shared accumulators or the stream-K workspace)."""
+    from mxq_amd import packing
+    p, w16, g = _packed_case(dev, 256, 4096, 11)
+    assert packing.linear(torch.empty(0, 4096, dtype=torch.float16, device=dev), p).shape == (0, 256)
+    assert packing.linear(torch.empty(2, 0, 4096, dtype=torch.float16, device=dev), p).shape == (2, 0, 256)
+    for M, path in ((3, "gemv"), (100, "gemm1"), (300, "gemm7")):
+        x = torch.randn(M, 4096, generator=g).half()
+        clean = packing.linear(x.to(dev), p, path=path)
+        x[1, 7] = float("nan")
+        x[M - 1, 4000] = float("inf")
+        y = packing.linear(x.to(dev), p, path=path)
+        assert torch.isnan(y[1]).all()
+        assert not torch.isfinite(y[M - 1]).any()
+        keep = [i for i in range(M) if i not in (1, M - 1)]
+        assert torch.equal(y[keep], clean[keep]) and torch.isfinite(y[keep]).all()
+
+
 @pytest.mark.parametrize("M", [1, 2, 3, 4])
 @pytest.mark.parametrize("N,K", [(64, 256), (256, 704), (4096, 4096)])
 def test_gemv_vs_oracle(dev, M, N, K):
