@@ -473,6 +473,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm6_f16_kernel(const uint16_t* 
     // a segment's last barrier nobody touches LDS any more, so the next segment may start at once
     // (two copies of the loop, one per wave-uniform role: each role keeps only its own loop invariants live)
     if (wave < N_CONS) {
+        __builtin_amdgcn_s_setprio(3);   // MFMA waves win issue arbitration against the DMA / dequant wave of their SIMD
         // a unit has at most two partial segments: the one its range starts in and the one it ends in
         int pj0 = -1, pn0 = 0, pj1 = -1, pn1 = 0;
         for (int pos = b0; pos < b1;) {
