@@ -1,7 +1,7 @@
-"""The layer-by-layer PTQ loop of ``nas_quant`` (reference mxq_quant/lib/prune.py:338-420), minus
-everything that needs the network or a checkpoint (model / dataset loading, ``prepare_calibration_input``'s
-Catcher around ``model.layers[0]``): the caller hands over the decoder layers and the calibration
-hidden states, exactly the state ``nas_quant`` is in at prune.py:366 ("Ready.").
+"""The layer-by-layer PTQ loop of ``nas_quant`` (reference mxq_quant/lib/prune.py:338-420) and its helpers
+``find_layers``, ``prepare_calibration_input`` and ``check_sparsity`` (prune.py:17-102), minus everything
+that needs the network or a checkpoint (model / dataset loading): ``quantize_sequential`` takes the decoder
+layers and the calibration hidden states, exactly the state ``nas_quant`` is in at prune.py:366 ("Ready.").
 
 For every layer, as the reference does (prune.py:368-417):
   1. ``find_layers`` collects its ``nn.Linear`` s, one ``MXQGPT`` each (:381-385);
@@ -89,6 +89,71 @@ def quantize_sequential(layers: Sequence[nn.Module], inps: torch.Tensor, layer_k
             outs[j] = _first(layer(inps[j].unsqueeze(0), **layer_kwargs))
         inps, outs = outs, inps
     return packed
+
+
+class _StopForward(Exception):
+    """Raised by the input recorder to abandon the rest of the model's forward."""
+
+
+def prepare_calibration_input(model: nn.Module, dataloader, device, nsamples: int = 128):
+    """Record what reaches the first decoder layer for every calibration batch (the reference's Catcher,
+    prune.py:64-102): returns ``(inps [nsamples, seqlen, hidden], outs, attention_mask, position_ids)`` --
+    the arguments ``quantize_sequential`` / ``nas_quant``'s layer loop start from.  ``model`` is HF-shaped
+    (``model.model.layers``, ``model.config.hidden_size / use_cache``, ``model.seqlen``); ``dataloader``
+    yields ``(input_ids, ...)`` tuples as ``lib/data.py``'s loaders do."""
+    use_cache = getattr(model.config, "use_cache", None)
+    model.config.use_cache = False
+    layers = model.model.layers
+    device = getattr(model, "hf_device_map", {}).get("model.embed_tokens", device)
+    dtype = next(iter(model.parameters())).dtype
+    inps = torch.zeros((nsamples, model.seqlen, model.config.hidden_size), dtype=dtype, device=device)
+    seen = {"n": 0, "attention_mask": None, "position_ids": None}
+
+    class Recorder(nn.Module):
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, inp, **kwargs):
+            if seen["n"] < nsamples:
+                inps[seen["n"]] = inp
+            seen["n"] += 1
+            seen["attention_mask"] = kwargs.get("attention_mask")
+            seen["position_ids"] = kwargs.get("position_ids")
+            raise _StopForward
+
+    first = layers[0]
+    layers[0] = Recorder(first)
+    try:
+        for batch in dataloader:
+            try:
+                model(batch[0].to(device))
+            except _StopForward:
+                pass
+    finally:
+        layers[0] = first
+        model.config.use_cache = use_cache
+    return inps, torch.zeros_like(inps), seen["attention_mask"], seen["position_ids"]
+
+
+def check_sparsity(model: nn.Module, log: Optional[Callable[[str], None]] = print) -> float:
+    """Fraction of exactly-zero weights over the decoder layers' Linears, with the reference's per-layer
+    report (prune.py:39-63).  Packed ``QuantLinear`` modules are counted through their dequantised weight."""
+    use_cache = getattr(model.config, "use_cache", None)
+    model.config.use_cache = False
+    count = total = 0
+    for i, layer in enumerate(model.model.layers):
+        sub_count = sub_total = 0
+        for lin in find_layers(layer, layers=(nn.Linear, QuantLinear)).values():
+            w = lin.dequantize() if isinstance(lin, QuantLinear) else lin.weight.data
+            sub_count += int((w == 0).sum().item())
+            sub_total += w.numel()
+        if log and sub_total:
+            log(f"layer {i} sparsity {float(sub_count) / sub_total:.6f}")
+        count += sub_count
+        total += sub_total
+    model.config.use_cache = use_cache
+    return float(count) / max(total, 1)
 
 
 def check_sparsity_linear(layers: Iterable[nn.Module]) -> float:

@@ -137,3 +137,53 @@ def test_pack_model_needs_the_gpu():
     from mxq_amd import checkpoint
     with pytest.raises(ValueError, match="GPU only"):
         checkpoint.pack_model(torch.nn.Sequential(torch.nn.Linear(64, 16)))
+
+
+def test_prepare_calibration_input_and_check_sparsity():
+    """The HF-shaped helpers around the layer loop (prune.py:39-102) on a toy model, CPU only."""
+    import types
+    from mxq_amd.lib.prune import check_sparsity, prepare_calibration_input
+
+    class Layer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(64, 64, bias=False)
+
+        def forward(self, x, attention_mask=None, position_ids=None):
+            return (self.lin(x),)
+
+    class Inner(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed_tokens = torch.nn.Embedding(100, 64)
+            self.layers = torch.nn.ModuleList([Layer(), Layer()])
+
+        def forward(self, ids):
+            h = self.embed_tokens(ids)
+            pos = torch.arange(ids.shape[1])[None]
+            for l in self.layers:
+                h = l(h, attention_mask=None, position_ids=pos)[0]
+            return h
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = Inner()
+            self.config = types.SimpleNamespace(use_cache=True, hidden_size=64)
+            self.seqlen = 8
+
+        def forward(self, ids):
+            return self.model(ids)
+
+    torch.manual_seed(0)
+    m = Model()
+    loader = [(torch.randint(0, 100, (1, 8)), None) for _ in range(5)]
+    inps, outs, mask, pos = prepare_calibration_input(m, loader, "cpu", nsamples=4)
+    assert inps.shape == (4, 8, 64) and outs.shape == inps.shape and mask is None and pos.tolist() == [list(range(8))]
+    assert torch.equal(inps[2], m.model.embed_tokens(loader[2][0])[0])     # what layer 0 received for batch 2
+    assert isinstance(m.model.layers[0], Layer) and m.config.use_cache is True     # model restored
+    with torch.no_grad():
+        m.model.layers[1].lin.weight[:16] = 0
+    lines = []
+    assert check_sparsity(m, log=lines.append) == pytest.approx(0.125)
+    assert lines == ["layer 0 sparsity 0.000000", "layer 1 sparsity 0.250000"]
