@@ -36,7 +36,15 @@ __device__ __forceinline__ void sym_apply(const float (&v)[T::VEC], float mx, fl
     const float s = T::rnd(T::rnd(1.0f / T::rnd(mx + 1e-6f)) * qmax);
     const float s2 = T::rnd(s + 1e-6f);
 #pragma unroll
-    for (int j = 0; j < T::VEC; ++j) o[j] = T::rnd(rintf(T::rnd(v[j] * s)) / s2);
+    for (int j = 0; j < T::VEC; j += 2) {   // roundings go pairwise (T::rnd2: one v_cvt_pk per two values)
+        float a = v[j] * s, b = v[j + 1] * s;
+        T::rnd2(a, b);
+        a = rintf(a) / s2;
+        b = rintf(b) / s2;
+        T::rnd2(a, b);
+        o[j] = a;
+        o[j + 1] = b;
+    }
 }
 
 template <typename T>
@@ -44,10 +52,22 @@ __device__ __forceinline__ void asym_apply(const float (&v)[T::VEC], float mn, f
     const float alpha = T::rnd(mx - mn);
     const float e = T::rnd(alpha + 1e-8f);
 #pragma unroll
-    for (int j = 0; j < T::VEC; ++j) {
-        const float n = T::rnd(T::rnd(v[j] - mn) / e);
-        const float q = T::rnd(rintf(T::rnd(n * L)) / L);
-        o[j] = T::rnd(T::rnd(q * e) + mn);
+    for (int j = 0; j < T::VEC; j += 2) {
+        float a = v[j] - mn, b = v[j + 1] - mn;
+        T::rnd2(a, b);
+        a /= e; b /= e;
+        T::rnd2(a, b);
+        a *= L; b *= L;
+        T::rnd2(a, b);
+        a = rintf(a) / L;
+        b = rintf(b) / L;
+        T::rnd2(a, b);
+        a *= e; b *= e;
+        T::rnd2(a, b);
+        a += mn; b += mn;
+        T::rnd2(a, b);
+        o[j] = a;
+        o[j + 1] = b;
     }
 }
 

@@ -34,7 +34,11 @@ __device__ __forceinline__ void quant_vec(const float (&v)[T::VEC], float alpha,
     const float e = T::rnd(alpha + 1e-8f);
     float xs[VEC], xn[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) xs[j] = T::rnd(v[j] - beta);
+    for (int j = 0; j < VEC; j += 2) {   // roundings go pairwise (T::rnd2)
+        xs[j] = v[j] - beta;
+        xs[j + 1] = v[j + 1] - beta;
+        T::rnd2(xs[j], xs[j + 1]);
+    }
     // (w - beta) / e must be the correctly rounded fp32 quotient re-rounded to T.  Fast path:
     // multiply by v_rcp_f32(e) and screen; any lane near a rounding boundary (or out of the
     // normal range) sends the wave through the IEEE divide (~5 % of the iterations).
@@ -53,10 +57,21 @@ __device__ __forceinline__ void quant_vec(const float (&v)[T::VEC], float alpha,
         for (int j = 0; j < VEC; ++j) xn[j] = xs[j] / e;
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        const float q = rintf(T::rnd(T::rnd(xn[j]) * L));
-        const float ql = FASTQ ? q * invL : q / L;
-        o[j] = T::rnd(T::rnd(T::rnd(ql) * e) + beta);
+    for (int j = 0; j < VEC; j += 2) {
+        float a = xn[j], b = xn[j + 1];
+        T::rnd2(a, b);
+        a *= L; b *= L;
+        T::rnd2(a, b);
+        a = rintf(a); b = rintf(b);
+        a = FASTQ ? a * invL : a / L;
+        b = FASTQ ? b * invL : b / L;
+        T::rnd2(a, b);
+        a *= e; b *= e;
+        T::rnd2(a, b);
+        a += beta; b += beta;
+        T::rnd2(a, b);
+        o[j] = a;
+        o[j + 1] = b;
     }
 }
 

@@ -10,6 +10,7 @@ namespace mxq_fq {
 struct F32 {
     static constexpr int VEC = 4;
     __device__ static __forceinline__ float rnd(float x) { return x; }
+    __device__ static __forceinline__ void rnd2(float&, float&) {}
     __device__ static __forceinline__ bool near_boundary(float) { return true; }
     static constexpr bool HAS_FAST_DIV = false;   // fp32 results are not re-rounded: always the IEEE divide
     __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const float*)p + e); }
@@ -27,6 +28,14 @@ struct BF16 {
     // round-to-nearest-even to 8 significant bits: the plain cast compiles to
     // v_cvt_pk_bf16_f32 on gfx950 and keeps NaNs (MI355X_MICROARCH.md, correctness boundaries)
     __device__ static __forceinline__ float rnd(float x) { return (float)(__bf16)x; }
+    // two values per v_cvt_pk_bf16_f32: 1.5 instead of 2 VALU ops per rounding
+    __device__ static __forceinline__ void rnd2(float& a, float& b) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        const bf2 p = {(__bf16)a, (__bf16)b};
+        const uint32_t u = __builtin_bit_cast(uint32_t, p);
+        a = __uint_as_float(u << 16);
+        b = __uint_as_float(u & 0xFFFF0000u);
+    }
     // fast-division screen: fl32(x * rcp(e)) rounds to the same bf16 as the correctly rounded
     // fl32(x / e) unless it lies within a few fp32 ulps of a bf16 rounding boundary
     // (no range test needed: e = bf16(alpha + 1e-8) is a positive normal number, bf16 has fp32's
@@ -57,6 +66,10 @@ struct BF16 {
 struct F16 {
     static constexpr int VEC = 8;
     __device__ static __forceinline__ float rnd(float x) { return (float)(_Float16)x; }
+    __device__ static __forceinline__ void rnd2(float& a, float& b) {
+        a = (float)(_Float16)a;
+        b = (float)(_Float16)b;
+    }
     __device__ static __forceinline__ bool near_boundary(float a) {   // 11 significant bits; no shortcut in the
         const uint32_t u = __float_as_uint(a);                          // fp16-subnormal range
         return ((u & 0x1FFFu) - 0x0FFCu) < 8u || !(a == 0.0f || (a > 6.2e-5f && a < 6.0e4f));
