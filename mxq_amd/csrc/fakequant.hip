@@ -75,33 +75,35 @@ __device__ __forceinline__ void quant_vec(const float (&v)[T::VEC], float alpha,
     }
 }
 
-// Register-resident variant for rows of up to NI * 64 * VEC elements (16-bit dtypes, cols <=
-// 4096): the row is loaded ONCE with all its 16-B loads in flight, the 4-bit-arm min/max and
-// the group min/max come from registers, then everything is quantised and stored.  HBM sees
+// Register-resident variant (16-bit dtypes): a row is split over WPR waves of the workgroup (1, 2 or 4; each
+// part a multiple of 64 columns and at most NI * 64 * VEC = 4096 elements), every part is loaded ONCE with all
+// its 16-B loads in flight, the 4-bit-arm min/max comes from registers (combined across the row's waves
+// through LDS when WPR > 1) and so do the group min/max; then everything is quantised and stored.  HBM sees
 // exactly one read and one write per element and no second pass exists.
-template <typename T, bool FASTQ, int NI>
+template <typename T, bool FASTQ, int NI, int WPR>
 __global__ __launch_bounds__(256) void mxq_fakequant_fwd_reg_kernel(const void* __restrict__ w,
                                                                     void* __restrict__ out, int rows, int cols,
                                                                     float L2) {
     constexpr int VEC = T::VEC;
     constexpr int LPG = 16 / VEC;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;   // wave-uniform
-    const int64_t base = (int64_t)row * cols;
-    uint4 raw[NI];   // the row stays in its storage format: 4 VGPRs per 16-B load
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * (4 / WPR) + wave / WPR;
+    const bool active = row < rows;   // wave-uniform; inactive waves still reach the barrier below
+    const int part = cols / WPR;
+    const int64_t base = (int64_t)row * cols + (wave % WPR) * part;
+    uint4 raw[NI];   // the part stays in its storage format: 4 VGPRs per 16-B load
     const bool is4 = ((lane * VEC) & 63) >= 48;   // 64 * VEC elements per iteration keep the chunk phase
     float mn4 = INFINITY, mx4 = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int e0 = (i * 64 + lane) * VEC;
         raw[i] = make_uint4(0, 0, 0, 0);
-        if (e0 < cols) raw[i] = T::load_raw(w, base + e0);
+        if (active && e0 < part) raw[i] = T::load_raw(w, base + e0);
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int e0 = (i * 64 + lane) * VEC;
-        if (e0 < cols && is4) {
+        if (active && e0 < part && is4) {
             float t[VEC];
             T::unpack(raw[i], t);
 #pragma unroll
@@ -113,11 +115,26 @@ __global__ __launch_bounds__(256) void mxq_fakequant_fwd_reg_kernel(const void* 
         mn4 = fminf(mn4, __shfl_xor(mn4, o, 64));
         mx4 = fmaxf(mx4, __shfl_xor(mx4, o, 64));
     }
+    if constexpr (WPR > 1) {
+        __shared__ float part_mn[4], part_mx[4];
+        if (lane == 0) {
+            part_mn[wave] = mn4;
+            part_mx[wave] = mx4;
+        }
+        __syncthreads();
+        const int w0 = wave / WPR * WPR;
+#pragma unroll
+        for (int k = 0; k < WPR; ++k) {
+            mn4 = fminf(mn4, part_mn[w0 + k]);
+            mx4 = fmaxf(mx4, part_mx[w0 + k]);
+        }
+    }
+    if (!active) return;
     const float alpha4 = T::rnd(mx4 - mn4);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int e0 = (i * 64 + lane) * VEC;
-        if (e0 < cols) {   // a 16-column group is never split by the row end (cols % 64 == 0)
+        if (e0 < part) {   // a 16-column group is never split by the part end (part % 64 == 0)
             float vi[VEC];
             T::unpack(raw[i], vi);
             float mn = vi[0], mx = vi[0];
@@ -227,10 +244,15 @@ int launch_fwd(const void* w, void* out, int rows, int cols, int num_bits, int d
     const float L2 = host_rnd((float)(exp2((double)num_bits) - 1.0), dtype);
     const bool fastq = mul_matches_div(L2, dtype) && mul_matches_div(15.0f, dtype);
     const dim3 grid((rows + 3) / 4);
-    if (fastq && T::VEC == 8 && cols <= 8 * 512)
-        mxq_fakequant_fwd_reg_kernel<T, true, 8><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
-    // (a 24-iteration instance for rows up to 12288 columns was measured slower than the two-pass
+    // register-resident whenever a row splits into 1, 2 or 4 parts of whole 64-column chunks of <= 4096 elements
+    // (a single-wave 24-iteration instance for rows up to 12288 columns was measured slower than the two-pass
     // kernel: hipcc keeps the unpacked row live, 231 VGPRs, 2 waves/SIMD)
+    if (fastq && T::VEC == 8 && cols <= 4096)
+        mxq_fakequant_fwd_reg_kernel<T, true, 8, 1><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
+    else if (fastq && T::VEC == 8 && cols <= 8192 && cols % 128 == 0)
+        mxq_fakequant_fwd_reg_kernel<T, true, 8, 2><<<(rows + 1) / 2, 256, 0, stream>>>(w, out, rows, cols, L2);
+    else if (fastq && T::VEC == 8 && cols <= 16384 && cols % 256 == 0)
+        mxq_fakequant_fwd_reg_kernel<T, true, 8, 4><<<rows, 256, 0, stream>>>(w, out, rows, cols, L2);
     else if (fastq) mxq_fakequant_fwd_kernel<T, true><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
     else mxq_fakequant_fwd_kernel<T, false><<<grid, 256, 0, stream>>>(w, out, rows, cols, L2);
     return (int)hipGetLastError();

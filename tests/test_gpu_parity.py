@@ -439,7 +439,10 @@ def test_g3_fakequant_llama_width(dev, g3, K):
     assert np.array_equal(_bits(out), g3[f"bf16_K{K}_out"])
 
 
-@pytest.mark.parametrize("shape,dt", [((4096, 4096), "bf16"), ((1000, 11008), "bf16"), ((512, 4096), "fp32")])
+@pytest.mark.parametrize("shape,dt", [((4096, 4096), "bf16"), ((1000, 11008), "bf16"), ((512, 4096), "fp32"),
+                                      ((1001, 8192), "bf16"),      # row split over 2 waves, odd row count
+                                      ((37, 16384), "bf16"),       # 4 waves per row at the register kernel's limit
+                                      ((64, 12352), "bf16")])      # 193 chunks: not splittable -> two-pass kernel
 def test_fakequant_full_size_properties(dev, shape, dt):
     """Config-4 shapes: idempotence (fake-quant of a fake-quant weight in fp32 is the
     identity up to one rounding), per-group level count, and agreement of a row sample
