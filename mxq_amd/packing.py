@@ -35,16 +35,16 @@ _WORKSPACES: Dict[tuple, torch.Tensor] = {}
 def gemm_workspace(device: torch.device) -> torch.Tensor:
     """Scratch buffer of the stream-K prefill GEMM (include/mxq_hip.h: mxq_linear_f16_ws), one per
     (device, stream): launches on one stream run in order and may share it, launches on different
-    streams may not.  Zeroed once here; the kernels leave its counters zeroed."""
+    streams may not.  Its counter head is zeroed once here; the kernels leave it zeroed."""
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("run one prefill-sized mxq_amd.linear() on this stream before capturing a graph "
-                               "(the GEMM workspace cannot be allocated during capture)")
         nbytes = _lib.load().mxq_gemm_workspace_bytes()
-        ws = _WORKSPACES[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        # (under graph capture the stream is the capture's own: the buffer comes from the graph's private pool
+        # and the 64 KiB counter head is zeroed by a captured memset, i.e. again on every replay)
+        ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ws[:65536].zero_()
     return ws
 
 

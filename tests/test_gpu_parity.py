@@ -196,6 +196,34 @@ def test_gemm_stream_k_tail(dev, M, N, K):
     assert torch.equal(packing.linear(xd, p, path="gemm6"), yd)
 
 
+def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):
+    """The stream-K GEMM leaves its workspace counters zeroed, so a captured launch can be replayed; and
+    launches on different streams use different workspaces, so they may overlap."""
+    from mxq_amd import packing
+    p, w16, g = _packed_case(dev, 2048, 4096, 5)
+    x = torch.randn(512, 4096, generator=g).half().to(dev)
+    ref = packing.linear(x, p, path="gemm7")                      # warm-up: allocates this stream's workspace
+    out = torch.empty_like(ref)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        packing.linear(x, p, out=out, path="gemm7")
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for s in (s1, s2):
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            outs.append([packing.linear(x, p, path="gemm7") for _ in range(8)])
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for lst in outs for o in lst)
+    keys = {k for k in packing._WORKSPACES if k[0] == x.device.index}
+    assert len(keys) >= 3                                          # default stream + two side streams
+
+
 def test_linear_empty_and_nonfinite_inputs(dev):
     """Empty token dimension returns an empty result without a launch; a NaN / inf activation poisons exactly
     its own token row, on the GEMV, the single-tile GEMM and the stream-K GEMM alike (no cross-row leakage
