@@ -196,6 +196,29 @@ def test_gemm_stream_k_tail(dev, M, N, K):
     assert torch.equal(packing.linear(xd, p, path="gemm6"), yd)
 
 
+def test_stream_k_partition_fuzz(dev):
+    """Random (tokens, out, in) shapes through the forced stream-K schedule against the single-tile kernel:
+    exercises unit ranges that start / end anywhere inside tiles, XCDs with unequal tail lengths, units with
+    one, two and many segments, ragged M and N edges."""
+    from mxq_amd import packing
+    rng = np.random.default_rng(2026)
+    g = torch.Generator(device=dev).manual_seed(9)
+    for _ in range(24):
+        M = int(rng.integers(5, 1500))
+        N = 16 * int(rng.integers(1, 200))
+        K = 64 * int(rng.choice([2, 3, 8, 16, 33, 64, 100, 172]))
+        W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
+        p = packing.quantize_pack(W)
+        x = torch.randn(M, K, generator=g, device=dev).half()
+        y = packing.linear(x, p, path="gemm7").float()
+        r = (x.float() @ packing.dequant(p).float().t())
+        err = ((y - r).abs().max() / r.abs().max()).item()
+        assert err <= REL_TOL, (M, N, K, err)
+        assert torch.equal(packing.linear(x, p, path="gemm7").float(), y), (M, N, K)
+    ws = packing.gemm_workspace(torch.device(dev))
+    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
+
+
 def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):
     """The stream-K GEMM leaves its workspace counters zeroed, so a captured launch can be replayed; and
     launches on different streams use different workspaces, so they may overlap."""
