@@ -28,7 +28,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
                                                                   const float* __restrict__ cos_t,
                                                                   const float* __restrict__ sin_t,
                                                                   uint16_t* __restrict__ out, int heads, int max_ctx) {
-    extern __shared__ float sm[];          // q[HD], scores[max_ctx], red[8], o2[2*HD]
+    extern __shared__ float sm[];          // q[HD], scores[max_ctx], red[8], o2[16*HD]
     float* q_s = sm;
     float* sc = sm + HD;
     float* red = sc + max_ctx;
@@ -98,13 +98,31 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
     __syncthreads();
     const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
 
-    // out[d] = sum_j p_j * V[j][d]; two halves of the key range per dim
-    const int d = tid & (HD - 1), half = tid >> 7;
-    float o = 0.f;
-    for (int j = half; j <= pos; j += 2) o += h2f(f2h(sc[j] * inv)) * h2f(vc[(int64_t)j * HD + d]);
-    o2[tid] = o;
+    // out[d] = sum_j p_j * V[j][d]: 16 key groups x 16 lanes of 8 dims (one 256-B V row per 16 lanes and load);
+    // a thread walks keys kg, kg + 16, ... so position 64 is 4 iterations deep instead of 32
+    const int dg = tid & 15, kg = tid >> 4;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int j = kg; j <= pos; j += 16) {
+        const float p = h2f(f2h(sc[j] * inv));
+        const uint4 w = *(const uint4*)(vc + (int64_t)j * HD + dg * 8);
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[2 * e] += p * h2f((uint16_t)(ws[e] & 0xFFFF));
+            o[2 * e + 1] += p * h2f((uint16_t)(ws[e] >> 16));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o2[kg * HD + dg * 8 + e] = o[e];
     __syncthreads();
-    if (tid < HD) out[h * HD + tid] = f2h(o2[tid] + o2[tid + HD]);
+    if (tid < HD) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += o2[g * HD + tid];
+        out[h * HD + tid] = f2h(t);
+    }
 }
 
 }   // namespace
@@ -113,7 +131,7 @@ int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, co
                                const void* sin_t, void* out, int heads, int head_dim, int max_ctx,
                                hipStream_t stream) {
     if (head_dim != HD) return (int)hipErrorInvalidValue;
-    const size_t smem = (size_t)(HD + max_ctx + 8 + 2 * HD) * 4;
+    const size_t smem = (size_t)(HD + max_ctx + 8 + 16 * HD) * 4;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)smem);
