@@ -8,7 +8,8 @@
 // host (mxq_amd/utils_quant.py) and reach the kernels as plain geometry:
 //   * group kernel: 2-D [rows, cols], groups of 8 / 128 consecutive columns; columns at or beyond
 //     `covered` (= cols rounded down to a whole group) get the range 0 the reference leaves there;
-//   * segment kernels: n_seg contiguous segments of seg_len elements (a token row of a 3-D activation,
+//   * row kernel (segments of <= 4096 elements, >= 1024 of them: one wave per segment, one pass) and
+//     segment kernels: n_seg contiguous segments of seg_len elements (a token row of a 3-D activation,
 //     a (batch, head) slab of a 4-D tensor, or the whole tensor for layerwise=True); segment i is "live"
 //     iff i % period < live, the others get range 0 (3-D inputs: the reference slices dim 1 with a group
 //     count derived from the last dim, so only the first `live` tokens of every sequence are ranged).
@@ -186,6 +187,62 @@ __global__ __launch_bounds__(256) void mxq_actquant_apply_kernel(const void* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// row kernel: segments of up to NI * 64 * VEC elements (4096 for 16-bit dtypes: a token row at Llama's hidden
+// size) stay in registers -- one wave per segment, one HBM read, no scratch, no second launch
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool SYM, int NI>
+__global__ __launch_bounds__(256) void mxq_actquant_row_kernel(const void* __restrict__ x, void* __restrict__ out,
+                                                               int64_t n_seg, int seg_len, int64_t period, int64_t live,
+                                                               float lv) {
+    constexpr int VEC = T::VEC;
+    const int lane = threadIdx.x & 63;
+    const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seg >= n_seg) return;   // wave-uniform
+    const int64_t base = seg * seg_len;
+    uint4 raw[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e0 = (i * 64 + lane) * VEC;
+        raw[i] = make_uint4(0, 0, 0, 0);
+        if (e0 < seg_len) raw[i] = T::load_raw(x, base + e0);
+    }
+    float mx = SYM ? 0.f : -INFINITY, mn = INFINITY;
+    if (seg % period < live) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e0 = (i * 64 + lane) * VEC;
+            if (e0 < seg_len) {
+                float v[VEC];
+                T::unpack(raw[i], v);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    mx = nan_max(mx, SYM ? fabsf(v[j]) : v[j]);
+                    if (!SYM) mn = nan_min(mn, v[j]);
+                }
+            }
+        }
+        for (int d = 1; d < 64; d <<= 1) {
+            mx = nan_max(mx, __shfl_xor(mx, d));
+            if (!SYM) mn = nan_min(mn, __shfl_xor(mn, d));
+        }
+    } else {
+        mx = 0.f;
+        mn = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e0 = (i * 64 + lane) * VEC;
+        if (e0 < seg_len) {
+            float v[VEC], o[VEC];
+            T::unpack(raw[i], v);
+            if (SYM) sym_apply<T>(v, mx, lv, o);
+            else asym_apply<T>(v, mn, mx, lv, o);
+            T::store(out, base + e0, o);
+        }
+    }
+}
+
 template <typename T, bool SYM>
 int launch_group(const void* x, void* out, int64_t rows, int cols, int group, float lv, hipStream_t stream) {
     const int lpg = group / T::VEC;
@@ -200,6 +257,11 @@ int launch_group(const void* x, void* out, int64_t rows, int cols, int group, fl
 template <typename T, bool SYM>
 int launch_seg(const void* x, void* out, void* range_ws, int64_t n_seg, int64_t seg_len, int64_t period, int64_t live,
                float lv, hipStream_t stream) {
+    if (seg_len <= 8 * 64 * T::VEC && n_seg >= 1024) {   // enough rows to fill the chip with one wave each
+        mxq_actquant_row_kernel<T, SYM, 8><<<(unsigned)((n_seg + 3) / 4), 256, 0, stream>>>(x, out, n_seg, (int)seg_len,
+                                                                                          period, live, lv);
+        return (int)hipGetLastError();
+    }
     const int64_t per_chunk = (int64_t)256 * T::VEC * SEG_UNROLL;
     const int chunks = (int)((seg_len + per_chunk - 1) / per_chunk);
     hipError_t e = hipMemsetAsync(range_ws, 0, (size_t)n_seg * 8, stream);   // key 0 is below every float's key

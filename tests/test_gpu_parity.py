@@ -573,7 +573,9 @@ def test_g9_activation_quantizers_16bit_hip(dev, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape,lw", [((2, 512, 4096), False),      # activations of a Llama block: one range per token
+@pytest.mark.parametrize("shape,lw", [((2, 512, 4096), False),      # activations of a Llama block: one range per token (row kernel)
+                                       ((1, 1100, 1024), False),     # row kernel with the reference's un-ranged tail tokens (1024 < 1100)
+                                       ((4, 64, 4096), False),       # too few rows for the row kernel: two-pass path
                                        ((1, 32, 256, 128), False),   # KV cache: one range per head, 32 K elements each
                                        ((64, 11008), False),         # 2-D groups at Llama's MLP width
                                        ((3, 100, 4096), True)])      # layerwise: a single 1.2 M-element segment
