@@ -187,3 +187,38 @@ def test_prepare_calibration_input_and_check_sparsity():
     lines = []
     assert check_sparsity(m, log=lines.append) == pytest.approx(0.125)
     assert lines == ["layer 0 sparsity 0.000000", "layer 1 sparsity 0.250000"]
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/LLM-QAT/models"),
+                    reason="needs the read-only reference checkout (build container only)")
+def test_reference_modeling_file_imports_against_this_utils_quant():
+    """with ``models.utils_quant`` aliased to mxq_amd.utils_quant, the reference's
+    own modeling_llama_quant.py imports and builds its decoder layer out of THIS repo's QuantizeLinear, with
+    the state_dict keys the reference checkpoints use.  (Forward / backward parity of that layer is golden G5
+    on the GPU.)  Runs in a subprocess so the aliasing does not leak into other tests."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.dont_write_bytecode = True
+sys.path.insert(0, %r)
+import mxq_amd.utils_quant as uq
+sys.path.insert(0, "/root/reference/LLM-QAT")
+sys.modules["models.utils_quant"] = uq
+import importlib
+m = importlib.import_module("models.modeling_llama_quant")
+from models.configuration_llama import LlamaConfig
+cfg = LlamaConfig(hidden_size=256, intermediate_size=704, num_attention_heads=4, num_hidden_layers=1, vocab_size=128)
+cfg.w_bits, cfg.a_bits, cfg.kv_bits = 2, 16, 16
+layer = m.LlamaDecoderLayer(cfg)
+lin = [layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj, layer.self_attn.o_proj,
+       layer.mlp.gate_proj, layer.mlp.up_proj, layer.mlp.down_proj]
+assert all(type(l) is uq.QuantizeLinear and l.w_bits == 2 and l.a_bits == 16 for l in lin)
+assert m.SymQuantizer is uq.SymQuantizer and lin[0].act_quantizer is uq.SymQuantizer
+keys = set(layer.state_dict())
+assert {"self_attn.q_proj.weight", "mlp.down_proj.weight", "input_layernorm.weight"} <= keys
+assert not any(k.endswith(".bias") for k in keys)
+print("OK")
+''' % (__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))),)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stderr[-2000:]
