@@ -134,8 +134,11 @@ int mxq_quantize_pack_layout(const void* W, int w_dtype, void* qweight, void* ro
  * [N] and qs / qz [N/16] for W4ROW). */
 int mxq_expand_layout(const void* qweight, const void* rowmeta, void* w16, uint8_t* codes, uint8_t* sc, float* zero,
                       float* qs, float* qz, int N, int K, int layout, void* stream);
-/* MFMA dequant-GEMM (the wave-specialised kernel) on any layout. */
+/* MFMA dequant-GEMM (the wave-specialised kernel) and the streaming GEMV (M <= 4 tokens) on any layout:
+ * one kernel template each, the layouts differ in the field offsets and in the group / quarter loop. */
 int mxq_gemm_f16_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                        int layout, void* stream);
+int mxq_gemv_f16_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         int layout, void* stream);
 
 /* Decode-time variant of mxq_gemv_f16 for ONE token with the neighbouring elementwise ops of a

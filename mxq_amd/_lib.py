@@ -47,6 +47,7 @@ SIGNATURES = {
     "mxq_quantize_pack_layout": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mxq_expand_layout": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "mxq_gemm_f16_layout": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "mxq_gemv_f16_layout": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_gemv_fused_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "mxq_attn_decode_f16": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     "mxq_fakequant_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -151,6 +151,13 @@ int mxq_expand_layout(const void* qweight, const void* rowmeta, void* w16, uint8
                                      (hipStream_t)stream);
 }
 
+int mxq_gemv_f16_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                        int layout, void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    if (!layout_ok(layout) || M > 4) return MXQ_E_SHAPE;
+    return mxq_launch_gemv_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
+}
+
 int mxq_gemm_f16_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         int layout, void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;

@@ -38,7 +38,9 @@ __device__ __forceinline__ float dot8(const uint32_t* w, const uint4 xa, float a
 //   recomputes the 4096-element reduction -- cheaper than a separate launch);
 //   2 = SwiGLU gate: the input row is [2K] = (gate, up) and x <- fp16(silu(gate)) * up.
 // residual (nullable): y <- residual + W.x (the decoder layer's skip connection).
-template <int MB, int GEMV_THREADS, int PRO>
+// LAYOUT: MXQ_LAYOUT_MIXED (3 two-bit groups + the 4-bit quarter per chunk), MXQ_LAYOUT_W2G16 (4 two-bit groups)
+// or MXQ_LAYOUT_W4ROW (4 four-bit quarters, scale / zero per row from rowmeta): csrc/mxq_format.h.
+template <int MB, int GEMV_THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED>
 __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16_t* __restrict__ x,
                                                                      const uint32_t* __restrict__ qweight,
                                                                      const float4* __restrict__ rowmeta,
@@ -52,28 +54,38 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     const int rb = blockIdx.x;
     const int NC = K / 64, NC4 = (NC + 3) / 4;
 
-    // packed operands of one (row, chunk): 13 registers, loaded straight from HBM
+    // packed operands of one (row, chunk): 13 registers (mixed layout), loaded straight from HBM
+    constexpr int NG2 = LAYOUT == MXQ_LAYOUT_MIXED ? 3 : LAYOUT == MXQ_LAYOUT_W2G16 ? 4 : 0;   // two-bit groups per chunk
+    constexpr int NW4 = LAYOUT == MXQ_LAYOUT_MIXED ? 2 : LAYOUT == MXQ_LAYOUT_W4ROW ? 8 : 0;   // four-bit code words per chunk
+    constexpr int BLK_DW = LAYOUT == MXQ_LAYOUT_W4ROW ? 128 : MXQ_BLK_DW;
     struct Tile {
-        uint32_t c2w[3], z2w[3], c4w[2], scw;
-        uint2 qq[3];
+        uint32_t c2w[NG2 ? NG2 : 1], z2w[NG2 ? NG2 : 1], c4w[NW4 ? NW4 : 1], scw;
+        uint2 qq[NG2 ? NG2 : 1];
     };
-    const uint32_t* tiles = qweight + (int64_t)rb * NC * MXQ_BLK_DW;
+    const uint32_t* tiles = qweight + (int64_t)rb * NC * BLK_DW;
     auto load_tile = [&](int c4) {
         Tile t = {};
         const int chunk = c4 * 4 + cs;
         if (chunk < NC) {   // ragged tail: K/64 not a multiple of 4
             // the wave reads 4 consecutive blocks = 2304 contiguous bytes; each load touches
             // four 64-B segments (one per chunk slot)
-            const uint32_t* tile = tiles + (int64_t)chunk * MXQ_BLK_DW;
+            const uint32_t* tile = tiles + (int64_t)chunk * BLK_DW;
+            if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                t.c2w[g] = tile[mxq_c2(g, r)];
-                t.z2w[g] = tile[mxq_z2(g, r)];
-                t.qq[g] = *(const uint2*)(tile + mxq_qq(g));
+                for (int i = 0; i < 8; ++i) t.c4w[i] = tile[mxq_w4_c4(i >> 1, i & 1, r)];
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG2; ++g) {
+                    t.c2w[g] = tile[LAYOUT == MXQ_LAYOUT_MIXED ? mxq_c2(g, r) : mxq_w2_c2(g, r)];
+                    t.z2w[g] = tile[LAYOUT == MXQ_LAYOUT_MIXED ? mxq_z2(g, r) : mxq_w2_z2(g, r)];
+                    t.qq[g] = *(const uint2*)(tile + mxq_qq(g));      // SC / QQ sit at the same offsets in both layouts
+                }
+                if constexpr (LAYOUT == MXQ_LAYOUT_MIXED) {
+                    t.c4w[0] = tile[mxq_c4(0, r)];
+                    t.c4w[1] = tile[mxq_c4(1, r)];
+                }
+                t.scw = ((const uint16_t*)tile)[mxq_sc_u16(r)];
             }
-            t.c4w[0] = tile[mxq_c4(0, r)];
-            t.c4w[1] = tile[mxq_c4(1, r)];
-            t.scw = ((const uint16_t*)tile)[mxq_sc_u16(r)];
         }
         return t;
     };
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
             const char* xk = smem + (size_t)chunk * 128;
             uint32_t o[8];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
+            for (int g = 0; g < NG2; ++g) {
                 mxq_deq2x16(cur.c2w[g],
                             mxq_scale(__uint_as_float(cur.qq[g].x), __uint_as_float(cur.qq[g].y),
                                       (cur.scw >> (4 * g)) & 15u),
@@ -157,14 +169,18 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
                     acc[m] = dot8(o + 4, xb, acc[m]);
                 }
             }
-            mxq_deq4x8(cur.c4w[0], s4, z4, o);
-            mxq_deq4x8(cur.c4w[1], s4, z4, o + 4);
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + 96);
-                const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + 112);
-                acc[m] = dot8(o, xa, acc[m]);
-                acc[m] = dot8(o + 4, xb, acc[m]);
+            for (int q = 0; q < NW4 / 2; ++q) {      // 16 four-bit weights per pair of code words
+                constexpr int X0 = LAYOUT == MXQ_LAYOUT_MIXED ? 96 : 0;   // the mixed layout's quarter is the chunk's last
+                mxq_deq4x8(cur.c4w[2 * q], s4, z4, o);
+                mxq_deq4x8(cur.c4w[2 * q + 1], s4, z4, o + 4);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + X0 + q * 32);
+                    const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + X0 + q * 32 + 16);
+                    acc[m] = dot8(o, xa, acc[m]);
+                    acc[m] = dot8(o + 4, xb, acc[m]);
+                }
             }
         }
         cur = nxt;
@@ -193,25 +209,35 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     }
 }
 
-template <int MB, int THREADS, int PRO>
+template <int MB, int THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED>
 int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
              const void* norm_w, float eps, const void* residual, hipStream_t stream) {
     const size_t smem = (size_t)MB * K * 2 + (size_t)(THREADS / 64) * MB * 16 * 4;
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB, THREADS, PRO>,
+        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    mxq_gemv_f16_kernel<MB, THREADS, PRO><<<N / 16, THREADS, smem, stream>>>(
+    mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT><<<N / 16, THREADS, smem, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K,
         (const uint16_t*)norm_w, eps, (const uint16_t*)residual);
     return (int)hipGetLastError();
 }
 
-template <int MB>
+template <int MB, int LAYOUT = MXQ_LAYOUT_MIXED>
 int launch(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream) {
-    if (N / 16 <= 384) return launch_t<MB, 1024, 0>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
-    return launch_t<MB, 512, 0>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
+    if (N / 16 <= 384)
+        return launch_t<MB, 1024, 0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
+    return launch_t<MB, 512, 0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
+}
+
+template <int LAYOUT>
+int launch_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                  hipStream_t stream) {
+    if (M == 1) return launch<1, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream);
+    if (M == 2) return launch<2, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream);
+    if (M <= 4) return launch<4, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream);
+    return (int)hipErrorInvalidValue;
 }
 
 }   // namespace
@@ -221,6 +247,16 @@ int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta,
     if (M == 1) return launch<1>(x, qweight, rowmeta, y, M, N, K, stream);
     if (M == 2) return launch<2>(x, qweight, rowmeta, y, M, N, K, stream);
     if (M <= 4) return launch<4>(x, qweight, rowmeta, y, M, N, K, stream);
+    return (int)hipErrorInvalidValue;
+}
+
+int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                               int layout, hipStream_t stream) {
+    switch (layout) {
+        case MXQ_LAYOUT_MIXED: return launch_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_W2G16: return launch_layout<MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_W4ROW: return launch_layout<MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, stream);
+    }
     return (int)hipErrorInvalidValue;
 }
 

@@ -45,6 +45,8 @@ int mxq_launch_gemm4_ablate_f16(const void* x, const void* qweight, const void* 
                                 int K, int abl, hipStream_t stream);   // profiling only
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream);
+int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+                               int K, int layout, hipStream_t stream);
 int mxq_launch_gemm4_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
                                 int K, int layout, hipStream_t stream);
 int mxq_launch_quantize_uniform(const void* W, int dtype, void* qweight, void* rowmeta, int N, int K, int layout,

@@ -294,11 +294,12 @@ def expand_uniform(p: PackedUniform, codes: bool = True):
     return w16, out
 
 
-def linear_layout(x: torch.Tensor, p, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """MFMA dequant-GEMM on a PackedMXQ (mixed) or PackedUniform weight, any token count."""
+def linear_layout(x: torch.Tensor, p, out: Optional[torch.Tensor] = None, path: str = "gemm") -> torch.Tensor:
+    """Quantised Linear on a PackedMXQ (mixed) or PackedUniform weight: path "gemm" = MFMA dequant-GEMM at any
+    token count, "gemv" = the streaming GEMV (<= 4 tokens), "auto" = GEMV up to 4 tokens, GEMM beyond."""
     layout = LAYOUTS[getattr(p, "layout", "mixed")]
     if layout == 0:
-        return linear(x, p, out=out, path="gemm")      # the mixed layout's default (fastest) kernel
+        return linear(x, p, out=out, path=path)        # the mixed layout's default (fastest) kernels
     _need_gpu(x, p.qweight)
     if x.dtype != torch.float16 or x.shape[-1] != p.K:
         raise ValueError("activations must be fp16 [..., in_features]")
@@ -306,8 +307,14 @@ def linear_layout(x: torch.Tensor, p, out: Optional[torch.Tensor] = None) -> tor
     M = x2.shape[0]
     if out is None:
         out = torch.empty((M, p.N), dtype=torch.float16, device=x.device)
+    if path not in ("gemm", "gemv", "auto"):
+        raise ValueError(f"unknown path {path!r}")
     lib = _lib.load()
+    fn, what = ((lib.mxq_gemv_f16_layout, "mxq_gemv_f16_layout") if path == "gemv" or (path == "auto" and M <= 4)
+                else (lib.mxq_gemm_f16_layout, "mxq_gemm_f16_layout"))
+    if M == 0:
+        return out.reshape(*x.shape[:-1], p.N)
     with torch.cuda.device(x.device):
-        _lib.check(lib.mxq_gemm_f16_layout(x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M,
-                                           p.N, p.K, layout, _stream(x2)), "mxq_gemm_f16_layout")
+        _lib.check(fn(x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K, layout,
+                      _stream(x2)), what)
     return out.reshape(*x.shape[:-1], p.N)

@@ -759,6 +759,25 @@ def test_g8_uniform_quantize_unpack_dequant(dev, layout, pre):
 
 
 @pytest.mark.parametrize("layout", ["w2g16", "w4row"])
+@pytest.mark.parametrize("M,N,K", [(1, 64, 256), (3, 256, 704), (4, 4096, 4096), (1, 4096, 11008)])
+def test_uniform_gemv_vs_oracle(dev, layout, M, N, K):
+    """The decode GEMV template on the uniform W2 / W4 layouts (BASELINE config 5 arms), against the oracle's
+    dequantised weight; ragged K (704 = 11 chunks) exercises the partial last tile."""
+    from mxq_amd import packing
+    g = torch.Generator().manual_seed(N + K + M)
+    W16 = (torch.randn(N, K, generator=g) * 0.02).half()
+    ref = O.uniform_quantize(W16.numpy(), layout)
+    p = packing.quantize_pack_uniform(W16.to(dev), layout)
+    x = torch.randn(M, K, generator=g).half()
+    y = packing.linear_layout(x.to(dev), p, path="gemv").cpu().numpy()
+    _check_gemm(y, O.linear_ref(x.numpy(), ref["w_deq32"].astype(np.float16)), f"gemv {layout} {M}x{N}x{K}")
+    ya = packing.linear_layout(x.to(dev), p, path="auto").cpu().numpy()
+    assert np.array_equal(ya, y)
+    with pytest.raises(ValueError):
+        packing.linear_layout(torch.zeros(5, K, dtype=torch.float16, device=dev), p, path="gemv")
+
+
+@pytest.mark.parametrize("layout", ["w2g16", "w4row"])
 @pytest.mark.parametrize("M,N,K", [(300, 144, 192), (512, 256, 1024), (64, 4096, 4096)])
 def test_uniform_gemm_vs_oracle(dev, layout, M, N, K):
     from mxq_amd import packing
