@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse", action="store_true",
+                    help="NOT the headline configuration: q|k|v and gate|up as one launch each (5 launches per layer "
+                         "instead of 7; same weights, same FLOPs), reported with config.fused_launches = true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,11 +124,16 @@ def main():
 
     my_layers = list(LS.layer_range(rank, world))
     layers = build_layers(my_layers, dev)
+    if args.fuse:   # LAYER_LINEARS order: q, k, v, o, gate, up, down
+        layers = [[("qkv", packing.concat_packed([p for _, p in lin[0:3]])), lin[3],
+                   ("gate_up", packing.concat_packed([p for _, p in lin[4:6]])), lin[6]] for lin in layers]
+    launches_per_layer = len(layers[0]) if layers else 0
     gx = torch.Generator(device=dev).manual_seed(7)
     x_h = torch.randn(SEQ, LS.HIDDEN, generator=gx, device=dev).half()          # hidden-width input
     x_i = torch.randn(SEQ, LS.INTERMEDIATE, generator=gx, device=dev).half()    # down_proj input
     y_h = torch.empty(SEQ, LS.HIDDEN, device=dev, dtype=torch.float16)
     y_i = torch.empty(SEQ, LS.INTERMEDIATE, device=dev, dtype=torch.float16)
+    y_f = {N: torch.empty(SEQ, N, device=dev, dtype=torch.float16) for N in (3 * LS.HIDDEN, 2 * LS.INTERMEDIATE)} if args.fuse else {}
     recv_buf = torch.empty_like(x_h)
     n_micro = world          # sequences in flight per step: per-GPU work stays one full-model pass
 
@@ -133,7 +141,7 @@ def main():
         for lin in layers:
             for name, p in lin:
                 x = x_i if p.K == LS.INTERMEDIATE else x_hidden
-                packing.linear(x, p, out=(y_i if p.N == LS.INTERMEDIATE else y_h), path="gemm")
+                packing.linear(x, p, out=(y_f[p.N] if p.N in y_f else y_i if p.N == LS.INTERMEDIATE else y_h), path="gemm")
 
     # N > 1: the schedule is mxq_amd.pipeline.LayerPipeline's (the same object the gloo tests drive on CPU):
     # per micro-batch recv from rank-1 -> this rank's layers -> send to rank+1
@@ -175,7 +183,7 @@ def main():
     tokens_per_step = SEQ * n_micro
     flops_per_step = LS.linear_flops(SEQ) * n_micro                      # whole job
     flops_rank_step = LS.linear_flops(SEQ, len(my_layers)) * n_micro     # this rank's launches
-    launches_rank_step = 7 * len(my_layers) * n_micro
+    launches_rank_step = launches_per_layer * len(my_layers) * n_micro
     ms_per_step = elapsed / args.steps * 1e3
     value = flops_per_step / (elapsed / args.steps) / 1e12
     kern_ms = dev_ms / args.steps / launches_rank_step
@@ -198,6 +206,7 @@ def main():
                                    "(48x2b+16x4b per 64), fp16 activations, fp32 accumulate",
                        "tokens_per_step": tokens_per_step, "flop_per_step": flops_per_step,
                        "weight_format": "mxq-v1 exact metadata", "bits_per_weight": round(bpw, 3),
+                       "fused_launches": bool(args.fuse),
                        "parallelism": "single GPU" if world == 1 else
                        f"pp{world}: whole layers sharded, {world} sequences in flight, RCCL send/recv of the "
                        f"[2048,4096] fp16 hidden state"},

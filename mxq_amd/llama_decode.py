@@ -22,10 +22,7 @@ from . import llama_shapes as LS
 from . import packing
 
 
-def _concat_packed(ps: List[packing.PackedMXQ]) -> packing.PackedMXQ:
-    K = ps[0].K
-    return packing.PackedMXQ(torch.cat([p.qweight for p in ps]), torch.cat([p.rowmeta for p in ps]),
-                             sum(p.N for p in ps), K)
+_concat_packed = packing.concat_packed
 
 
 class DecodeStage:

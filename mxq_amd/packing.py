@@ -83,6 +83,17 @@ class PackedMXQ:
         return 8.0 * self.nbytes() / (self.N * self.K)
 
 
+def concat_packed(ps) -> PackedMXQ:
+    """Stack packed weights along the output dimension (e.g. q | k | v, or gate | up): format v1 is
+    row-block-major, so this is a plain concatenation of the block arrays and of the row metadata, and one
+    launch then computes all the stacked Linears of a shared input."""
+    ps = list(ps)
+    if not ps or any(p.K != ps[0].K for p in ps):
+        raise ValueError("concat_packed needs packed weights with the same in_features")
+    return PackedMXQ(torch.cat([p.qweight for p in ps]), torch.cat([p.rowmeta for p in ps]),
+                     sum(p.N for p in ps), ps[0].K)
+
+
 def _alloc(N: int, K: int, device) -> PackedMXQ:
     lib = _lib.load()
     nbytes = lib.mxq_qweight_bytes(N, K)
