@@ -84,3 +84,35 @@ def test_all_code_values_and_bit_positions(emu):
     p["qz2"] = -np.abs(rng.standard_normal((1, 3))).astype(np.float32) * 5
     p["qs4"] = np.array([3e-4], np.float32); p["qz4"] = np.array([-7.25], np.float32)
     _roundtrip_and_dequant(emu, p, N, K, O.mxq_dequant(p).astype(np.float16))
+
+
+# ----------------------------------------------------------------------------------------
+# property test: ANY parameter set (not only ones a quantiser would produce) survives pack -> unpack
+# bit for bit and dequantises to the oracle's fp32 formula rounded once to fp16
+# ----------------------------------------------------------------------------------------
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2**32 - 1), nc=st.integers(1, 5), rb=st.integers(1, 3),
+       zscale=st.sampled_from([1e-3, 1.0, 37.0, 1e4]), sscale=st.sampled_from([1e-6, 3e-4, 0.02, 5.0]))
+def test_property_pack_unpack_dequant(emu, seed, nc, rb, zscale, sscale):
+    N, K = 16 * rb, 64 * nc
+    rng = np.random.default_rng(seed)
+    G = 3 * nc
+    p = dict(
+        codes2=rng.integers(0, 4, (N, 48 * nc), dtype=np.uint8), sc2=rng.integers(0, 16, (N, G), dtype=np.uint8),
+        zero2=(rng.standard_normal((N, G)) * zscale).astype(np.float32),
+        qs2=(np.abs(rng.standard_normal((rb, G))) * sscale).astype(np.float32),
+        qz2=(rng.standard_normal((rb, G)) * 6).astype(np.float32),
+        codes4=rng.integers(0, 16, (N, 16 * nc), dtype=np.uint8), sc4=rng.integers(0, 16, (N,), dtype=np.uint8),
+        zero4=(rng.standard_normal((N,)) * zscale).astype(np.float32),
+        qs4=(np.abs(rng.standard_normal((rb,))) * sscale).astype(np.float32),
+        qz4=(rng.standard_normal((rb,)) * 6).astype(np.float32), N=N, K=K)
+    # a few exact edge values: zero scale, zero zero-point, negative-zero
+    p["zero2"][0, 0] = 0.0
+    p["zero2"][-1, -1] = -0.0
+    p["qs2"][0, 0] = 0.0
+    with np.errstate(over="ignore", invalid="ignore"):
+        w16 = O.mxq_dequant(p).astype(np.float16)       # overflow to inf is part of the contract (one rounding)
+    _roundtrip_and_dequant(emu, p, N, K, w16)

@@ -69,6 +69,40 @@ def test_g1_pack_codes_roundtrip(dev, g1):
     assert torch.equal(p.qweight, p2.qweight) and torch.equal(p.rowmeta, p2.rowmeta)
 
 
+@pytest.mark.parametrize("seed,N,K,zscale,sscale", [(1, 32, 320, 1e-3, 3e-4), (2, 16, 704, 37.0, 0.02), (3, 64, 1024, 1e4, 5.0),
+                                                    (4, 48, 64, 1.0, 1e-6)])
+def test_arbitrary_params_pack_unpack_dequant_bit_exact(dev, seed, N, K, zscale, sscale):
+    """Parameter sets no quantiser would produce (random codes, scale codes, zero-points of any magnitude,
+    a zero scale, -0.0): the pack / unpack kernels are the identity on them and the LUT / v_perm dequant
+    kernel equals the oracle's fp32 formula rounded once to fp16, overflow to inf included.  Same generator
+    as the CPU property test of the host-compiled helpers (tests/test_format_host_emu.py)."""
+    from mxq_amd import packing
+    rng = np.random.default_rng(seed)
+    nc, rb = K // 64, N // 16
+    G = 3 * nc
+    p = dict(
+        codes2=rng.integers(0, 4, (N, 48 * nc), dtype=np.uint8), sc2=rng.integers(0, 16, (N, G), dtype=np.uint8),
+        zero2=(rng.standard_normal((N, G)) * zscale).astype(np.float32),
+        qs2=(np.abs(rng.standard_normal((rb, G))) * sscale).astype(np.float32),
+        qz2=(rng.standard_normal((rb, G)) * 6).astype(np.float32),
+        codes4=rng.integers(0, 16, (N, 16 * nc), dtype=np.uint8), sc4=rng.integers(0, 16, (N,), dtype=np.uint8),
+        zero4=(rng.standard_normal((N,)) * zscale).astype(np.float32),
+        qs4=(np.abs(rng.standard_normal((rb,))) * sscale).astype(np.float32),
+        qz4=(rng.standard_normal((rb,)) * 6).astype(np.float32), N=N, K=K)
+    p["zero2"][0, 0] = 0.0
+    p["zero2"][-1, -1] = -0.0
+    p["qs2"][0, 0] = 0.0
+    pk = packing.pack_codes(_to_dev(p, dev), N, K)
+    got = packing.unpack(pk)
+    for k in KEYS:
+        a, b = got[k].cpu().numpy(), p[k]
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                              b.view(np.uint32) if b.dtype == np.float32 else b), k
+    with np.errstate(over="ignore", invalid="ignore"):
+        w16 = O.mxq_dequant(p).astype(np.float16)
+    assert np.array_equal(packing.dequant(pk).cpu().numpy().view(np.uint16), w16.view(np.uint16))
+
+
 @pytest.mark.parametrize("name", ["a", "b"])
 def test_g2_llama_width_sha(dev, g2, name):
     from mxq_amd import packing
