@@ -139,18 +139,25 @@ __device__ __forceinline__ void consumer(char* smem, int wave, int lane, int NT,
     }
     mfma_rows<0, 4, ABL>(acc, wf1, xf1);   // (NT-1, kk=1)
 
+    // Output through LDS (the x ring is idle after the last barrier) so that the tile leaves as full 128-B lines,
+    // 16 B per lane, instead of 32-B pieces in 16 rows per instruction: see store_tile_staged in gemm6.hip.
+    constexpr int ROW = 144;
+    char* st = smem + OFF_A + wave * (64 * ROW);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + fr;
-        if (m >= M) continue;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fq * 4;
-            if (n >= N) continue;
             half4 h = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2],
                        (_Float16)acc[i][j][3]};
-            *(half4*)(y + (int64_t)m * N + n) = h;
+            *(half4*)(st + (j * 16 + fr) * ROW + (i * 16 + fq * 4) * 2) = h;
         }
+    const int n = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const u32x4 v = *(const u32x4*)(st + row * ROW + (lane & 7) * 16);
+        const int m = m0 + wm * 64 + row;
+        if (m < M && n < N) *(u32x4*)(y + (int64_t)m * N + n) = v;
     }
 }
 
