@@ -336,7 +336,7 @@ __device__ __forceinline__ void consumer(char* smem, int wave, int lane, int NT,
 
 // The wave that completed a tile's K-step count: sum every contributor's slot in unit order (its own
 // included, re-read from the workspace, so the order never depends on who finishes) and write y.
-__device__ __forceinline__ void sk_finish(const SkSeg& sk, int j, int NT_tile, int wave, int lane,
+__device__ __forceinline__ void sk_finish(const SkSeg& sk, int j, int NT_tile, int wave, int lane, char* smem,
                                           uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
     const int lo = j * NT_tile, hi = lo + NT_tile;
     int uf = 0;
@@ -364,7 +364,7 @@ __device__ __forceinline__ void sk_finish(const SkSeg& sk, int j, int NT_tile, i
     }
     if (lane == 0)   // ready for the next launch
         __hip_atomic_store(sk.cnt + (j * 8 + sk.e) * N_CONS + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    store_tile(acc, y, M, N, m0, n0, wave >> 1, wave & 1, lane & 15, lane >> 4);
+    store_tile_staged(acc, smem, y, M, N, m0, n0, wave, lane);   // runs after the unit's last segment: LDS is idle
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -549,12 +549,12 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm6_f16_kernel(const uint16_t* 
             if (pj0 >= 0 && old0 + pn0 == NT) {
                 int tm, tn;
                 tile_of_block(base + pj0 * 8, tiles_m, tiles_n, tm, tn);
-                sk_finish(sk, pj0, NT, wave, ln, y, M, N, tm * BM, tn * BN);
+                sk_finish(sk, pj0, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
             }
             if (pj1 >= 0 && old1 + pn1 == NT) {
                 int tm, tn;
                 tile_of_block(base + pj1 * 8, tiles_m, tiles_n, tm, tn);
-                sk_finish(sk, pj1, NT, wave, ln, y, M, N, tm * BM, tn * BN);
+                sk_finish(sk, pj1, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
             }
         }
     } else {
