@@ -50,6 +50,17 @@ class QuantLinear(nn.Module):
         p = packing.quantize_pack(linear.weight.data, dead)
         return cls.from_packed(p, linear.bias.data if linear.bias is not None else None)
 
+    @classmethod
+    def fuse(cls, mods) -> "QuantLinear":
+        """One module computing several QuantLinears of a shared input in one launch (q | k | v, gate | up):
+        format v1 is row-block-major, so the packed weights concatenate along out_features
+        (packing.concat_packed); the output is the concatenation of the parts' outputs."""
+        mods = list(mods)
+        if any((m.bias is None) != (mods[0].bias is None) for m in mods):
+            raise ValueError("fuse: either every part has a bias or none")
+        bias = torch.cat([m.bias for m in mods]) if mods[0].bias is not None else None
+        return cls.from_packed(packing.concat_packed([m.packed() for m in mods]), bias)
+
     # -- views ----------------------------------------------------------------------------
     def packed(self) -> packing.PackedMXQ:
         return packing.PackedMXQ(self.qweight, self.rowmeta, self.out_features, self.in_features)

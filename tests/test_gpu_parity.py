@@ -355,6 +355,12 @@ def test_quantlinear_module(dev):
         ql(x.float())
     with pytest.raises(ValueError):
         ql(torch.randn(2, 100, device=dev).half())
+    # fused q | k | v style module: same numbers as the parts, one launch
+    parts = [QuantLinear.from_linear(torch.nn.Linear(512, n, bias=True).to(dev).half()) for n in (256, 128, 64)]
+    fused = QuantLinear.fuse(parts)
+    assert fused.out_features == 448
+    for xx in (x, torch.randn(300, 512, device=dev).half()):       # GEMV path and GEMM path
+        assert torch.equal(fused(xx), torch.cat([p(xx) for p in parts], dim=-1))
 
 
 class _MlpBlock(torch.nn.Module):
