@@ -96,7 +96,7 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * 3 = 256x128 ping-pong kernel (two wave groups alternate MFMA and memory slots),
  * 4 = 256x128 wave-specialised kernel (8 MFMA waves + 4 DMA/dequant waves),
  * 5 = variant 4 with the 2-bit dequant moved to the MFMA waves.
- * Values 16..31 / 32..47 / 48..63 / 64..575 select profiling-only ablation builds of variants 2 / 4 / 5 / 6
+ * Values 16..31 / 32..47 / 48..63 / 64..1087 select profiling-only ablation builds of variants 2 / 4 / 5 / 6
  * (parts of the kernel removed to time the rest: wrong results). */
 int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* stream);

@@ -91,7 +91,7 @@ int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, voi
         return mxq_launch_gemm2_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 16, (hipStream_t)stream);
     if (variant >= 48 && variant < 64)   // profiling-only ablation builds of variant 5 (wrong results)
         return mxq_launch_gemm5_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 48, (hipStream_t)stream);
-    if (variant >= 64 && variant < 576)   // profiling-only ablation builds of variant 6 (wrong results)
+    if (variant >= 64 && variant < 1088)   // profiling-only ablation builds of variant 6 (wrong results)
         return mxq_launch_gemm6_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 64, (hipStream_t)stream);
     if (variant >= 32 && variant < 48)   // profiling-only ablation builds of variant 4 (wrong results)
         return mxq_launch_gemm4_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 32, (hipStream_t)stream);
