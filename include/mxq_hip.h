@@ -91,16 +91,6 @@ int mxq_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* 
                  void* stream);
 int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                  void* stream); /* M <= 4 */
-/* mxq_gemm_f16 with an explicit kernel variant, for A/B benchmarking and tests:
- * 0 = auto, 1 = 128x128 two-stage kernel, 2 = 256x128 LDS-DMA-pipelined kernel,
- * 3 = 256x128 ping-pong kernel (two wave groups alternate MFMA and memory slots),
- * 4 = 256x128 wave-specialised kernel (8 MFMA waves + 4 DMA/dequant waves),
- * 5 = variant 4 with the 2-bit dequant moved to the MFMA waves.
- * Values 16..31 / 32..47 / 48..63 / 64..1087 select profiling-only ablation builds of variants 2 / 4 / 5 / 6
- * (parts of the kernel removed to time the rest: wrong results). */
-int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                    int variant, void* stream);
-
 /* The same Linear with a caller-owned scratch buffer, which lets the prefill GEMM balance launches
  * whose tile count is not a multiple of the CU count (stream-K tail, csrc/gemm6.hip): e.g. 512 tokens
  * x 4096^2 is 64 tiles, a quarter of the 256 CUs, unless every CU takes a quarter of a tile's K range.
@@ -110,9 +100,11 @@ int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, voi
  * different workspaces).  workspace == NULL selects the workspace-free schedule of mxq_linear_f16.
  * The tail is only split where that pays (about 24 idle K-steps per CU; it does for 128 < M <= 1024 on
  * the Llama shapes, not for gate/up at M = 2048).
- * mxq_gemm_f16_ws: variant 0 = default dispatch, 6 = the stream-K kernel at any M, 7 = the same but
- * splitting whenever it is structurally possible (tests), 1..5 as in mxq_gemm_f16_ex (workspace ignored).  Results of every variant agree to fp32-summation-order
- * rounding and are run-to-run deterministic. */
+ * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 6 = the
+ * wave-specialised stream-K kernel at any M, 7 = the same but splitting whenever it is structurally possible
+ * (tests); anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
+ * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
+ * used by tools/ alone: they are not part of this ABI.) */
 size_t mxq_gemm_workspace_bytes(void);
 int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                       void* workspace, size_t workspace_bytes, void* stream);

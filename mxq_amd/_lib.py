@@ -35,7 +35,6 @@ SIGNATURES = {
     "mxq_dequant_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mxq_linear_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "mxq_gemm_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
-    "mxq_gemm_f16_ex": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_actquant_group_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_actquant_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int,
                                  c_void_p]),

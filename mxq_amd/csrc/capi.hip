@@ -76,28 +76,6 @@ int mxq_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* 
     return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
 }
 
-int mxq_gemm_f16_ex(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                    int variant, void* stream) {
-    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
-    switch (variant) {
-        case 0: return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-        case 1: return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-        case 2: return mxq_launch_gemm2_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-        case 3: return mxq_launch_gemm3_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-        case 4: return mxq_launch_gemm4_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-        case 5: return mxq_launch_gemm5_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-    }
-    if (variant >= 16 && variant < 32)   // profiling-only ablation builds of variant 2 (wrong results)
-        return mxq_launch_gemm2_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 16, (hipStream_t)stream);
-    if (variant >= 48 && variant < 64)   // profiling-only ablation builds of variant 5 (wrong results)
-        return mxq_launch_gemm5_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 48, (hipStream_t)stream);
-    if (variant >= 64 && variant < 1088)   // profiling-only ablation builds of variant 6 (wrong results)
-        return mxq_launch_gemm6_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 64, (hipStream_t)stream);
-    if (variant >= 32 && variant < 48)   // profiling-only ablation builds of variant 4 (wrong results)
-        return mxq_launch_gemm4_ablate_f16(x, qweight, rowmeta, y, M, N, K, variant - 32, (hipStream_t)stream);
-    return MXQ_E_SHAPE;
-}
-
 int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                  void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
@@ -196,10 +174,11 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
     if (variant == 0) return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
+    if (variant == 1) return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
     if (variant == 6 || variant == 7)
         return mxq_launch_gemm6_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 7,
                                     (hipStream_t)stream);
-    return mxq_gemm_f16_ex(x, qweight, rowmeta, y, M, N, K, variant, stream);
+    return MXQ_E_SHAPE;
 }
 
 int mxq_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype, void* stream) {

@@ -331,11 +331,6 @@ static int launch4(const void* x, const void* qweight, const void* rowmeta, void
 
 }   // namespace
 
-int mxq_launch_gemm4_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         hipStream_t stream) {
-    return launch4<0>(x, qweight, rowmeta, y, M, N, K, stream);
-}
-
 // uniform layouts of the config-5 sweep (mxq_format.h): same kernel, different producer dequant
 int mxq_launch_gemm4_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                 int layout, hipStream_t stream) {
@@ -343,23 +338,6 @@ int mxq_launch_gemm4_layout_f16(const void* x, const void* qweight, const void* 
         case MXQ_LAYOUT_MIXED: return launch4<0, MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, stream);
         case MXQ_LAYOUT_W2G16: return launch4<0, MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, stream);
         case MXQ_LAYOUT_W4ROW: return launch4<0, MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, stream);
-    }
-    return (int)hipErrorInvalidValue;
-}
-
-// profiling-only ablation builds (wrong results): 1 no x DMA, 2 no MFMA, 4 no dequant, 8 no fragment reads
-int mxq_launch_gemm4_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                                int abl, hipStream_t stream) {
-    switch (abl) {
-        case 1: return launch4<1>(x, qweight, rowmeta, y, M, N, K, stream);
-        case 2: return launch4<2>(x, qweight, rowmeta, y, M, N, K, stream);
-        case 4: return launch4<4>(x, qweight, rowmeta, y, M, N, K, stream);
-        case 8: return launch4<8>(x, qweight, rowmeta, y, M, N, K, stream);
-        case 10: return launch4<10>(x, qweight, rowmeta, y, M, N, K, stream);
-        case 5: return launch4<5>(x, qweight, rowmeta, y, M, N, K, stream);
-        case 13: return launch4<13>(x, qweight, rowmeta, y, M, N, K, stream);
-        case 7: return launch4<7>(x, qweight, rowmeta, y, M, N, K, stream);
-        case 15: return launch4<15>(x, qweight, rowmeta, y, M, N, K, stream);
     }
     return (int)hipErrorInvalidValue;
 }

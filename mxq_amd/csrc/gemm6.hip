@@ -629,11 +629,15 @@ int mxq_launch_gemm6_f16(const void* x, const void* qweight, const void* rowmeta
     return launch6<0>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, force != 0, stream);
 }
 
-// profiling-only builds (wrong results): 1 = no x DMAs, 2 = no MFMA, 4 = no dequant at all, 16 = half the x DMAs,
+#ifdef MXQ_PROFILING
+// Built only into libmxq_hip_prof.so (make prof; tools/): parts of the kernel removed to time the rest.
+// WRONG RESULTS by construction -- never part of libmxq_hip.so or of include/mxq_hip.h.
+// 1 = no x DMAs, 2 = no MFMA, 4 = no dequant at all, 16 = half the x DMAs,
 // 32 = no 2-bit (consumer-side) dequant, 64 = no 4-bit (producer-side) dequant, 256 = no output stores,
 // 512 = output staged through LDS but not written
-int mxq_launch_gemm6_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                                int abl, hipStream_t stream) {
+extern "C" int mxq_prof_gemm6_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+                                         int K, int abl, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     switch (abl) {
         case 1: return launch6<1>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
         case 2: return launch6<2>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
@@ -645,5 +649,6 @@ int mxq_launch_gemm6_ablate_f16(const void* x, const void* qweight, const void* 
         case 256: return launch6<256>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // no y stores
         case 512: return launch6<512>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // LDS staging, no global stores
     }
-    return (int)hipErrorInvalidValue;
+    return -1;   // MXQ_E_SHAPE: not an ablation this build carries
 }
+#endif   // MXQ_PROFILING

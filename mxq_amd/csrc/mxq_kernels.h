@@ -23,26 +23,10 @@ int mxq_launch_gemm_f16(const void* x, const void* qweight, const void* rowmeta,
                         hipStream_t stream);
 int mxq_launch_gemm1_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          hipStream_t stream);   // 128x128 tile, two LDS stages (gemm.hip)
-int mxq_launch_gemm2_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         hipStream_t stream);   // 256x128 tile, LDS-DMA rings, counted waits (gemm2.hip)
-int mxq_launch_gemm2_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
-                                int K, int abl, hipStream_t stream);   // profiling only
-int mxq_launch_gemm3_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         hipStream_t stream);   // 256x128 tile, two wave groups ping-pong MFMA / memory slots (gemm3.hip)
-int mxq_launch_gemm4_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         hipStream_t stream);   // 256x128 tile, 8 MFMA waves + 4 DMA/dequant waves (gemm4.hip)
-int mxq_launch_gemm5_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         hipStream_t stream);   // gemm4 with the 2-bit dequant moved to the MFMA waves (gemm5.hip)
 size_t mxq_gemm6_workspace_bytes();
 int mxq_launch_gemm6_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          void* workspace, size_t ws_bytes, int force,
                          hipStream_t stream);   // gemm5 + stream-K tail (gemm6.hip); force: split even when it does not pay
-int mxq_launch_gemm6_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
-                                int K, int abl, hipStream_t stream);   // profiling only
-int mxq_launch_gemm5_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
-                                int K, int abl, hipStream_t stream);   // profiling only
-int mxq_launch_gemm4_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
-                                int K, int abl, hipStream_t stream);   // profiling only
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream);
 int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,

@@ -176,11 +176,15 @@ def dequant(p: PackedMXQ) -> torch.Tensor:
     return out
 
 
+GEMM_PATHS = {"gemm": 0, "gemm1": 1, "gemm6": 6, "gemm7": 7}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
+
+
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
     """y = x @ dequant(p).T for x [..., K] fp16 -> [..., N] fp16 (fp32 accumulation).
 
-    path: "auto" (GEMV kernel for <= 4 tokens, MFMA GEMM otherwise), "gemm", "gemv", or an
-    explicit GEMM kernel variant "gemm1" (128x128) .. "gemm6" (wave-specialised + stream-K tail)."""
+    path: "auto" (GEMV kernel for <= 4 tokens, MFMA GEMM otherwise), "gemm", "gemv", or an explicit GEMM
+    kernel: "gemm1" (128x128 tile), "gemm6" (wave-specialised + stream-K tail), "gemm7" (gemm6 splitting its
+    tail whenever that is structurally possible: tests)."""
     _need_gpu(x, p.qweight)
     if x.dtype != torch.float16:
         raise ValueError(f"activations must be float16 (W2/4 x A16), got {x.dtype}")
@@ -208,8 +212,8 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
             wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
             if path == "auto":
                 rc = lib.mxq_linear_f16_ws(*args, wsp, wsn, _stream(x2))
-            elif path == "gemm" or (path[4:].isdigit() and path.startswith("gemm")):
-                rc = lib.mxq_gemm_f16_ws(*args, int(path[4:] or 0), wsp, wsn, _stream(x2))
+            elif path in GEMM_PATHS:
+                rc = lib.mxq_gemm_f16_ws(*args, GEMM_PATHS[path], wsp, wsn, _stream(x2))
             else:
                 raise ValueError(f"unknown path {path!r}")
         _lib.check(rc, f"mxq_linear_f16[{path}]")

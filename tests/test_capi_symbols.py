@@ -71,7 +71,9 @@ def test_argument_validation_rejects_before_any_launch(lib):
         assert fn(P, P, P, P, 0, 64, 256, None) == E_SHAPE          # no tokens
         assert fn(P, Q, P, P, 2, 64, 256, None) == E_ALIGN
     assert lib.mxq_gemv_f16(P, P, P, P, 5, 64, 256, None) == E_SHAPE   # GEMV is for <= 4 tokens
-    assert lib.mxq_gemm_f16_ex(P, P, P, P, 8, 64, 256, 999, None) == E_SHAPE
+    # unknown kernel variants are rejected, not dispatched (no profiling build is reachable through this ABI)
+    for variant in (2, 3, 4, 5, 16, 64, 999, -1):
+        assert lib.mxq_gemm_f16_ws(P, P, P, P, 8, 64, 256, variant, None, 0, None) == E_SHAPE
     assert lib.mxq_linear_f16_ws(P, P, P, P, 8, 64, 256, Q, 1 << 27, None) == E_ALIGN
     assert lib.mxq_gemm_f16_ws(P, P, P, None, 8, 64, 256, 0, None, 0, None) == E_NULL
     assert lib.mxq_gemv_fused_f16(P, P, P, P, 64, 256, 1, None, 1e-5, None, None) == E_NULL   # RMSNorm needs its weight
@@ -93,3 +95,13 @@ def test_argument_validation_rejects_before_any_launch(lib):
     assert lib.mxq_gemv_awq_f16(P, P, P, P, P, 1, 4096, 4096, 48, None) == E_SHAPE    # group size
     assert lib.mxq_gemv_proto_f16(P, P, P, P, P, P, P, P, P, 1, 2048, 4096, 16, None) == E_SHAPE   # IC must be 4096
     assert lib.mxq_gemm_workspace_bytes() == 64 * 1024 + 256 * 2 * 256 * 128 * 4 or lib.mxq_gemm_workspace_bytes() > 64 * 1024
+
+
+def test_no_profiling_entry_point_in_the_product_library(lib):
+    """Ablation / profiling builds (wrong results) live in libmxq_hip_prof.so (`make prof`), never here."""
+    import subprocess
+    from mxq_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    syms = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert not [s_ for s_ in syms if "ablat" in s_ or "prof" in s_], "profiling symbols leaked into the product ABI"
+    assert not hasattr(lib, "mxq_gemm_f16_ex")

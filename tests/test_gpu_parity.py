@@ -157,6 +157,9 @@ def test_mxqgpt_driver_api(dev, g1):
 # ----------------------------------------------------------------------------------------
 # dequant-GEMM / GEMV
 # ----------------------------------------------------------------------------------------
+GEMM_KERNELS = ["gemm", "gemm1", "gemm6", "gemm7"]      # packing.GEMM_PATHS: every kernel the product library ships
+
+
 def _packed_case(dev, N, K, seed):
     from mxq_amd import packing
     g = torch.Generator().manual_seed(seed)
@@ -167,10 +170,10 @@ def _packed_case(dev, N, K, seed):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (128, 256, 512), (200, 192, 320), (5, 64, 128), (77, 16, 704),
                                    (256, 4096, 1024), (300, 144, 192), (512, 128, 128)])
-@pytest.mark.parametrize("path", ["gemm", "gemm1", "gemm2", "gemm3", "gemm4", "gemm5", "gemm6"])
+@pytest.mark.parametrize("path", GEMM_KERNELS)
 def test_gemm_vs_oracle(dev, M, N, K, path):
-    """Ragged M (200, 5, 77), N below / not a multiple of the tile, ragged K; both kernel
-    variants (128x128 two-stage, 256x128 LDS-DMA pipelined) and the automatic choice."""
+    """Ragged M (200, 5, 77), N below / not a multiple of the tile, ragged K; every shipped kernel
+    (128x128 two-stage, 256x128 wave-specialised with and without its stream-K split) and the automatic choice."""
     from mxq_amd import packing
     p, w16, g = _packed_case(dev, N, K, M * 7 + N)
     x = torch.randn(M, K, generator=g).half()
@@ -196,7 +199,7 @@ def test_gemm_integer_exact_layout(dev):
     pk = packing.pack_codes(_to_dev(p, dev), N, K)
     yref = x.astype(np.float32) @ w.T
     assert np.abs(yref).max() < 2048
-    for path, rows in (("gemm1", M), ("gemm2", M), ("gemm3", M), ("gemm4", M), ("gemm5", M), ("gemm6", M), ("gemv", 3)):
+    for path, rows in [(k, M) for k in GEMM_KERNELS] + [("gemv", 3)]:
         y = packing.linear(torch.from_numpy(x[:rows]).to(dev), pk, path=path).cpu().numpy().astype(np.float32)
         assert np.array_equal(y, yref[:rows]), path
 
@@ -210,8 +213,8 @@ def test_gemm_integer_exact_layout(dev):
 def test_gemm_stream_k_tail(dev, M, N, K):
     """csrc/gemm6.hip: tiles beyond the last full round of CUs are split along K over all CUs and
     reduced through the workspace.  Checks (1) against the oracle matmul, (2) that the workspace
-    counters are left zeroed, (3) run-to-run bit-determinism, (4) agreement with the workspace-free
-    kernel (gemm5) to summation-order rounding."""
+    counters are left zeroed, (3) run-to-run bit-determinism, (4) agreement with the 128x128-tile
+    kernel (no split) to summation-order rounding."""
     from mxq_amd import packing
     p, w16, g = _packed_case(dev, N, K, M + N + K)
     x = torch.randn(M, K, generator=g).half()
@@ -222,7 +225,7 @@ def test_gemm_stream_k_tail(dev, M, N, K):
     assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
     for _ in range(3):
         assert torch.equal(packing.linear(xd, p, path="gemm7"), y)
-    y5 = packing.linear(xd, p, path="gemm5")
+    y5 = packing.linear(xd, p, path="gemm1")
     assert ((y.float() - y5.float()).abs().max() / y5.float().abs().max()).item() <= 1e-3
     # the default dispatch is the same kernel, splitting only where it pays: equal up to summation order
     yd = packing.linear(xd, p, path="gemm")
