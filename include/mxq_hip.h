@@ -101,8 +101,9 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * The tail is only split where that pays (about 24 idle K-steps per CU; it does for 128 < M <= 1024 on
  * the Llama shapes, not for gate/up at M = 2048).
  * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 6 = the
- * wave-specialised stream-K kernel at any M, 7 = the same but splitting whenever it is structurally possible
- * (tests); anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
+ * round-1 wave-specialised stream-K kernel at any M, 7 = the same but splitting whenever it is structurally
+ * possible (tests), 8 / 9 = likewise for the kernel whose MFMA waves stream x and whose dequant runs on
+ * dedicated waves (csrc/gemm8.hip); anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
  * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
  * used by tools/ alone: they are not part of this ABI.) */
 size_t mxq_gemm_workspace_bytes(void);

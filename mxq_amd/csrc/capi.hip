@@ -175,6 +175,9 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
     if (variant == 0) return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
     if (variant == 1) return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+    if (variant == 8 || variant == 9)
+        return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 9,
+                                    (hipStream_t)stream);
     if (variant == 6 || variant == 7)
         return mxq_launch_gemm6_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 7,
                                     (hipStream_t)stream);

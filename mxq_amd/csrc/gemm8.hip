@@ -1,0 +1,739 @@
+// W2/4 x A16 dequant-GEMM, v8: MFMA waves own the activation stream, dedicated waves own ALL of the dequant.
+//
+// Counterpart of the reference's (never built) AWQ tensor-core GEMM
+// mxq_quant/cuda_kernel/csrc/quantization/gemm_cuda_gen.cu:28-218 and of the implicit nn.Linear on the
+// fake-quant weight (mxq_quant/main.py:85); arithmetic contract x16 . fp16(scale * (q - zero))^T of
+// lib/quantizer.py:19-20 + mxqgpt.py:448, fp32 accumulation.
+//
+// gemm6 (round 1) put the 2-bit dequant (~48 VALU ops per K-step) INSIDE the MFMA waves' instruction streams and
+// every LDS-DMA on four producer waves (10 DMA issues each per K-step, ~100 cycles apiece: they had no time left
+// for more dequant).  An in-order wave that carries VALU chains between its MFMAs stalls its MFMAs on them, and
+// both MFMA waves of a SIMD do so in lockstep.  Here the roles are cut the other way:
+//   * waves 0-7  "MFMA waves": fragment reads + 32 MFMAs per K-step, and the x tile's LDS-DMA (4 x 1 KiB
+//     buffer_load ... lds each per K-step, addressed by ONE per-lane offset VGPR each + a scalar K offset; rows
+//     beyond M read as zeros through the buffer descriptor's range check) -- no VALU work in the loop at all;
+//   * waves 8-11 "dequant waves" (one per SIMD): the packed blocks' LDS-DMA (2 per wave and K-step) and the whole
+//     dequant of chunk t+1 (2-bit LUT/v_perm groups and the 4-bit arm) from the LDS copy into the fp16 W16 tile.
+//     Their VALU ops fill the vector-issue slots the MFMAs leave free, in no fixed order relative to them.
+// Tile 256 tokens x 128 channels x K-step 64 (= one MXQ chunk), one raw s_barrier per K-step, x ring 3 slots
+// (DMA two steps ahead, counted vmcnt), packed ring 3 slots, W16 double buffer; hybrid stream-K tail with the
+// same unit / slot / counter protocol as gemm6 (see there).  D^T = W . x^T: a lane owns 4 consecutive channels.
+#include <hip/hip_runtime.h>
+
+#include "mxq_dequant.h"
+#include "mxq_format.h"
+#include "mxq_kernels.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 256, BN = 128, BK = 64;
+constexpr int N_MMA = 8, N_DEQ = 4, THREADS = (N_MMA + N_DEQ) * 64;
+constexpr int A_STAGE = BM * BK * 2, A_SLOTS = 3;
+constexpr int BP_BLK = MXQ_BLK_BYTES;            // 576 B: stride of 144 dwords keeps blocks on distinct banks
+constexpr int BP_STAGE = (BN / 16) * BP_BLK, BP_SLOTS = 4;
+constexpr int W_STAGE = BN * BK * 2;
+constexpr int OFF_A = 0;
+constexpr int OFF_BP = OFF_A + A_SLOTS * A_STAGE;
+constexpr int OFF_W = (OFF_BP + BP_SLOTS * BP_STAGE + 255) / 256 * 256;
+constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;
+static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+
+// profiling-only switches (template parameter ABL; product build = 0)
+constexpr int ABL_NO_MFMA = 2, ABL_NO_DEQ = 4, ABL_NO_XDMA = 1, ABL_NO_STORE = 256;
+// scheduling experiments (correct results): issue priorities of the two roles
+constexpr int EXP_NO_PRIO = 1024, EXP_DEQ_PRIO = 2048, EXP_STAMPS = 4096;
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+
+// LDS-DMA through a buffer descriptor: 16 B per lane, LDS destination = wave-uniform base + 16 * lane;
+// global source = descriptor base + voff (per lane) + soff (scalar); out-of-range sources deliver zeros
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ void bufdma16(rsrc_t rsrc, uint32_t voff, uint32_t soff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+
+// XCD-aware tile order (speed only; same as gemm6)
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0) {
+        const int e = bid & 7, l = bid >> 3;
+        const int rm = tiles_m >> 2, rn = tiles_n >> 1;
+        const int full = rm * 16;
+        const int p = l / full;
+        const int j = l - p * full;
+        const int left = rn - p * 16;
+        const int pw = left < 16 ? left : 16;
+        tm = (e & 3) * rm + j / pw;
+        tn = (e >> 2) * rn + p * 16 + j % pw;
+        return;
+    }
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tm = lin % tiles_m;
+    tn = lin / tiles_m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream-K bookkeeping (protocol: gemm6.hip header)
+// ------------------------------------------------------------------------------------------------
+struct SkSeg {
+    float* ws;        // partial slots: [unit = 8u+e][2][BM*BN] fp32
+    int* cnt;         // K-step counters: [tail tile = 8j+e][N_MMA waves]
+    int u, e, units;  // this unit, its XCD, units per XCD
+    int S;            // K-steps in one XCD's tail = tail tiles per XCD * NT
+    int j;            // tile index inside the XCD's tail
+    int first;        // 1: the segment starts at the unit's range start (slot 0), else slot 1
+};
+typedef unsigned long long u64;
+__device__ __forceinline__ void st_agent(float* slot, int f, int lane, f32x4 v) {
+    union { f32x4 v4; u64 q[2]; } c;
+    c.v4 = v;
+    u64* p = (u64*)slot + (f * 2) * 64 + lane;
+    __hip_atomic_store(p, c.q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 64, c.q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 ld_agent(const float* slot, int f, int lane) {
+    union { f32x4 v4; u64 q[2]; } c;
+    const u64* p = (const u64*)slot + (f * 2) * 64 + lane;
+    c.q[0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.q[1] = __hip_atomic_load(p + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return c.v4;
+}
+__device__ __forceinline__ int sk_bound(int u, int S, int units) { return (int)((uint32_t)u * (uint32_t)S / (uint32_t)units); }
+
+// ------------------------------------------------------------------------------------------------
+// MFMA waves
+// ------------------------------------------------------------------------------------------------
+typedef half8 Frag4[4];
+
+__device__ __forceinline__ void load_frags(const char* smem, int t, int kk, int wm, int wn, int fr, int fq, Frag4& wf,
+                                           Frag4& xf) {
+    const char* a_base = smem + OFF_A + (t % A_SLOTS) * A_STAGE;
+    const char* w_base = smem + OFF_W + (t & 1) * W_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(w_base + swz(wn * 64 + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz(wm * 64 + j * 16 + fr, kk * 4 + fq));
+}
+
+template <int I0, int I1, int ABL>
+__device__ __forceinline__ void mfma_rows(f32x4 (&acc)[4][4], const Frag4& wf, const Frag4& xf) {
+#pragma unroll
+    for (int i = I0; i < I1; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (ABL & ABL_NO_MFMA) asm volatile("" ::"v"(wf[i]), "v"(xf[j]));
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+}
+
+// the x tile of K-step t: wave w fills rows 32w .. 32w+31 of slot t % 3 with 4 DMAs of 8 full 128-B rows;
+// lane -> (row 8i + lane / 8, 16-B chunk lane % 8), source chunk XOR-swizzled so that the fragment reads are
+// conflict-poor (swz above).  voff[i] = that row's byte offset from the tile's first row + the chunk.
+struct XDma {
+    rsrc_t rsrc;         // x rows m0 .. of this tile (range-checked: rows beyond M read as zeros)
+    uint32_t voff[4];
+    uint32_t k0;         // byte offset of the segment's first K-step inside a row
+};
+template <int I0, int I1>
+__device__ __forceinline__ void issue_x(const XDma& d, char* smem, int wave, int t) {
+    char* dst = smem + OFF_A + (t % A_SLOTS) * A_STAGE + wave * 4096;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) bufdma16(d.rsrc, d.voff[i], d.k0 + (uint32_t)t * (BK * 2), dst + i * 1024);
+}
+
+#define MXQ_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// diagnostic builds only (EXP_STAMPS): cycle stamps around the phases of a K-step; sums leave through the workspace
+typedef unsigned long long u64t;
+struct Stamps { u64t work, wait, bar, n; };
+__device__ __forceinline__ u64t stamp() {
+    u64t t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+// One K-step t >= 1: MFMAs of (t-1, kk=1) and (t, kk=0), fragment reads of step t, and -- ISSUE -- the x DMAs of
+// step t+2 (slot (t+2) % 3 was last read in step t-1), spread behind groups of MFMAs.
+template <int ABL, bool ISSUE>
+__device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, int wn, int fr, int fq, const XDma& xd,
+                                         f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1, Frag4& xf1,
+                                         Stamps& st) {
+    u64t t0 = 0, t1 = 0, t2 = 0;
+    if constexpr ((ABL & EXP_STAMPS) != 0) t0 = stamp();
+    mfma_rows<0, 1, ABL>(acc, wf1, xf1);
+    MXQ_FENCE();
+    load_frags(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
+    MXQ_FENCE();
+    mfma_rows<1, 2, ABL>(acc, wf1, xf1);
+    MXQ_FENCE();
+    if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) issue_x<0, 2>(xd, smem, wave, t + 2);
+    MXQ_FENCE();
+    mfma_rows<2, 4, ABL>(acc, wf1, xf1);
+    MXQ_FENCE();
+    load_frags(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
+    MXQ_FENCE();
+    mfma_rows<0, 2, ABL>(acc, wf0, xf0);
+    MXQ_FENCE();
+    if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) issue_x<2, 4>(xd, smem, wave, t + 2);
+    MXQ_FENCE();
+    mfma_rows<2, 4, ABL>(acc, wf0, xf0);
+    if constexpr ((ABL & EXP_STAMPS) != 0) t1 = stamp();
+    // this step's 4 DMAs stay in flight across the barrier; the previous step's (x of step t+1) have landed
+    if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if constexpr ((ABL & EXP_STAMPS) != 0) t2 = stamp();
+    __builtin_amdgcn_s_barrier();
+    if constexpr ((ABL & EXP_STAMPS) != 0) {
+        const u64t t3 = stamp();
+        st.work += t1 - t0; st.wait += t2 - t1; st.bar += t3 - t2; st.n += 1;
+    }
+}
+
+__device__ __forceinline__ void store_tile(const f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N, int m0,
+                                           int n0, int wm, int wn, int fr, int fq) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fq * 4;
+            if (n >= N) continue;
+            half4 h = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2],
+                       (_Float16)acc[i][j][3]};
+            *(half4*)(y + (int64_t)m * N + n) = h;
+        }
+    }
+}
+
+// The tile through LDS (the wave's own 9 KB of the idle x ring) so that it leaves as full 128-B lines, 16 B per
+// lane; only for workgroups that run a single whole tile (a stream-K unit's next segment may already be
+// refilling the ring).
+__device__ __forceinline__ void store_tile_staged(const f32x4 (&acc)[4][4], char* smem, uint16_t* __restrict__ y, int M,
+                                                  int N, int m0, int n0, int wave, int lane) {
+    constexpr int ROW = 144;   // 128 B of channels + 16 B: keeps the b128 reads aligned and spreads the banks
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    char* st = smem + OFF_A + wave * (64 * ROW);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            half4 h = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2],
+                       (_Float16)acc[i][j][3]};
+            *(half4*)(st + (j * 16 + fr) * ROW + (i * 16 + fq * 4) * 2) = h;
+        }
+    const int n = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const u32x4 v = *(const u32x4*)(st + row * ROW + (lane & 7) * 16);
+        const int m = m0 + wm * 64 + row;
+        if (m < M && n < N) *(u32x4*)(y + (int64_t)m * N + n) = v;
+    }
+}
+
+template <int ABL>
+__device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int NT, const uint16_t* __restrict__ x,
+                                            uint16_t* __restrict__ y, int M, int N, int K, int m0, int n0, int kt0,
+                                            int NT_tile, const SkSeg& sk, bool lds_free) {
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    XDma xd;
+    {
+        const int rows = M - m0 < BM ? M - m0 : BM;                       // live rows of this tile
+        xd.rsrc = make_rsrc(x + (int64_t)m0 * K, (uint32_t)rows * (uint32_t)K * 2u);
+        xd.k0 = (uint32_t)kt0 * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + (lane >> 3);
+            xd.voff[i] = (uint32_t)row * (uint32_t)K * 2u + ((((uint32_t)lane & 7u) ^ ((uint32_t)row & 7u)) << 4);
+        }
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag4 wf0, xf0, wf1, xf1;
+
+    // prologue: x of steps 0 and 1
+    if constexpr (!(ABL & ABL_NO_XDMA)) {
+        issue_x<0, 4>(xd, smem, wave, 0);
+        if (NT > 1) issue_x<0, 4>(xd, smem, wave, 1);
+    }
+    if (NT > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // prologue barrier 1: x tile 0 and packed blocks 0..2 landed
+    __builtin_amdgcn_s_barrier();   // prologue barrier 2: W16(0) written by the dequant waves
+
+    // step 0: no previous half
+    load_frags(smem, 0, 0, wm, wn, fr, fq, wf0, xf0);
+    load_frags(smem, 0, 1, wm, wn, fr, fq, wf1, xf1);
+    if (NT > 2) {
+        if constexpr (!(ABL & ABL_NO_XDMA)) issue_x<0, 4>(xd, smem, wave, 2);
+        mfma_rows<0, 4, ABL>(acc, wf0, xf0);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    } else {
+        mfma_rows<0, 4, ABL>(acc, wf0, xf0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    int t = 1;
+    Stamps st = {0, 0, 0, 0};
+    for (; t + 2 < NT; ++t) mma_step<ABL, true>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
+    if constexpr ((ABL & EXP_STAMPS) != 0) {   // this workgroup's wave: {work, wait, barrier, steps} cycle sums
+        if (lane == 0 && sk.ws) {
+            u64t* d = (u64t*)sk.ws + ((int64_t)blockIdx.x * (N_MMA + N_DEQ) + wave) * 4;
+            d[0] = st.work; d[1] = st.wait; d[2] = st.bar; d[3] = st.n;
+        }
+    }
+    for (; t < NT; ++t) mma_step<ABL, false>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
+    mfma_rows<0, 4, ABL>(acc, wf1, xf1);   // (NT-1, kk=1)
+
+    if (NT != NT_tile) {
+        // partial segment: park the accumulators in this unit's slot; counted in after the unit's last segment
+        float* mine = sk.ws + ((int64_t)((sk.u * 8 + sk.e) * 2 + (sk.first ? 0 : 1)) * (BM * BN)) + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st_agent(mine, i * 4 + j, lane, acc[i][j]);
+        return;
+    }
+    if constexpr (!(ABL & ABL_NO_STORE)) {
+        if (lds_free) store_tile_staged(acc, smem, y, M, N, m0, n0, wave, lane);
+        else store_tile(acc, y, M, N, m0, n0, wm, wn, fr, fq);
+    } else {   // keep every accumulator alive without writing the tile
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (s == 123.456f) y[0] = 1;
+    }
+}
+
+// The wave that completed a tile's K-step count: sum every contributor's slot in unit order and write y.
+__device__ __forceinline__ void sk_finish(const SkSeg& sk, int j, int NT_tile, int wave, int lane, char* smem,
+                                          uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
+    const int lo = j * NT_tile, hi = lo + NT_tile;
+    int uf = 0;
+    while (uf + 1 < sk.units && sk_bound(uf + 1, sk.S, sk.units) <= lo) ++uf;
+    f32x4 acc[4][4];
+    bool any = false;
+    for (int v = uf; v < sk.units && sk_bound(v, sk.S, sk.units) < hi; ++v) {
+        const int vb = sk_bound(v, sk.S, sk.units);
+        if (sk_bound(v + 1, sk.S, sk.units) <= (vb > lo ? vb : lo)) continue;   // empty range: no slot was written
+        const float* src = sk.ws + ((int64_t)((v * 8 + sk.e) * 2 + (vb >= lo ? 0 : 1)) * (BM * BN)) + wave * 4096;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // 8 fragments (16 loads) in flight at a time
+            f32x4 p[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) p[i][jj] = ld_agent(src, (h * 2 + i) * 4 + jj, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[h * 2 + i][jj] = any ? acc[h * 2 + i][jj] + p[i][jj] : p[i][jj];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        any = true;
+    }
+    if (lane == 0)   // ready for the next launch
+        __hip_atomic_store(sk.cnt + (j * 8 + sk.e) * N_MMA + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    store_tile_staged(acc, smem, y, M, N, m0, n0, wave, lane);   // runs after the unit's last segment: LDS is idle
+}
+
+// ------------------------------------------------------------------------------------------------
+// dequant waves
+// ------------------------------------------------------------------------------------------------
+struct Deq {
+    char* smem;
+    rsrc_t rsrc;          // this tile's 8 row-blocks of packed weights (range-checked at the N edge)
+    uint32_t voff[2];     // lane's 16-B piece inside row-block 2d + b of the tile (the range check is on this offset:
+                          // a row-block beyond the weight's last one reads as zeros, whatever the K offset)
+    uint32_t k0;          // byte offset of the segment's first K-step inside a row-block's run
+    int d, lane, NT;
+    int row, r, h;        // W row of this thread (0..127), its row inside the block, column half (wave-uniform)
+    int off_blk;          // byte offset of the row's block inside a packed slot
+    float s4, z4;
+};
+
+template <int LAYOUT>
+__device__ __forceinline__ void issue_bp(const Deq& c, int t) {
+    // dequant wave d copies packed blocks 2d, 2d+1 (rows 32d .. 32d+31), 36 lanes each (32 for W4ROW);
+    // the LDS stride stays 576 B for every layout (bank-conflict-free block spacing)
+    constexpr int BYTES = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : MXQ_BLK_BYTES;
+    char* dst = c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.d * 2 * BP_BLK;
+    if (c.lane < BYTES / 16) {
+        const uint32_t so = c.k0 + (uint32_t)t * BYTES;
+        bufdma16(c.rsrc, c.voff[0], so, dst);
+        bufdma16(c.rsrc, c.voff[1], so, dst + BP_BLK);
+    }
+}
+
+__device__ __forceinline__ void put8(char* wt, int row, int slot, const uint32_t* o) {
+    *(u32x4*)(wt + swz(row, slot)) = (u32x4){o[0], o[1], o[2], o[3]};
+}
+
+// The packed words one thread needs for one chunk, read from the LDS copy ONE K-step before they are used, so that
+// the dequant arithmetic never waits for an LDS read.  h = 0: 2-bit groups 0, 1 (columns 0..31); h = 1: group 2 and
+// the 4-bit quarter (columns 32..63).  W2G16: h = 0 groups 0, 1; h = 1 groups 2, 3.  W4ROW: 4 code words each.
+struct Pk {
+    uint32_t c[4];    // code words
+    uint32_t z[2];    // 2-bit zero-points (fp32 bits)
+    uint32_t scw;     // the row's scale codes
+    f32x2 qq[2];      // (qs, qz) of the thread's 2-bit groups
+};
+
+template <int LAYOUT>
+__device__ __forceinline__ void load_pk(const Deq& c, int t, Pk& k) {
+    const uint32_t* blk = (const uint32_t*)(c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.off_blk);
+    if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k.c[i] = blk[mxq_w4_c4(c.h * 2 + (i >> 1), i & 1, c.r)];
+        return;
+    }
+    k.scw = ((const uint16_t*)blk)[mxq_sc_u16(c.r)];
+    const int g0 = c.h * 2;   // first 2-bit group of this thread
+    k.c[0] = blk[(LAYOUT == MXQ_LAYOUT_MIXED ? mxq_c2(0, c.r) : mxq_w2_c2(0, c.r)) + g0 * 16];
+    k.z[0] = blk[(LAYOUT == MXQ_LAYOUT_MIXED ? mxq_z2(0, c.r) : mxq_w2_z2(0, c.r)) + g0 * 16];
+    k.qq[0] = *(const f32x2*)(blk + mxq_qq(0) + g0 * 2);
+    if (LAYOUT == MXQ_LAYOUT_W2G16 || c.h == 0) {
+        k.c[1] = blk[(LAYOUT == MXQ_LAYOUT_MIXED ? mxq_c2(1, c.r) : mxq_w2_c2(1, c.r)) + g0 * 16];
+        k.z[1] = blk[(LAYOUT == MXQ_LAYOUT_MIXED ? mxq_z2(1, c.r) : mxq_w2_z2(1, c.r)) + g0 * 16];
+        k.qq[1] = *(const f32x2*)(blk + mxq_qq(1) + g0 * 2);
+    } else {
+        k.c[2] = blk[mxq_c4(0, c.r)];
+        k.c[3] = blk[mxq_c4(1, c.r)];
+    }
+}
+
+// chunk t: preloaded packed words -> fp16 W16[t & 1]
+template <int LAYOUT>
+__device__ __forceinline__ void dequant_pk(const Deq& c, int t, const Pk& k) {
+    char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
+    uint32_t o[8];
+    if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            mxq_deq4x8(k.c[2 * q], c.s4, c.z4, o);
+            mxq_deq4x8(k.c[2 * q + 1], c.s4, c.z4, o + 4);
+            put8(wt, c.row, (c.h * 2 + q) * 2, o);
+            put8(wt, c.row, (c.h * 2 + q) * 2 + 1, o + 4);
+        }
+        return;
+    }
+    const int g0 = c.h * 2;
+    mxq_deq2x16(k.c[0], mxq_scale(k.qq[0][0], k.qq[0][1], (k.scw >> (4 * g0)) & 15u), __uint_as_float(k.z[0]), o);
+    put8(wt, c.row, g0 * 2, o);
+    put8(wt, c.row, g0 * 2 + 1, o + 4);
+    if (LAYOUT == MXQ_LAYOUT_W2G16 || c.h == 0) {
+        mxq_deq2x16(k.c[1], mxq_scale(k.qq[1][0], k.qq[1][1], (k.scw >> (4 * g0 + 4)) & 15u), __uint_as_float(k.z[1]), o);
+        put8(wt, c.row, g0 * 2 + 2, o);
+        put8(wt, c.row, g0 * 2 + 3, o + 4);
+    } else {
+        mxq_deq4x8(k.c[2], c.s4, c.z4, o);
+        mxq_deq4x8(k.c[3], c.s4, c.z4, o + 4);
+        put8(wt, c.row, 6, o);
+        put8(wt, c.row, 7, o + 4);
+    }
+}
+
+template <int ABL, int LAYOUT>
+__device__ __forceinline__ void deq_segment(char* smem, int wave, int lane, const uint32_t* __restrict__ qweight,
+                                            const float4* __restrict__ rowmeta, int N, int K, int n0, int kt0,
+                                            int nsteps, u64t* dbg) {
+    constexpr int BLK_B = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : MXQ_BLK_BYTES;
+    const int NT_tile = K / BK;
+    Deq c;
+    c.smem = smem;
+    c.d = wave - N_MMA;
+    c.lane = lane;
+    c.NT = nsteps;
+    {
+        const int rb0 = n0 >> 4, rbs = (N >> 4) - rb0 < BN / 16 ? (N >> 4) - rb0 : BN / 16;   // live row-blocks
+        const uint32_t blk_stride = (uint32_t)NT_tile * BLK_B;   // bytes between consecutive row-blocks
+        c.rsrc = make_rsrc((const char*)qweight + (int64_t)rb0 * NT_tile * BLK_B, (uint32_t)rbs * blk_stride);
+        c.voff[0] = (uint32_t)lane * 16u + (uint32_t)(c.d * 2) * blk_stride;
+        c.voff[1] = c.voff[0] + blk_stride;
+        c.k0 = (uint32_t)kt0 * BLK_B;
+    }
+    const int dt = c.d * 64 + lane;   // 0..255
+    c.row = dt & 127;
+    c.h = __builtin_amdgcn_readfirstlane(dt >> 7);   // wave-uniform: dequant waves 0,1 -> 0; 2,3 -> 1
+    c.r = c.row & 15;
+    c.off_blk = (c.row >> 4) * BP_BLK;
+    {
+        int gn = n0 + c.row;
+        gn = gn < N ? gn : N - 1;
+        const float4 m = rowmeta[gn];
+        c.s4 = mxq_scale(m.z, m.w, (uint32_t)m.y);
+        c.z4 = m.x;
+    }
+    // prologue: packed blocks 0..3; W16(0); the packed words of chunk 1 in registers
+    for (int t = 0; t < BP_SLOTS && t < c.NT; ++t) issue_bp<LAYOUT>(c, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Pk cur = {}, nxt = {};
+    if constexpr (!(ABL & ABL_NO_DEQ)) {
+        load_pk<LAYOUT>(c, 0, cur);
+        dequant_pk<LAYOUT>(c, 0, cur);
+        if (c.NT > 1) load_pk<LAYOUT>(c, 1, cur);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // K-step t: read the packed words of chunk t+2 (landed one step ago), issue the DMA of chunk t+4 (its slot held
+    // chunk t, read into registers two steps ago), dequantise chunk t+1 from registers into W16[(t+1) & 1]
+    int t = 0;
+    Stamps st = {0, 0, 0, 0};
+    for (; t + 4 < c.NT; ++t) {   // steady state: everything unconditional
+        u64t t0 = 0, t1 = 0, t2 = 0;
+        if constexpr ((ABL & EXP_STAMPS) != 0) t0 = stamp();
+        if constexpr (!(ABL & ABL_NO_DEQ)) load_pk<LAYOUT>(c, t + 2, nxt);
+        issue_bp<LAYOUT>(c, t + 4);
+        if constexpr (!(ABL & ABL_NO_DEQ)) dequant_pk<LAYOUT>(c, t + 1, cur);
+        if constexpr ((ABL & EXP_STAMPS) != 0) t1 = stamp();
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // this step's 2 DMAs stay in flight
+        cur = nxt;
+        if constexpr ((ABL & EXP_STAMPS) != 0) t2 = stamp();
+        __builtin_amdgcn_s_barrier();
+        if constexpr ((ABL & EXP_STAMPS) != 0) {
+            const u64t t3 = stamp();
+            st.work += t1 - t0; st.wait += t2 - t1; st.bar += t3 - t2; st.n += 1;
+        }
+    }
+    if constexpr ((ABL & EXP_STAMPS) != 0) {
+        if (lane == 0 && dbg) {
+            u64t* d = dbg + ((int64_t)blockIdx.x * (N_MMA + N_DEQ) + wave) * 4;
+            d[0] = st.work; d[1] = st.wait; d[2] = st.bar; d[3] = st.n;
+        }
+    }
+    for (; t < c.NT; ++t) {
+        if constexpr (!(ABL & ABL_NO_DEQ)) {
+            if (t + 2 < c.NT) load_pk<LAYOUT>(c, t + 2, nxt);
+            if (t + 1 < c.NT) dequant_pk<LAYOUT>(c, t + 1, cur);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        cur = nxt;
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// grid = dp_blocks (one whole tile each) + 8 * units stream-K workgroups
+template <int ABL, int LAYOUT>
+__global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* __restrict__ x,
+                                                               const uint32_t* __restrict__ qweight,
+                                                               const float4* __restrict__ rowmeta,
+                                                               uint16_t* __restrict__ y, int M, int N, int K,
+                                                               int tiles_m, int tiles_n, int dp_blocks, int tail,
+                                                               int units, float* __restrict__ ws,
+                                                               int* __restrict__ cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NT = K / BK;
+    const int bid = blockIdx.x;
+    SkSeg sk;
+    sk.ws = ws;
+    sk.cnt = cnt;
+    sk.units = units;
+    sk.S = 0;
+    sk.u = sk.e = sk.j = sk.first = 0;
+    // a data-parallel workgroup is the degenerate unit: one tile, its whole K range
+    int base = bid, b0 = 0, b1 = NT;
+    if (bid >= dp_blocks) {
+        const int s = bid - dp_blocks;
+        sk.e = s & 7;
+        sk.u = s >> 3;
+        base = dp_blocks + sk.e;
+        sk.S = ((tail + 7 - sk.e) >> 3) * NT;   // tail tile t belongs to XCD t & 7: the first tail % 8 XCDs hold one more
+        b0 = sk_bound(sk.u, sk.S, units);
+        b1 = sk_bound(sk.u + 1, sk.S, units);
+    }
+    // every wave walks the same segment list, so the barrier counts of the two roles stay matched
+    if (wave < N_MMA) {
+        if constexpr (!(ABL & (EXP_NO_PRIO | EXP_DEQ_PRIO)))
+            __builtin_amdgcn_s_setprio(3);   // MFMA waves win issue arbitration against the dequant wave of their SIMD
+        int pj0 = -1, pn0 = 0, pj1 = -1, pn1 = 0;
+        for (int pos = b0; pos < b1;) {
+            sk.j = pos / NT;
+            const int end = b1 < (sk.j + 1) * NT ? b1 : (sk.j + 1) * NT;
+            sk.first = pos == b0;
+            int tm, tn;
+            tile_of_block(base + sk.j * 8, tiles_m, tiles_n, tm, tn);
+            int ln;   // lane id recomputed per segment and made opaque: nothing lane-derived is hoisted across the loop
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+            mma_segment<ABL>(smem, wave, ln, end - pos, x, y, M, N, K, tm * BM, tn * BN, pos - sk.j * NT, NT, sk,
+                             bid < dp_blocks);
+            if (end - pos != NT) {
+                if (sk.first) { pj0 = sk.j; pn0 = end - pos; }
+                else { pj1 = sk.j; pn1 = end - pos; }
+            }
+            pos = end;
+        }
+        if (pj0 >= 0 || pj1 >= 0) {
+            int ln;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+            // every slot store of this wave has reached the coherence point before any count moves
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int old0 = 0, old1 = 0;
+            if (ln == 0) {   // both bumps in flight together
+                if (pj0 >= 0) old0 = __hip_atomic_fetch_add(cnt + (pj0 * 8 + sk.e) * N_MMA + wave, pn0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pj1 >= 0) old1 = __hip_atomic_fetch_add(cnt + (pj1 * 8 + sk.e) * N_MMA + wave, pn1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            old0 = __builtin_amdgcn_readfirstlane(old0);
+            old1 = __builtin_amdgcn_readfirstlane(old1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler ordering only: the slot loads are agent-scope themselves
+            if (pj0 >= 0 && old0 + pn0 == NT) {
+                int tm, tn;
+                tile_of_block(base + pj0 * 8, tiles_m, tiles_n, tm, tn);
+                sk_finish(sk, pj0, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
+            }
+            if (pj1 >= 0 && old1 + pn1 == NT) {
+                int tm, tn;
+                tile_of_block(base + pj1 * 8, tiles_m, tiles_n, tm, tn);
+                sk_finish(sk, pj1, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
+            }
+        }
+    } else {
+        if constexpr ((ABL & EXP_DEQ_PRIO) != 0) __builtin_amdgcn_s_setprio(3);   // experiment: the dequant chain first
+        for (int pos = b0; pos < b1;) {
+            const int j = pos / NT;
+            const int end = b1 < (j + 1) * NT ? b1 : (j + 1) * NT;
+            int tm, tn;
+            tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
+            int ln;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+            deq_segment<ABL, LAYOUT>(smem, wave, ln, qweight, rowmeta, N, K, tn * BN, pos - j * NT, end - pos,
+                                     (u64t*)ws);
+            pos = end;
+        }
+    }
+}
+
+int cu_count() {
+    static int cus = 0;   // one device model per process on this platform
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
+constexpr size_t CNT_BYTES = 64 * 1024;   // K-step counters at the head of the workspace (>= 8*units*N_MMA ints)
+
+template <int ABL, int LAYOUT = MXQ_LAYOUT_MIXED>
+static int launch8(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                   void* workspace, size_t ws_bytes, bool force, hipStream_t stream) {
+    // the DMA descriptors address one tile's rows with 32-bit offsets: 256 rows of x, 8 row-blocks of packed weights
+    if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(BN / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 32))
+        return -1;   // MXQ_E_SHAPE
+    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm8_f16_kernel<ABL, LAYOUT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
+    const int NT = K / BK;
+    const int cus = cu_count() / 8 * 8, units = cus / 8;
+    int dp_blocks = tiles, tail = 0;
+    if (workspace && tiles % cus != 0 && units * 8 * N_MMA * sizeof(int) <= CNT_BYTES &&
+        ws_bytes >= CNT_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
+        const int t8 = (tiles % cus) / 8;   // tail tiles per XCD (the first tail % 8 XCDs hold one more)
+        const bool pays = (int64_t)(cus - tiles % cus) * NT >= (int64_t)24 * cus;   // see gemm6.hip
+        if ((force || pays) && (int64_t)t8 * NT >= (int64_t)units * 4) {
+            tail = tiles % cus;
+            dp_blocks = tiles - tail;
+        }
+    }
+    const int grid = dp_blocks + (tail ? cus : 0);
+    mxq_gemm8_f16_kernel<ABL, LAYOUT><<<grid, THREADS, SMEM_BYTES, stream>>>(
+        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
+        dp_blocks, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace);
+    return (int)hipGetLastError();
+}
+
+}   // namespace
+
+int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                         void* workspace, size_t ws_bytes, int force, hipStream_t stream) {
+    return launch8<0>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, force != 0, stream);
+}
+
+int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                int layout, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    switch (layout) {
+        case MXQ_LAYOUT_MIXED: return launch8<0, MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
+        case MXQ_LAYOUT_W2G16: return launch8<0, MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
+        case MXQ_LAYOUT_W4ROW: return launch8<0, MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
+    }
+    return -1;
+}
+
+#ifdef MXQ_PROFILING
+// Built only into libmxq_hip_prof.so (make prof; tools/): parts of the kernel removed to time the rest.
+// WRONG RESULTS by construction -- never part of libmxq_hip.so or of include/mxq_hip.h.
+// 1 = no x DMAs, 2 = no MFMA, 4 = no dequant, 256 = no output stores (sums)
+extern "C" int mxq_prof_gemm8_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+                                         int K, int abl, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (abl) {
+        case 0: return launch8<0>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 1: return launch8<1>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 2: return launch8<2>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 4: return launch8<4>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 5: return launch8<5>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 6: return launch8<6>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 256: return launch8<256>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 260: return launch8<260>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 1024: return launch8<1024>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // correct results
+        case 2048: return launch8<2048>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // correct results
+        case 2050: return launch8<2050>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+    }
+    return -1;   // MXQ_E_SHAPE: not an ablation this build carries
+}
+
+// Diagnostic build with cycle stamps (cdna guide section 7, "In-kernel stamps"): dbg receives, per workgroup and wave,
+// {work, wait, barrier, steps} cycle sums over the steady-state K-steps (u64 x 4 x 12 waves x grid).  Never timed.
+template <int ABL>
+static int launch8_stamps(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                          void* dbg, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm8_f16_kernel<ABL, MXQ_LAYOUT_MIXED>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    mxq_gemm8_f16_kernel<ABL, MXQ_LAYOUT_MIXED><<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
+        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
+        tiles_m * tiles_n, 0, 32, (float*)dbg, nullptr);
+    return (int)hipGetLastError();
+}
+extern "C" int mxq_prof_gemm8_stamps_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+                                         int K, int abl, void* dbg, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (abl) {
+        case 0: return launch8_stamps<4096>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
+        case 2048: return launch8_stamps<4096 + 2048>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
+        case 1024: return launch8_stamps<4096 + 1024>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
+        case 4: return launch8_stamps<4096 + 4>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
+        case 2: return launch8_stamps<4096 + 2>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
+    }
+    return -1;
+}
+#endif   // MXQ_PROFILING

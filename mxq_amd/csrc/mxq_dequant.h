@@ -59,14 +59,32 @@ MXQ_HD void mxq_deq2x16(uint32_t d, float s, float z, uint32_t out[8]) {
     }
 }
 
+// byte N of a word as float (one v_cvt_f32_ubyteN; spelled as asm on the device because the optimiser folds the
+// nibble masks of the caller into per-element shift+and+convert sequences otherwise: 3 ops instead of 1)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MXQ_UBYTE_F32(N)                                                          \
+    __device__ __forceinline__ float mxq_ubyte##N(uint32_t v) {                   \
+        float f;                                                                  \
+        asm("v_cvt_f32_ubyte" #N " %0, %1" : "=v"(f) : "v"(v));                   \
+        return f;                                                                 \
+    }
+MXQ_UBYTE_F32(0) MXQ_UBYTE_F32(1) MXQ_UBYTE_F32(2) MXQ_UBYTE_F32(3)
+#undef MXQ_UBYTE_F32
+#else
+MXQ_HD float mxq_ubyte0(uint32_t v) { return (float)(v & 0xFF); }
+MXQ_HD float mxq_ubyte1(uint32_t v) { return (float)((v >> 8) & 0xFF); }
+MXQ_HD float mxq_ubyte2(uint32_t v) { return (float)((v >> 16) & 0xFF); }
+MXQ_HD float mxq_ubyte3(uint32_t v) { return (float)(v >> 24); }
+#endif
+
 // 8 four-bit codes (byte-spread word d) -> 4 x packed fp16 pairs
 MXQ_HD void mxq_deq4x8(uint32_t d, float s, float z, uint32_t out[4]) {
     const uint32_t m0 = d & 0x0F0F0F0Fu;          // elements 0..3, one per byte
     const uint32_t m1 = (d >> 4) & 0x0F0F0F0Fu;   // elements 4..7
-    out[0] = mxq_pack_f16(s * ((float)(m0 & 0xFF) - z), s * ((float)((m0 >> 8) & 0xFF) - z));
-    out[1] = mxq_pack_f16(s * ((float)((m0 >> 16) & 0xFF) - z), s * ((float)(m0 >> 24) - z));
-    out[2] = mxq_pack_f16(s * ((float)(m1 & 0xFF) - z), s * ((float)((m1 >> 8) & 0xFF) - z));
-    out[3] = mxq_pack_f16(s * ((float)((m1 >> 16) & 0xFF) - z), s * ((float)(m1 >> 24) - z));
+    out[0] = mxq_pack_f16(s * (mxq_ubyte0(m0) - z), s * (mxq_ubyte1(m0) - z));
+    out[1] = mxq_pack_f16(s * (mxq_ubyte2(m0) - z), s * (mxq_ubyte3(m0) - z));
+    out[2] = mxq_pack_f16(s * (mxq_ubyte0(m1) - z), s * (mxq_ubyte1(m1) - z));
+    out[3] = mxq_pack_f16(s * (mxq_ubyte2(m1) - z), s * (mxq_ubyte3(m1) - z));
 }
 
 // Integer unpack (the bit-exact contract of the unpack kernel)

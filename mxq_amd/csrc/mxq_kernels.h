@@ -27,8 +27,19 @@ size_t mxq_gemm6_workspace_bytes();
 int mxq_launch_gemm6_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          void* workspace, size_t ws_bytes, int force,
                          hipStream_t stream);   // gemm5 + stream-K tail (gemm6.hip); force: split even when it does not pay
+int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                         void* workspace, size_t ws_bytes, int force,
+                         hipStream_t stream);   // MFMA waves stream x, dedicated waves dequantise (gemm8.hip); same workspace as gemm6
+int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream);
+// v2 GEMV (gemv2.hip): 16-byte weight loads, M <= 8; teams: 0 = auto, else waves / 4 per workgroup (1, 2, 4)
+int mxq_launch_gemv2_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                         int layout, int teams, hipStream_t stream);
+int mxq_launch_gemv2_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                               int prologue, const void* norm_w, float eps, const void* residual, int teams,
+                               hipStream_t stream);
 int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
                                int K, int layout, hipStream_t stream);
 int mxq_launch_gemm4_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,

@@ -176,7 +176,7 @@ def dequant(p: PackedMXQ) -> torch.Tensor:
     return out
 
 
-GEMM_PATHS = {"gemm": 0, "gemm1": 1, "gemm6": 6, "gemm7": 7}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
+GEMM_PATHS = {"gemm": 0, "gemm1": 1, "gemm6": 6, "gemm7": 7, "gemm8": 8, "gemm9": 9}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
 
 
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
@@ -208,7 +208,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         elif path == "auto" and M <= 4:                          # GEMV: no workspace involved
             rc = lib.mxq_linear_f16(*args, _stream(x2))
         else:
-            ws = gemm_workspace(x2.device) if path in ("auto", "gemm", "gemm6", "gemm7") else None
+            ws = gemm_workspace(x2.device) if path in ("auto", "gemm", "gemm6", "gemm7", "gemm8", "gemm9") else None
             wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
             if path == "auto":
                 rc = lib.mxq_linear_f16_ws(*args, wsp, wsn, _stream(x2))

@@ -157,7 +157,7 @@ def test_mxqgpt_driver_api(dev, g1):
 # ----------------------------------------------------------------------------------------
 # dequant-GEMM / GEMV
 # ----------------------------------------------------------------------------------------
-GEMM_KERNELS = ["gemm", "gemm1", "gemm6", "gemm7"]      # packing.GEMM_PATHS: every kernel the product library ships
+GEMM_KERNELS = ["gemm", "gemm1", "gemm6", "gemm7", "gemm8", "gemm9"]      # packing.GEMM_PATHS: every kernel the product library ships
 
 
 def _packed_case(dev, N, K, seed):
@@ -210,7 +210,8 @@ def test_gemm_integer_exact_layout(dev):
                                    (1024, 4224, 2048),    # 132 tiles: XCDs 0-3 hold 17 tail tiles, 4-7 hold 16
                                    (100, 1152, 8192),     # 9 tiles: XCD 0 holds two, the others one; half-empty 256-row tile
                                    (2048, 5120, 1024)])   # 320 tiles = one full round + a 64-tile tail
-def test_gemm_stream_k_tail(dev, M, N, K):
+@pytest.mark.parametrize("sk", ["gemm7", "gemm9"])
+def test_gemm_stream_k_tail(dev, M, N, K, sk):
     """csrc/gemm6.hip: tiles beyond the last full round of CUs are split along K over all CUs and
     reduced through the workspace.  Checks (1) against the oracle matmul, (2) that the workspace
     counters are left zeroed, (3) run-to-run bit-determinism, (4) agreement with the 128x128-tile
@@ -219,21 +220,23 @@ def test_gemm_stream_k_tail(dev, M, N, K):
     p, w16, g = _packed_case(dev, N, K, M + N + K)
     x = torch.randn(M, K, generator=g).half()
     xd = x.to(dev)
-    y = packing.linear(xd, p, path="gemm7")
-    _check_gemm(y.cpu().numpy(), O.linear_ref(x.numpy(), w16), f"gemm7 {M}x{N}x{K}")
+    y = packing.linear(xd, p, path=sk)
+    _check_gemm(y.cpu().numpy(), O.linear_ref(x.numpy(), w16), f"{sk} {M}x{N}x{K}")
     ws = packing.gemm_workspace(xd.device)
     assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
     for _ in range(3):
-        assert torch.equal(packing.linear(xd, p, path="gemm7"), y)
+        assert torch.equal(packing.linear(xd, p, path=sk), y)
     y5 = packing.linear(xd, p, path="gemm1")
     assert ((y.float() - y5.float()).abs().max() / y5.float().abs().max()).item() <= 1e-3
     # the default dispatch is the same kernel, splitting only where it pays: equal up to summation order
     yd = packing.linear(xd, p, path="gemm")
     assert ((y.float() - yd.float()).abs().max() / y5.float().abs().max()).item() <= 1e-3
-    assert torch.equal(packing.linear(xd, p, path="gemm6"), yd)
+    if sk == "gemm7":
+        assert torch.equal(packing.linear(xd, p, path="gemm6"), yd)
 
 
-def test_stream_k_partition_fuzz(dev):
+@pytest.mark.parametrize("sk", ["gemm7", "gemm9"])
+def test_stream_k_partition_fuzz(dev, sk):
     """Random (tokens, out, in) shapes through the forced stream-K schedule against the single-tile kernel:
     exercises unit ranges that start / end anywhere inside tiles, XCDs with unequal tail lengths, units with
     one, two and many segments, ragged M and N edges."""
@@ -247,11 +250,11 @@ def test_stream_k_partition_fuzz(dev):
         W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
         p = packing.quantize_pack(W)
         x = torch.randn(M, K, generator=g, device=dev).half()
-        y = packing.linear(x, p, path="gemm7").float()
+        y = packing.linear(x, p, path=sk).float()
         r = (x.float() @ packing.dequant(p).float().t())
         err = ((y - r).abs().max() / r.abs().max()).item()
         assert err <= REL_TOL, (M, N, K, err)
-        assert torch.equal(packing.linear(x, p, path="gemm7").float(), y), (M, N, K)
+        assert torch.equal(packing.linear(x, p, path=sk).float(), y), (M, N, K)
     ws = packing.gemm_workspace(torch.device(dev))
     assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
 
@@ -292,7 +295,7 @@ def test_linear_empty_and_nonfinite_inputs(dev):
     p, w16, g = _packed_case(dev, 256, 4096, 11)
     assert packing.linear(torch.empty(0, 4096, dtype=torch.float16, device=dev), p).shape == (0, 256)
     assert packing.linear(torch.empty(2, 0, 4096, dtype=torch.float16, device=dev), p).shape == (2, 0, 256)
-    for M, path in ((3, "gemv"), (100, "gemm1"), (300, "gemm7")):
+    for M, path in ((3, "gemv"), (100, "gemm1"), (300, "gemm7"), (300, "gemm9"), (700, "gemm8")):
         x = torch.randn(M, 4096, generator=g).half()
         clean = packing.linear(x.to(dev), p, path=path)
         x[1, 7] = float("nan")

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Where a K-step of the gemm8 prefill kernel spends its cycles, per wave role (diagnostic build with s_memtime
+stamps in libmxq_hip_prof.so; the stamps perturb the run: read the SHARES, not the length).
+    python tools/gemm_stamps.py [--m 2048] [--n 4096] [--k 4096] [--abl 0,2048,4,2]"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mxq_amd import packing  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--m", type=int, default=2048)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=4096)
+    ap.add_argument("--abl", default="0,2048,1024,4,2")
+    ap.add_argument("--lib", default="mxq_amd/libmxq_hip_prof.so")
+    args = ap.parse_args()
+    lib = ctypes.CDLL(os.path.join(ROOT, args.lib))
+    fn = lib.mxq_prof_gemm8_stamps_f16
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
+    dev = torch.device("cuda:0")
+    M, N, K = args.m, args.n, args.k
+    g = torch.Generator(device=dev).manual_seed(1)
+    p = packing.quantize_pack((torch.randn(N, K, generator=g, device=dev) * 0.02).half())
+    x = torch.randn(M, K, generator=g, device=dev).half()
+    y = torch.empty(M, N, device=dev, dtype=torch.float16)
+    grid = ((M + 255) // 256) * ((N + 127) // 128)
+    for abl in [int(a) for a in args.abl.split(",")]:
+        dbg = torch.zeros(grid * 12 * 4, dtype=torch.int64, device=dev)
+        for _ in range(20):   # warm clocks; the last launch's sums are read
+            rc = fn(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), y.data_ptr(), M, N, K, abl, dbg.data_ptr(),
+                    torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+        torch.cuda.synchronize()
+        d = dbg.view(grid, 12, 4).double().cpu()
+        steps = d[:, :, 3].clamp(min=1)
+        per = d[:, :, :3] / steps[:, :, None]            # cycles per K-step
+        for name, sl in (("MFMA waves 0-7", slice(0, 8)), ("dequant waves h=0 (8,9)", slice(8, 10)),
+                         ("dequant waves h=1 (10,11)", slice(10, 12))):
+            w = per[:, sl, :].mean(dim=(0, 1))
+            print(f"abl {abl:5d} {name:28s} work {w[0]:7.0f}  wait {w[1]:6.0f}  barrier {w[2]:6.0f}  total {w.sum():7.0f} cycles/step",
+                  flush=True)
+
+
+if __name__ == "__main__":
+    main()
