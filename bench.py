@@ -13,7 +13,7 @@ N > 1: whole decoder layers are sharded over the ranks (rank r owns layers [32r/
 SURVEY.md 8e) and N sequences flow through the layer pipeline per step, the [2048, 4096] fp16
 hidden state hopping rank -> rank+1 by RCCL send/recv: per-GPU work is fixed ("weak").
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (mxq_gemm6_f16_kernel,
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (mxq_gemm8_f16_kernel,
 MFMA-bound): algorithmic 2*M*N*K flops of the launches of one step / their device time measured
 with HIP events on the launch stream.  `cpu_baseline` times the CPU restatement of the
 reference's dequant + F.linear (oracle/cpu_linear.py) on a bounded sample, rank 0 / N = 1 only.
@@ -190,7 +190,7 @@ def main():
     achieved = flops_rank_step / (dev_ms / args.steps * 1e-3) / 1e12
 
     traffic = None       # HBM bytes per launch from rocprofv3 PMC counters (collected offline, see the file)
-    tpath = os.path.join(ROOT, "profiles", "r01_gemm6_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_gemm8_traffic.json")
     if world == 1 and os.path.exists(tpath):
         traffic = json.load(open(tpath))["avg_hbm_bytes_per_launch"]
     if rank == 0:
@@ -212,7 +212,7 @@ def main():
                        f"[2048,4096] fp16 hidden state"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "mxq_gemm6_f16_kernel", "avg_launch_ms": round(kern_ms, 5),
+                         "kernel": "mxq_gemm8_f16_kernel", "avg_launch_ms": round(kern_ms, 5),
                          "launches_per_step": launches_rank_step,
                          "algorithmic_flop_per_launch": flops_rank_step / launches_rank_step},
         }

@@ -92,7 +92,7 @@ int mxq_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* 
 int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                  void* stream); /* M <= 4 */
 /* The same Linear with a caller-owned scratch buffer, which lets the prefill GEMM balance launches
- * whose tile count is not a multiple of the CU count (stream-K tail, csrc/gemm6.hip): e.g. 512 tokens
+ * whose tile count is not a multiple of the CU count (stream-K tail, csrc/gemm8.hip): e.g. 512 tokens
  * x 4096^2 is 64 tiles, a quarter of the 256 CUs, unless every CU takes a quarter of a tile's K range.
  * `workspace` is device memory of at least mxq_gemm_workspace_bytes() bytes, 16-byte aligned, whose
  * first 64 KiB the caller zeroes ONCE (hipMemset) before first use; the kernels leave it zeroed, so
@@ -100,10 +100,10 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * different workspaces).  workspace == NULL selects the workspace-free schedule of mxq_linear_f16.
  * The tail is only split where that pays (about 24 idle K-steps per CU; it does for 128 < M <= 1024 on
  * the Llama shapes, not for gate/up at M = 2048).
- * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 6 = the
- * round-1 wave-specialised stream-K kernel at any M, 7 = the same but splitting whenever it is structurally
- * possible (tests), 8 / 9 = likewise for the kernel whose MFMA waves stream x and whose dequant runs on
- * dedicated waves (csrc/gemm8.hip); anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
+ * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 8 = the
+ * 256x128-tile kernel (MFMA waves stream x, dedicated waves dequantise, persistent over tiles, stream-K tail;
+ * csrc/gemm8.hip) at any M, 9 = the same but splitting its tail whenever that is structurally possible (tests);
+ * anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
  * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
  * used by tools/ alone: they are not part of this ABI.) */
 size_t mxq_gemm_workspace_bytes(void);

@@ -140,7 +140,7 @@ int mxq_gemm_f16_layout(const void* x, const void* qweight, const void* rowmeta,
                         int layout, void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (!layout_ok(layout)) return MXQ_E_SHAPE;
-    return mxq_launch_gemm4_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
+    return mxq_launch_gemm8_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, nullptr, 0, (hipStream_t)stream);
 }
 
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -150,7 +150,7 @@ int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void
     return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
 }
 
-size_t mxq_gemm_workspace_bytes(void) { return mxq_gemm6_workspace_bytes(); }
+size_t mxq_gemm_workspace_bytes(void) { return mxq_gemm8_workspace_bytes(); }
 
 static int gemm_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* workspace, size_t ws_bytes, hipStream_t stream) {
@@ -158,7 +158,7 @@ static int gemm_ws(const void* x, const void* qweight, const void* rowmeta, void
     // CUs busy when there are few tiles: 64 tokens x 4096^2 34 us vs 57 us for the 128-row-tile kernel);
     // without one, mxq_linear_f16's dispatch
     if (!workspace) return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, stream);
-    return mxq_launch_gemm6_f16(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
+    return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
 }
 
 int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -177,9 +177,6 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (variant == 1) return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
     if (variant == 8 || variant == 9)
         return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 9,
-                                    (hipStream_t)stream);
-    if (variant == 6 || variant == 7)
-        return mxq_launch_gemm6_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 7,
                                     (hipStream_t)stream);
     return MXQ_E_SHAPE;
 }

@@ -1,23 +1,38 @@
-// W2/4 x A16 dequant-GEMM, v8: MFMA waves own the activation stream, dedicated waves own ALL of the dequant.
+// W2/4 x A16 dequant-GEMM for prefill (any token count > 8): MFMA waves own the activation stream, dedicated waves
+// own ALL of the dequant; persistent over tiles, hybrid stream-K tail.
 //
 // Counterpart of the reference's (never built) AWQ tensor-core GEMM
 // mxq_quant/cuda_kernel/csrc/quantization/gemm_cuda_gen.cu:28-218 and of the implicit nn.Linear on the
 // fake-quant weight (mxq_quant/main.py:85); arithmetic contract x16 . fp16(scale * (q - zero))^T of
 // lib/quantizer.py:19-20 + mxqgpt.py:448, fp32 accumulation.
 //
-// gemm6 (round 1) put the 2-bit dequant (~48 VALU ops per K-step) INSIDE the MFMA waves' instruction streams and
-// every LDS-DMA on four producer waves (10 DMA issues each per K-step, ~100 cycles apiece: they had no time left
-// for more dequant).  An in-order wave that carries VALU chains between its MFMAs stalls its MFMAs on them, and
-// both MFMA waves of a SIMD do so in lockstep.  Here the roles are cut the other way:
-//   * waves 0-7  "MFMA waves": fragment reads + 32 MFMAs per K-step, and the x tile's LDS-DMA (4 x 1 KiB
-//     buffer_load ... lds each per K-step, addressed by ONE per-lane offset VGPR each + a scalar K offset; rows
-//     beyond M read as zeros through the buffer descriptor's range check) -- no VALU work in the loop at all;
+// Tile 256 tokens x 128 channels x K-step 64 (= one MXQ chunk); 12 waves with fixed roles:
+//   * waves 0-7  "MFMA waves" (one 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_f16 each): fragment reads + 32 MFMAs
+//     per K-step, and the x tile's LDS-DMA (4 x 1 KiB buffer_load ... lds each per K-step, addressed by one
+//     per-lane offset VGPR each + a scalar K offset; rows beyond M read as zeros through the buffer descriptor's
+//     range check) -- no VALU work in the loop at all.  (Round 1's kernel put the 2-bit dequant, ~48 VALU ops per
+//     K-step, INSIDE the MFMA waves' instruction streams: an in-order wave that carries VALU chains between its
+//     MFMAs stalls its MFMAs on them, and both MFMA waves of a SIMD do so in lockstep.)
 //   * waves 8-11 "dequant waves" (one per SIMD): the packed blocks' LDS-DMA (2 per wave and K-step) and the whole
-//     dequant of chunk t+1 (2-bit LUT/v_perm groups and the 4-bit arm) from the LDS copy into the fp16 W16 tile.
-//     Their VALU ops fill the vector-issue slots the MFMAs leave free, in no fixed order relative to them.
-// Tile 256 tokens x 128 channels x K-step 64 (= one MXQ chunk), one raw s_barrier per K-step, x ring 3 slots
-// (DMA two steps ahead, counted vmcnt), packed ring 3 slots, W16 double buffer; hybrid stream-K tail with the
-// same unit / slot / counter protocol as gemm6 (see there).  D^T = W . x^T: a lane owns 4 consecutive channels.
+//     dequant of chunk t+1 (2-bit LUT / v_perm groups and the 4-bit arm) into the fp16 W16 tile, from packed words
+//     read out of the LDS copy one K-step earlier.  Their VALU ops fill the vector-issue slots the MFMAs leave
+//     free, in no fixed order relative to them; they run at raised issue priority (the dequant chain is the longer
+//     one of a K-step) and with scalar fp32 ops (no SLP packing: Makefile).
+//   * one raw s_barrier per K-step; x ring 3 slots (DMA two steps ahead, counted vmcnt), packed ring 4 slots, W16
+//     double buffer: 146 KiB of LDS.  D^T = W . x^T: a lane owns 4 consecutive channels of a token.
+//   * the output leaves without an LDS round trip (store_tile_xpose), so a workgroup that runs several tiles issues
+//     the next tile's first DMAs behind the last barrier of this one and they fly under its epilogue.
+//
+// Grid = min(tiles, CUs) persistent workgroups dealing whole tiles round-robin + (with a workspace) one stream-K
+// workgroup per CU for the tiles beyond the last full round ("tail"): their K-steps are dealt evenly, XCD by XCD
+// (tail tile t belongs to XCD t & 7; an XCD's 32 units share its tail tiles so the operands stay in that L2).  A
+// unit's K range covers the end of one tile and the start of the next; each piece ("segment") runs the same pipeline
+// on a shifted K window.  A segment that does not cover its tile's whole K leaves its fp32 accumulators in a
+// workspace slot and, after the unit's last segment, bumps a per-(tile, wave) K-step counter; the wave whose bump
+// completes the count sums the slots in unit order (its own re-read from the slot) -- a fixed order, so the
+// result does not depend on which wave finishes -- writes fp16 y and re-zeroes the counter.  Nobody ever waits on
+// another workgroup.  Slots and counters cross XCDs (one L2 each): slot traffic is agent-scope relaxed atomics
+// (global_store / load ... sc1), ordered against the counter bump by s_waitcnt vmcnt(0).
 #include <hip/hip_runtime.h>
 
 #include "mxq_dequant.h"
@@ -48,7 +63,7 @@ static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 // profiling-only switches (template parameter ABL; product build = 0)
 constexpr int ABL_NO_MFMA = 2, ABL_NO_DEQ = 4, ABL_NO_XDMA = 1, ABL_NO_STORE = 256;
 // scheduling experiments (correct results): issue priorities of the two roles
-constexpr int EXP_NO_PRIO = 1024, EXP_DEQ_PRIO = 2048, EXP_STAMPS = 4096;
+constexpr int EXP_NO_PRIO = 1024, EXP_MMA_PRIO = 2048, EXP_STAMPS = 4096;
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
@@ -62,7 +77,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 
-// XCD-aware tile order (speed only; same as gemm6)
+// XCD-aware tile order (speed only): tiles are dealt to the 8 XCDs as compact 2-D blocks (4 x 2 regions)
 __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
     if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0) {
         const int e = bid & 7, l = bid >> 3;
@@ -84,7 +99,7 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
 }
 
 // ------------------------------------------------------------------------------------------------
-// stream-K bookkeeping (protocol: gemm6.hip header)
+// stream-K bookkeeping (protocol: header)
 // ------------------------------------------------------------------------------------------------
 struct SkSeg {
     float* ws;        // partial slots: [unit = 8u+e][2][BM*BN] fp32
@@ -219,6 +234,41 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[4][4], uint16_t* _
     }
 }
 
+// The tile WITHOUT an LDS round trip: a lane's accumulators are 4 channels (8 B as fp16) of W-fragment block i for
+// each of 4 token blocks j; the 4 lanes {fr, fr+16, fr+32, fr+48} hold one token's 64 channels as a 4 x 4 grid of
+// 8-byte cells (block i, quarter fq).  Two butterfly stages of lane swaps (v_permlane32_swap: lanes +-32 <-> blocks
+// +-2; v_permlane16_swap: lanes +-16 <-> blocks +-1) transpose the grid, after which lane fq owns block fq whole:
+// 32 contiguous bytes = two 16-byte stores, and the 4 lanes together write the token's full 128-B line.  Needs no
+// LDS, so the x ring can be refilled for the NEXT tile while this one is still being written (persistent loop).
+__device__ __forceinline__ void store_tile_xpose(const f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N,
+                                                 int m0, int n0, int wm, int wn, int fr, int fq) {
+    typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+    const int n = n0 + wn * 64 + fq * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t c[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            c[i][0] = mxq_pack_f16(acc[i][j][0], acc[i][j][1]);
+            c[i][1] = mxq_pack_f16(acc[i][j][2], acc[i][j][3]);
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            u32x2v r;
+            r = __builtin_amdgcn_permlane32_swap(c[0][d], c[2][d], false, false); c[0][d] = r[0]; c[2][d] = r[1];
+            r = __builtin_amdgcn_permlane32_swap(c[1][d], c[3][d], false, false); c[1][d] = r[0]; c[3][d] = r[1];
+            r = __builtin_amdgcn_permlane16_swap(c[0][d], c[1][d], false, false); c[0][d] = r[0]; c[1][d] = r[1];
+            r = __builtin_amdgcn_permlane16_swap(c[2][d], c[3][d], false, false); c[2][d] = r[0]; c[3][d] = r[1];
+        }
+        const int m = m0 + wm * 64 + j * 16 + fr;
+        if (m < M && n < N) {
+            uint16_t* dst = y + (int64_t)m * N + n;
+            *(u32x4*)dst = (u32x4){c[0][0], c[0][1], c[1][0], c[1][1]};
+            *(u32x4*)(dst + 8) = (u32x4){c[2][0], c[2][1], c[3][0], c[3][1]};
+        }
+    }
+}
+
 // The tile through LDS (the wave's own 9 KB of the idle x ring) so that it leaves as full 128-B lines, 16 B per
 // lane; only for workgroups that run a single whole tile (a stream-K unit's next segment may already be
 // refilling the ring).
@@ -245,22 +295,37 @@ __device__ __forceinline__ void store_tile_staged(const f32x4 (&acc)[4][4], char
     }
 }
 
-template <int ABL>
-__device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int NT, const uint16_t* __restrict__ x,
-                                            uint16_t* __restrict__ y, int M, int N, int K, int m0, int n0, int kt0,
-                                            int NT_tile, const SkSeg& sk, bool lds_free) {
-    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
-    XDma xd;
-    {
-        const int rows = M - m0 < BM ? M - m0 : BM;                       // live rows of this tile
-        xd.rsrc = make_rsrc(x + (int64_t)m0 * K, (uint32_t)rows * (uint32_t)K * 2u);
-        xd.k0 = (uint32_t)kt0 * (BK * 2);
+__device__ __forceinline__ void xdma_setup(XDma& xd, const uint16_t* __restrict__ x, int M, int K, int m0, int kt0,
+                                           int wave, int lane) {
+    const int rows = M - m0 < BM ? M - m0 : BM;                       // live rows of this tile
+    xd.rsrc = make_rsrc(x + (int64_t)m0 * K, (uint32_t)rows * (uint32_t)K * 2u);
+    xd.k0 = (uint32_t)kt0 * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 32 + i * 8 + (lane >> 3);
-            xd.voff[i] = (uint32_t)row * (uint32_t)K * 2u + ((((uint32_t)lane & 7u) ^ ((uint32_t)row & 7u)) << 4);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        xd.voff[i] = (uint32_t)row * (uint32_t)K * 2u + ((((uint32_t)lane & 7u) ^ ((uint32_t)row & 7u)) << 4);
     }
+}
+// a segment's prologue DMAs: x of its steps 0 and 1 (needs the whole x ring idle: every read of the previous
+// segment's slots lies before that segment's last barrier)
+template <int ABL>
+__device__ __forceinline__ void mma_prologue_issue(const XDma& xd, char* smem, int wave, int NT) {
+    if constexpr (!(ABL & ABL_NO_XDMA)) {
+        issue_x<0, 4>(xd, smem, wave, 0);
+        if (NT > 1) issue_x<0, 4>(xd, smem, wave, 1);
+    }
+}
+
+// One segment = NT K-steps of one tile.  pre: its prologue DMAs are already in flight (issued by the caller behind
+// the previous segment's last barrier; other VMEM traffic of this wave -- the previous tile's output stores -- may
+// sit in between, so the first wait is a full one).  After the last barrier, BEFORE the final 16 MFMAs and the
+// output, `next(...)` runs: the persistent loop issues the next tile's prologue DMAs there, which then fly under
+// this tile's epilogue.
+template <int ABL, class Next>
+__device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int NT, const XDma& xd, bool pre,
+                                            uint16_t* __restrict__ y, int M, int N, int m0, int n0, int NT_tile,
+                                            const SkSeg& sk, Next&& next) {
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -268,14 +333,10 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     Frag4 wf0, xf0, wf1, xf1;
 
-    // prologue: x of steps 0 and 1
-    if constexpr (!(ABL & ABL_NO_XDMA)) {
-        issue_x<0, 4>(xd, smem, wave, 0);
-        if (NT > 1) issue_x<0, 4>(xd, smem, wave, 1);
-    }
-    if (NT > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (!pre) mma_prologue_issue<ABL>(xd, smem, wave, NT);
+    if (NT > 1 && !pre) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // prologue barrier 1: x tile 0 and packed blocks 0..2 landed
+    __builtin_amdgcn_s_barrier();   // prologue barrier 1: x tile 0 and packed blocks 0..3 landed
     __builtin_amdgcn_s_barrier();   // prologue barrier 2: W16(0) written by the dequant waves
 
     // step 0: no previous half
@@ -301,7 +362,8 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
         }
     }
     for (; t < NT; ++t) mma_step<ABL, false>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
-    mfma_rows<0, 4, ABL>(acc, wf1, xf1);   // (NT-1, kk=1)
+    next();                                  // the ring is idle from here on
+    mfma_rows<0, 4, ABL>(acc, wf1, xf1);     // (NT-1, kk=1)
 
     if (NT != NT_tile) {
         // partial segment: park the accumulators in this unit's slot; counted in after the unit's last segment
@@ -313,15 +375,14 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
         return;
     }
     if constexpr (!(ABL & ABL_NO_STORE)) {
-        if (lds_free) store_tile_staged(acc, smem, y, M, N, m0, n0, wave, lane);
-        else store_tile(acc, y, M, N, m0, n0, wm, wn, fr, fq);
+        store_tile_xpose(acc, y, M, N, m0, n0, wm, wn, fr, fq);
     } else {   // keep every accumulator alive without writing the tile
-        float s = 0.f;
+        float s_ = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (s == 123.456f) y[0] = 1;
+            for (int j = 0; j < 4; ++j) s_ += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (s_ == 123.456f) y[0] = 1;
     }
 }
 
@@ -354,7 +415,7 @@ __device__ __forceinline__ void sk_finish(const SkSeg& sk, int j, int NT_tile, i
     }
     if (lane == 0)   // ready for the next launch
         __hip_atomic_store(sk.cnt + (j * 8 + sk.e) * N_MMA + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    store_tile_staged(acc, smem, y, M, N, m0, n0, wave, lane);   // runs after the unit's last segment: LDS is idle
+    store_tile_xpose(acc, y, M, N, m0, n0, wave >> 1, wave & 1, lane & 15, lane >> 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -370,6 +431,7 @@ struct Deq {
     int row, r, h;        // W row of this thread (0..127), its row inside the block, column half (wave-uniform)
     int off_blk;          // byte offset of the row's block inside a packed slot
     float s4, z4;
+    float4 rm;            // the row's 4-bit-arm parameters as loaded (rowmeta)
 };
 
 template <int LAYOUT>
@@ -453,41 +515,46 @@ __device__ __forceinline__ void dequant_pk(const Deq& c, int t, const Pk& k) {
     }
 }
 
-template <int ABL, int LAYOUT>
-__device__ __forceinline__ void deq_segment(char* smem, int wave, int lane, const uint32_t* __restrict__ qweight,
-                                            const float4* __restrict__ rowmeta, int N, int K, int n0, int kt0,
-                                            int nsteps, u64t* dbg) {
+template <int LAYOUT>
+__device__ __forceinline__ void deq_setup(Deq& c, char* smem, int wave, int lane, const uint32_t* __restrict__ qweight,
+                                          int N, int K, int n0, int kt0, int nsteps) {
     constexpr int BLK_B = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : MXQ_BLK_BYTES;
     const int NT_tile = K / BK;
-    Deq c;
     c.smem = smem;
     c.d = wave - N_MMA;
     c.lane = lane;
     c.NT = nsteps;
-    {
-        const int rb0 = n0 >> 4, rbs = (N >> 4) - rb0 < BN / 16 ? (N >> 4) - rb0 : BN / 16;   // live row-blocks
-        const uint32_t blk_stride = (uint32_t)NT_tile * BLK_B;   // bytes between consecutive row-blocks
-        c.rsrc = make_rsrc((const char*)qweight + (int64_t)rb0 * NT_tile * BLK_B, (uint32_t)rbs * blk_stride);
-        c.voff[0] = (uint32_t)lane * 16u + (uint32_t)(c.d * 2) * blk_stride;
-        c.voff[1] = c.voff[0] + blk_stride;
-        c.k0 = (uint32_t)kt0 * BLK_B;
-    }
+    const int rb0 = n0 >> 4, rbs = (N >> 4) - rb0 < BN / 16 ? (N >> 4) - rb0 : BN / 16;   // live row-blocks
+    const uint32_t blk_stride = (uint32_t)NT_tile * BLK_B;   // bytes between consecutive row-blocks
+    c.rsrc = make_rsrc((const char*)qweight + (int64_t)rb0 * NT_tile * BLK_B, (uint32_t)rbs * blk_stride);
+    c.voff[0] = (uint32_t)lane * 16u + (uint32_t)(c.d * 2) * blk_stride;
+    c.voff[1] = c.voff[0] + blk_stride;
+    c.k0 = (uint32_t)kt0 * BLK_B;
     const int dt = c.d * 64 + lane;   // 0..255
     c.row = dt & 127;
     c.h = __builtin_amdgcn_readfirstlane(dt >> 7);   // wave-uniform: dequant waves 0,1 -> 0; 2,3 -> 1
     c.r = c.row & 15;
     c.off_blk = (c.row >> 4) * BP_BLK;
-    {
-        int gn = n0 + c.row;
-        gn = gn < N ? gn : N - 1;
-        const float4 m = rowmeta[gn];
-        c.s4 = mxq_scale(m.z, m.w, (uint32_t)m.y);
-        c.z4 = m.x;
-    }
-    // prologue: packed blocks 0..3; W16(0); the packed words of chunk 1 in registers
+}
+// a segment's prologue DMAs (packed blocks of its first BP_SLOTS K-steps: needs the whole packed ring idle) and
+// the row's 4-bit-arm parameters; the values are first used behind prologue barrier 1
+template <int LAYOUT>
+__device__ __forceinline__ void deq_prologue_issue(Deq& c, const float4* __restrict__ rowmeta, int N, int n0) {
     for (int t = 0; t < BP_SLOTS && t < c.NT; ++t) issue_bp<LAYOUT>(c, t);
+    int gn = n0 + c.row;
+    gn = gn < N ? gn : N - 1;
+    c.rm = rowmeta[gn];
+}
+
+// One segment on the dequant waves; pre / next as in mma_segment.
+template <int ABL, int LAYOUT, class Next>
+__device__ __forceinline__ void deq_segment(Deq& c, int wave, int lane, const float4* __restrict__ rowmeta, int N,
+                                            int n0, bool pre, u64t* dbg, Next&& next) {
+    if (!pre) deq_prologue_issue<LAYOUT>(c, rowmeta, N, n0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    c.s4 = mxq_scale(c.rm.z, c.rm.w, (uint32_t)c.rm.y);
+    c.z4 = c.rm.x;
     Pk cur = {}, nxt = {};
     if constexpr (!(ABL & ABL_NO_DEQ)) {
         load_pk<LAYOUT>(c, 0, cur);
@@ -532,16 +599,22 @@ __device__ __forceinline__ void deq_segment(char* smem, int wave, int lane, cons
         cur = nxt;
         __builtin_amdgcn_s_barrier();
     }
+    next();   // the rings are idle from here on
 }
 
-// grid = dp_blocks (one whole tile each) + 8 * units stream-K workgroups
+#define MXQ_LANE_ID(ln) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln))
+
+// grid = dp_grid persistent workgroups, which deal the first dp_tiles tiles round-robin (tile = block + k * dp_grid:
+// blocks b and b + 8 share an XCD and dp_grid is a multiple of 8 or the tile count itself, so a workgroup's tiles
+// keep its XCD's label) and overlap one tile's output with the next one's first DMAs, + 8 * units stream-K
+// workgroups for the `tail` tiles beyond them.
 template <int ABL, int LAYOUT>
 __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* __restrict__ x,
                                                                const uint32_t* __restrict__ qweight,
                                                                const float4* __restrict__ rowmeta,
                                                                uint16_t* __restrict__ y, int M, int N, int K,
-                                                               int tiles_m, int tiles_n, int dp_blocks, int tail,
-                                                               int units, float* __restrict__ ws,
+                                                               int tiles_m, int tiles_n, int dp_tiles, int dp_grid,
+                                                               int tail, int units, float* __restrict__ ws,
                                                                int* __restrict__ cnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -553,21 +626,70 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
     sk.units = units;
     sk.S = 0;
     sk.u = sk.e = sk.j = sk.first = 0;
-    // a data-parallel workgroup is the degenerate unit: one tile, its whole K range
-    int base = bid, b0 = 0, b1 = NT;
-    if (bid >= dp_blocks) {
-        const int s = bid - dp_blocks;
-        sk.e = s & 7;
-        sk.u = s >> 3;
-        base = dp_blocks + sk.e;
-        sk.S = ((tail + 7 - sk.e) >> 3) * NT;   // tail tile t belongs to XCD t & 7: the first tail % 8 XCDs hold one more
-        b0 = sk_bound(sk.u, sk.S, units);
-        b1 = sk_bound(sk.u + 1, sk.S, units);
+    auto nothing = [] {};
+    if (wave < N_MMA) {
+        if constexpr ((ABL & EXP_MMA_PRIO) != 0) __builtin_amdgcn_s_setprio(3);   // experiment: MFMA waves first
+    } else {
+        // the dequant chain is the longer one of a K-step: its VALU ops go first whenever they are ready (the MFMAs
+        // lose a 4-cycle issue slot each time, the chain would lose up to 16)
+        if constexpr (!(ABL & (EXP_NO_PRIO | EXP_MMA_PRIO))) __builtin_amdgcn_s_setprio(3);
     }
+
+    if (bid < dp_grid) {
+        // ---- persistent data-parallel workgroup: whole tiles bid, bid + dp_grid, ...
+        int tm, tn;
+        tile_of_block(bid, tiles_m, tiles_n, tm, tn);
+        if (wave < N_MMA) {
+            int ln;
+            MXQ_LANE_ID(ln);
+            XDma cur, nxt;
+            xdma_setup(cur, x, M, K, tm * BM, 0, wave, ln);
+            mma_prologue_issue<ABL>(cur, smem, wave, NT);
+            for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
+                MXQ_LANE_ID(ln);   // recomputed per tile and opaque: nothing lane-derived is hoisted (and spilled) across the loop
+                const int m0 = tm * BM, n0 = tn * BN;
+                const bool more = tile + dp_grid < dp_tiles;
+                if (more) tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
+                mma_segment<ABL>(smem, wave, ln, NT, cur, true, y, M, N, m0, n0, NT, sk, [&] {
+                    if (more) {
+                        xdma_setup(nxt, x, M, K, tm * BM, 0, wave, ln);
+                        mma_prologue_issue<ABL>(nxt, smem, wave, NT);
+                    }
+                });
+                cur = nxt;
+            }
+        } else {
+            int ln;
+            MXQ_LANE_ID(ln);
+            Deq cur, nxt;
+            deq_setup<LAYOUT>(cur, smem, wave, ln, qweight, N, K, tn * BN, 0, NT);
+            deq_prologue_issue<LAYOUT>(cur, rowmeta, N, tn * BN);
+            for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
+                MXQ_LANE_ID(ln);
+                const int n0 = tn * BN;
+                const bool more = tile + dp_grid < dp_tiles;
+                if (more) tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
+                deq_segment<ABL, LAYOUT>(cur, wave, ln, rowmeta, N, n0, true, (u64t*)ws, [&] {
+                    if (more) {
+                        deq_setup<LAYOUT>(nxt, smem, wave, ln, qweight, N, K, tn * BN, 0, NT);
+                        deq_prologue_issue<LAYOUT>(nxt, rowmeta, N, tn * BN);
+                    }
+                });
+                cur = nxt;
+            }
+        }
+        return;
+    }
+
+    // ---- stream-K unit u of XCD e: K-steps [b0, b1) of that XCD's tail tiles laid end to end
+    const int su = bid - dp_grid;
+    sk.e = su & 7;
+    sk.u = su >> 3;
+    const int base = dp_tiles + sk.e;
+    sk.S = ((tail + 7 - sk.e) >> 3) * NT;   // tail tile t belongs to XCD t & 7: the first tail % 8 XCDs hold one more
+    const int b0 = sk_bound(sk.u, sk.S, units), b1 = sk_bound(sk.u + 1, sk.S, units);
     // every wave walks the same segment list, so the barrier counts of the two roles stay matched
     if (wave < N_MMA) {
-        if constexpr (!(ABL & (EXP_NO_PRIO | EXP_DEQ_PRIO)))
-            __builtin_amdgcn_s_setprio(3);   // MFMA waves win issue arbitration against the dequant wave of their SIMD
         int pj0 = -1, pn0 = 0, pj1 = -1, pn1 = 0;
         for (int pos = b0; pos < b1;) {
             sk.j = pos / NT;
@@ -575,10 +697,11 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             sk.first = pos == b0;
             int tm, tn;
             tile_of_block(base + sk.j * 8, tiles_m, tiles_n, tm, tn);
-            int ln;   // lane id recomputed per segment and made opaque: nothing lane-derived is hoisted across the loop
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-            mma_segment<ABL>(smem, wave, ln, end - pos, x, y, M, N, K, tm * BM, tn * BN, pos - sk.j * NT, NT, sk,
-                             bid < dp_blocks);
+            int ln;
+            MXQ_LANE_ID(ln);
+            XDma xd;
+            xdma_setup(xd, x, M, K, tm * BM, pos - sk.j * NT, wave, ln);
+            mma_segment<ABL>(smem, wave, ln, end - pos, xd, false, y, M, N, tm * BM, tn * BN, NT, sk, nothing);
             if (end - pos != NT) {
                 if (sk.first) { pj0 = sk.j; pn0 = end - pos; }
                 else { pj1 = sk.j; pn1 = end - pos; }
@@ -587,7 +710,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
         }
         if (pj0 >= 0 || pj1 >= 0) {
             int ln;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+            MXQ_LANE_ID(ln);
             // every slot store of this wave has reached the coherence point before any count moves
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -611,16 +734,16 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             }
         }
     } else {
-        if constexpr ((ABL & EXP_DEQ_PRIO) != 0) __builtin_amdgcn_s_setprio(3);   // experiment: the dequant chain first
         for (int pos = b0; pos < b1;) {
             const int j = pos / NT;
             const int end = b1 < (j + 1) * NT ? b1 : (j + 1) * NT;
             int tm, tn;
             tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
             int ln;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-            deq_segment<ABL, LAYOUT>(smem, wave, ln, qweight, rowmeta, N, K, tn * BN, pos - j * NT, end - pos,
-                                     (u64t*)ws);
+            MXQ_LANE_ID(ln);
+            Deq c;
+            deq_setup<LAYOUT>(c, smem, wave, ln, qweight, N, K, tn * BN, pos - j * NT, end - pos);
+            deq_segment<ABL, LAYOUT>(c, wave, ln, rowmeta, N, tn * BN, false, (u64t*)ws, nothing);
             pos = end;
         }
     }
@@ -653,24 +776,30 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
     const int NT = K / BK;
     const int cus = cu_count() / 8 * 8, units = cus / 8;
-    int dp_blocks = tiles, tail = 0;
+    int dp_tiles = tiles, tail = 0;
     if (workspace && tiles % cus != 0 && units * 8 * N_MMA * sizeof(int) <= CNT_BYTES &&
         ws_bytes >= CNT_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
         const int t8 = (tiles % cus) / 8;   // tail tiles per XCD (the first tail % 8 XCDs hold one more)
-        const bool pays = (int64_t)(cus - tiles % cus) * NT >= (int64_t)24 * cus;   // see gemm6.hip
+        // Splitting the tail costs ~20 us (every unit parks 128 KB of fp32 partials, the finishers read them back)
+        // and saves the idle share of one tile time, (1 - tail/CUs) * NT K-steps of ~1 us: worth it from ~24 idle
+        // K-steps per CU (M = 512: 60 -> 37 us at 4096^2; NOT Llama's gate/up at M = 2048, tail 176 / 256, NT = 64)
+        const bool pays = (int64_t)(cus - tiles % cus) * NT >= (int64_t)24 * cus;
         if ((force || pays) && (int64_t)t8 * NT >= (int64_t)units * 4) {
             tail = tiles % cus;
-            dp_blocks = tiles - tail;
+            dp_tiles = tiles - tail;
         }
     }
-    const int grid = dp_blocks + (tail ? cus : 0);
+    const int dp_grid = dp_tiles < cus ? dp_tiles : cus;   // persistent: at most one data-parallel workgroup per CU
+    const int grid = dp_grid + (tail ? cus : 0);
     mxq_gemm8_f16_kernel<ABL, LAYOUT><<<grid, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
-        dp_blocks, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace);
+        dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace);
     return (int)hipGetLastError();
 }
 
 }   // namespace
+
+size_t mxq_gemm8_workspace_bytes() { return CNT_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
 
 int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          void* workspace, size_t ws_bytes, int force, hipStream_t stream) {
@@ -721,7 +850,7 @@ static int launch8_stamps(const void* x, const void* qweight, const void* rowmet
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     mxq_gemm8_f16_kernel<ABL, MXQ_LAYOUT_MIXED><<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
-        tiles_m * tiles_n, 0, 32, (float*)dbg, nullptr);
+        tiles_m * tiles_n, tiles_m * tiles_n, 0, 32, (float*)dbg, nullptr);
     return (int)hipGetLastError();
 }
 extern "C" int mxq_prof_gemm8_stamps_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,

@@ -34,11 +34,14 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int XPITCH = 144;   // bytes per chunk of the LDS activation copy: 128 + 16 keeps the 16 chunk lanes off each other's banks
 
+// (hipcc, ROCm 7.2: __builtin_bit_cast applied directly to an element of an ext_vector_type value reads element 0;
+// the elements are copied to scalars first)
 __device__ __forceinline__ float dot8(const uint32_t* w, const u32x4 xa, float acc) {
-    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[0]), __builtin_bit_cast(half2v, xa[0]), acc, false);
-    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[1]), __builtin_bit_cast(half2v, xa[1]), acc, false);
-    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[2]), __builtin_bit_cast(half2v, xa[2]), acc, false);
-    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[3]), __builtin_bit_cast(half2v, xa[3]), acc, false);
+    const uint32_t x0 = xa[0], x1 = xa[1], x2 = xa[2], x3 = xa[3];
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[0]), __builtin_bit_cast(half2v, x0), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[1]), __builtin_bit_cast(half2v, x1), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[2]), __builtin_bit_cast(half2v, x2), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[3]), __builtin_bit_cast(half2v, x3), acc, false);
     return acc;
 }
 
@@ -179,17 +182,20 @@ __global__ __launch_bounds__(TEAMS * 256) void mxq_gemv2_f16_kernel(const uint16
             if (four) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    mxq_deq4x8(cur.a[j], s4[j], z4[j], o);
-                    mxq_deq4x8(cur.b[j], s4[j], z4[j], o + 4);
+                    const uint32_t ca = cur.a[j], cb = cur.b[j];
+                    mxq_deq4x8(ca, s4[j], z4[j], o);
+                    mxq_deq4x8(cb, s4[j], z4[j], o + 4);
 #pragma unroll
                     for (int m = 0; m < MB; ++m) acc[m][j] = dot8(o + 4, xb[m], dot8(o, xa[m], acc[m][j]));
                 }
             } else {
-                const float qs = __uint_as_float(cur.qq[0]), qz = __uint_as_float(cur.qq[1]);
+                const uint32_t qs_u = cur.qq[0], qz_u = cur.qq[1];
+                const float qs = __uint_as_float(qs_u), qz = __uint_as_float(qz_u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t scw = (cur.sc[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                    mxq_deq2x16(cur.a[j], mxq_scale(qs, qz, (scw >> (4 * role)) & 15u), __uint_as_float(cur.b[j]), o);
+                    const uint32_t cw = cur.a[j], zw = cur.b[j];
+                    mxq_deq2x16(cw, mxq_scale(qs, qz, (scw >> (4 * role)) & 15u), __uint_as_float(zw), o);
 #pragma unroll
                     for (int m = 0; m < MB; ++m) acc[m][j] = dot8(o + 4, xb[m], dot8(o, xa[m], acc[m][j]));
                 }
@@ -248,7 +254,9 @@ int launch_n(const void* x, const void* qweight, const void* rowmeta, void* y, i
              float eps, const void* residual, hipStream_t stream, int teams) {
     if (teams == 0) teams = N / 16 <= 384 ? 4 : 2;
     if (MB == 8 && teams == 4) teams = 2;   // 8 tokens x 4 rows of accumulators do not fit 128 VGPRs (16 waves per CU)
-    if (teams == 4) return launch_t<MB, 4, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream);
+    if constexpr (MB < 8) {
+        if (teams == 4) return launch_t<MB, 4, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream);
+    }
     if (teams == 2) return launch_t<MB, 2, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream);
     if (teams == 1) return launch_t<MB, 1, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream);
     return -1;

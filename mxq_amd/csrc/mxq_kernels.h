@@ -23,13 +23,10 @@ int mxq_launch_gemm_f16(const void* x, const void* qweight, const void* rowmeta,
                         hipStream_t stream);
 int mxq_launch_gemm1_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          hipStream_t stream);   // 128x128 tile, two LDS stages (gemm.hip)
-size_t mxq_gemm6_workspace_bytes();
-int mxq_launch_gemm6_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         void* workspace, size_t ws_bytes, int force,
-                         hipStream_t stream);   // gemm5 + stream-K tail (gemm6.hip); force: split even when it does not pay
+size_t mxq_gemm8_workspace_bytes();
 int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          void* workspace, size_t ws_bytes, int force,
-                         hipStream_t stream);   // MFMA waves stream x, dedicated waves dequantise (gemm8.hip); same workspace as gemm6
+                         hipStream_t stream);   // 256x128 tile: MFMA waves stream x, dedicated waves dequantise; stream-K tail with a workspace (gemm8.hip); force: split even when it does not pay
 int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -42,8 +39,6 @@ int mxq_launch_gemv2_fused_f16(const void* x, const void* qweight, const void* r
                                hipStream_t stream);
 int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
                                int K, int layout, hipStream_t stream);
-int mxq_launch_gemm4_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
-                                int K, int layout, hipStream_t stream);
 int mxq_launch_quantize_uniform(const void* W, int dtype, void* qweight, void* rowmeta, int N, int K, int layout,
                                 hipStream_t stream);
 int mxq_launch_uniform_expand(const void* qweight, const void* rowmeta, void* w16, uint8_t* codes, uint8_t* sc,

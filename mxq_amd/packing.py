@@ -176,15 +176,15 @@ def dequant(p: PackedMXQ) -> torch.Tensor:
     return out
 
 
-GEMM_PATHS = {"gemm": 0, "gemm1": 1, "gemm6": 6, "gemm7": 7, "gemm8": 8, "gemm9": 9}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
+GEMM_PATHS = {"gemm": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
 
 
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
     """y = x @ dequant(p).T for x [..., K] fp16 -> [..., N] fp16 (fp32 accumulation).
 
     path: "auto" (GEMV kernel for <= 4 tokens, MFMA GEMM otherwise), "gemm", "gemv", or an explicit GEMM
-    kernel: "gemm1" (128x128 tile), "gemm6" (wave-specialised + stream-K tail), "gemm7" (gemm6 splitting its
-    tail whenever that is structurally possible: tests)."""
+    kernel: "gemm1" (128x128 tile), "gemm8" (256x128 tile, wave-specialised, persistent, stream-K tail), "gemm9"
+    (gemm8 splitting its tail whenever that is structurally possible: tests)."""
     _need_gpu(x, p.qweight)
     if x.dtype != torch.float16:
         raise ValueError(f"activations must be float16 (W2/4 x A16), got {x.dtype}")
@@ -208,7 +208,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         elif path == "auto" and M <= 4:                          # GEMV: no workspace involved
             rc = lib.mxq_linear_f16(*args, _stream(x2))
         else:
-            ws = gemm_workspace(x2.device) if path in ("auto", "gemm", "gemm6", "gemm7", "gemm8", "gemm9") else None
+            ws = gemm_workspace(x2.device) if path in ("auto", "gemm", "gemm8", "gemm9") else None
             wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
             if path == "auto":
                 rc = lib.mxq_linear_f16_ws(*args, wsp, wsn, _stream(x2))

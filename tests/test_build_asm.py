@@ -15,11 +15,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 
 
-def _asm(src):
+def _asm(src, *extra):
     out = os.path.join(ROOT, "tests", "_build", src.replace(".hip", ".s"))
     os.makedirs(os.path.dirname(out), exist_ok=True)
     subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-                           "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S",
+                           *extra, "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S",
                            os.path.join(CSRC, src), "-o", out], stderr=subprocess.DEVNULL)
     return open(out).read()
 
@@ -32,43 +32,66 @@ def _kernel_body(s, pattern):
 
 
 def _innermost_loop(lines, at):
-    """Smallest [label .. backward branch to that label] range containing line `at`."""
-    labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
-    last = {}                       # label -> last backward branch to it (a loop may have several latches)
+    """All instructions of the innermost loop around line `at`, from the compiler's own loop annotations on the
+    basic-block labels ('This Inner Loop Header' / 'in Loop: Header=BBx_y Depth=d'); rotated loops and loops with
+    several latches come out whole."""
+    blocks = []                      # (first line, header id or None, depth)
     for i, l in enumerate(lines):
-        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
-        if m and m.group(1) in labels and labels[m.group(1)] <= i:
-            last[m.group(1)] = i
-    best = None
-    for lab, end in last.items():
-        if labels[lab] <= at <= end and (best is None or end - labels[lab] < best[1] - best[0]):
-            best = (labels[lab], end)
-    assert best, "no enclosing loop"
-    return lines[best[0]:best[1] + 1]
+        m = re.match(r"^(?:\.L(BB\d+_\d+):|; %bb\.\d+:)(.*)$", l)
+        if not m:
+            continue
+        own, rest = m.group(1), m.group(2)
+        if i + 1 < len(lines) and re.match(r"^\s*;\s*(=>|Parent Loop|in Loop|Child Loop)", lines[i + 1]):
+            rest += " " + lines[i + 1]            # the annotation may continue on the next line(s)
+            if i + 2 < len(lines) and re.match(r"^\s*;\s*(=>|Parent Loop|in Loop|Child Loop)", lines[i + 2]):
+                rest += " " + lines[i + 2]
+        hdr = depth = None
+        mh = re.search(r"This Inner Loop Header: Depth=(\d+)", rest)
+        if mh and own:
+            hdr, depth = own, int(mh.group(1))
+        else:
+            mi = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", rest)
+            if mi:
+                hdr, depth = mi.group(1), int(mi.group(2))
+        blocks.append((i, hdr, depth))
+    assert blocks, "no basic blocks found"
+    bounds = [b[0] for b in blocks] + [len(lines)]
+    mine = max(k for k, b in enumerate(blocks) if b[0] <= at)
+    hdr = blocks[mine][1]
+    assert hdr, "line is not inside a loop"
+    body = []
+    for k, (start, h, _d) in enumerate(blocks):
+        if h == hdr:
+            body += lines[start:bounds[k + 1]]
+    return body
 
 
-def test_gemm6_main_loops_keep_dma_in_flight():
-    """Product kernel = the <ABL 0, mixed layout> instantiation.  Its DMA waves' steady-state K-step ends in the
-    hand-placed counted wait (this step's 10 LDS-DMAs stay in flight across the barrier) and contains no
-    compiler-inserted drain; its MFMA waves' K-step (32 MFMAs, 16 fragment reads) waits on no vmcnt at all."""
-    lines = _kernel_body(_asm("gemm6.hip"), "mxq_gemm6_f16_kernelILi0ELi0E")
-    waits = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(10) lgkmcnt(0)" in l]
-    assert waits, "expected the counted steady-state wait of the DMA waves"
+def test_gemm8_main_loops_keep_dma_in_flight():
+    """Product kernel = the <ABL 0, mixed layout> instantiation.  The dequant waves' steady-state K-step ends in the
+    hand-placed counted wait (this step's 2 LDS-DMAs stay in flight across the barrier) and contains no
+    compiler-inserted drain; the MFMA waves' K-step (32 MFMAs, 16 fragment reads, 4 x DMAs) ends in its own
+    counted wait, carries (almost) no VALU work and is never drained either."""
+    lines = _kernel_body(_asm("gemm8.hip", "-fno-slp-vectorize"), "mxq_gemm8_f16_kernelILi0ELi0E")
+    waits = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(2) lgkmcnt(0)" in l]
+    assert waits, "expected the counted steady-state wait of the dequant waves"
     for at in waits:
         loop = _innermost_loop(lines, at)
-        assert not [l for l in loop if re.search(r"s_waitcnt.*vmcnt\(0\)", l)], "drain inside the DMA K-step"
-        assert sum("global_load_lds_dwordx4" in l for l in loop) == 10
+        assert not [l for l in loop if re.search(r"s_waitcnt.*vmcnt\(0\)", l)], "drain inside the dequant K-step"
+        assert sum(bool(re.search(r"buffer_load_dwordx4.* lds", l)) for l in loop) == 2
         assert sum(bool(re.search(r"\bs_barrier\b", l)) for l in loop) == 1
-    first_mfma = [i for i, l in enumerate(lines) if "v_mfma_f32_16x16x32_f16" in l]
-    loops = {id(lp): lp for lp in (_innermost_loop(lines, i) for i in first_mfma[16:48])}   # past the peeled first step
-    steady = [lp for lp in loops.values() if sum("v_mfma_f32_16x16x32_f16" in l for l in lp) == 32]
+        assert not [l for l in loop if "v_pk_mul_f32" in l or "v_pk_add_f32" in l], "SLP-packed fp32 ops in the dequant"
+    waits = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(4) lgkmcnt(0)" in l]
+    steady = [lp for lp in (_innermost_loop(lines, at) for at in waits)
+              if sum("v_mfma_f32_16x16x32_f16" in l for l in lp) == 32]
     assert steady, "expected the 32-MFMA steady-state K-step of the MFMA waves"
     for lp in steady:
-        assert not [l for l in lp if "vmcnt" in l], "the MFMA waves' K-step must not wait on VMEM"
+        assert not [l for l in lp if re.search(r"s_waitcnt.*vmcnt\(0\)", l)], "drain inside the MFMA K-step"
         assert sum("ds_read_b128" in l for l in lp) == 16
+        assert sum(bool(re.search(r"buffer_load_dwordx4.* lds", l)) for l in lp) == 4
+        assert sum(bool(re.match(r"\s+v_(?!mfma)", l)) for l in lp) <= 12, "VALU work crept into the MFMA waves' loop"
 
 
-@pytest.mark.parametrize("src", ["gemm.hip", "gemm4.hip", "gemm6.hip", "gemv.hip", "fakequant.hip", "actquant.hip", "pack.hip"])
+@pytest.mark.parametrize("src", ["gemm.hip", "gemm8.hip", "gemv.hip", "gemv2.hip", "fakequant.hip", "actquant.hip", "pack.hip"])
 def test_no_spills_no_scratch(src):
     s = _asm(src)
     for m in re.finditer(r"\.vgpr_spill_count:\s+(\d+)", s):

@@ -157,7 +157,7 @@ def test_mxqgpt_driver_api(dev, g1):
 # ----------------------------------------------------------------------------------------
 # dequant-GEMM / GEMV
 # ----------------------------------------------------------------------------------------
-GEMM_KERNELS = ["gemm", "gemm1", "gemm6", "gemm7", "gemm8", "gemm9"]      # packing.GEMM_PATHS: every kernel the product library ships
+GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9"]      # packing.GEMM_PATHS: every kernel the product library ships
 
 
 def _packed_case(dev, N, K, seed):
@@ -210,9 +210,8 @@ def test_gemm_integer_exact_layout(dev):
                                    (1024, 4224, 2048),    # 132 tiles: XCDs 0-3 hold 17 tail tiles, 4-7 hold 16
                                    (100, 1152, 8192),     # 9 tiles: XCD 0 holds two, the others one; half-empty 256-row tile
                                    (2048, 5120, 1024)])   # 320 tiles = one full round + a 64-tile tail
-@pytest.mark.parametrize("sk", ["gemm7", "gemm9"])
-def test_gemm_stream_k_tail(dev, M, N, K, sk):
-    """csrc/gemm6.hip: tiles beyond the last full round of CUs are split along K over all CUs and
+def test_gemm_stream_k_tail(dev, M, N, K, sk="gemm9"):
+    """csrc/gemm8.hip: tiles beyond the last full round of CUs are split along K over all CUs and
     reduced through the workspace.  Checks (1) against the oracle matmul, (2) that the workspace
     counters are left zeroed, (3) run-to-run bit-determinism, (4) agreement with the 128x128-tile
     kernel (no split) to summation-order rounding."""
@@ -231,12 +230,10 @@ def test_gemm_stream_k_tail(dev, M, N, K, sk):
     # the default dispatch is the same kernel, splitting only where it pays: equal up to summation order
     yd = packing.linear(xd, p, path="gemm")
     assert ((y.float() - yd.float()).abs().max() / y5.float().abs().max()).item() <= 1e-3
-    if sk == "gemm7":
-        assert torch.equal(packing.linear(xd, p, path="gemm6"), yd)
+    assert torch.equal(packing.linear(xd, p, path="gemm8"), yd)
 
 
-@pytest.mark.parametrize("sk", ["gemm7", "gemm9"])
-def test_stream_k_partition_fuzz(dev, sk):
+def test_stream_k_partition_fuzz(dev, sk="gemm9"):
     """Random (tokens, out, in) shapes through the forced stream-K schedule against the single-tile kernel:
     exercises unit ranges that start / end anywhere inside tiles, XCDs with unequal tail lengths, units with
     one, two and many segments, ragged M and N edges."""
@@ -265,11 +262,11 @@ def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):
     from mxq_amd import packing
     p, w16, g = _packed_case(dev, 2048, 4096, 5)
     x = torch.randn(512, 4096, generator=g).half().to(dev)
-    ref = packing.linear(x, p, path="gemm7")                      # warm-up: allocates this stream's workspace
+    ref = packing.linear(x, p, path="gemm9")                      # warm-up: allocates this stream's workspace
     out = torch.empty_like(ref)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        packing.linear(x, p, out=out, path="gemm7")
+        packing.linear(x, p, out=out, path="gemm9")
     for _ in range(3):
         out.zero_()
         graph.replay()
@@ -280,7 +277,7 @@ def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):
     for s in (s1, s2):
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            outs.append([packing.linear(x, p, path="gemm7") for _ in range(8)])
+            outs.append([packing.linear(x, p, path="gemm9") for _ in range(8)])
     torch.cuda.synchronize()
     assert all(torch.equal(o, ref) for lst in outs for o in lst)
     keys = {k for k in packing._WORKSPACES if k[0] == x.device.index}
@@ -295,7 +292,7 @@ def test_linear_empty_and_nonfinite_inputs(dev):
     p, w16, g = _packed_case(dev, 256, 4096, 11)
     assert packing.linear(torch.empty(0, 4096, dtype=torch.float16, device=dev), p).shape == (0, 256)
     assert packing.linear(torch.empty(2, 0, 4096, dtype=torch.float16, device=dev), p).shape == (2, 0, 256)
-    for M, path in ((3, "gemv"), (100, "gemm1"), (300, "gemm7"), (300, "gemm9"), (700, "gemm8")):
+    for M, path in ((3, "gemv"), (100, "gemm1"), (300, "gemm9"), (700, "gemm8")):
         x = torch.randn(M, 4096, generator=g).half()
         clean = packing.linear(x.to(dev), p, path=path)
         x[1, 7] = float("nan")

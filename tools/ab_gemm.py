@@ -4,7 +4,7 @@
 GPU-side time per launch under hipGraph replay (20 launches per graph, no host launch overhead in the number),
 variants interleaved over several rounds (cdna guide rule 24), random data (rule 25).
 
-    python tools/ab_gemm.py --variants gemm6,gemm8,abl8:4,torch [--m 2048] [--shapes 4096x4096,...]
+    python tools/ab_gemm.py --variants gemm1,gemm8,abl8:4,torch [--m 2048] [--shapes 4096x4096,...]
 
 variant names: gemmN = product kernel through mxq_gemm_f16_ws (checked against the fp32 matmul on the bit-exact
 dequantised weight); ablK:B = libmxq_hip_prof.so's mxq_prof_gemmK_ablate_f16 with ablation bits B (WRONG results by
@@ -54,7 +54,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=2048)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--variants", default="gemm6,gemm8,torch")
+    ap.add_argument("--variants", default="gemm8,torch")
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008", help="NxK list")
     ap.add_argument("--json", default=None)
     args = ap.parse_args()

@@ -18,7 +18,7 @@ case "$1" in
     a=$2; b=$3; rounds=${4:-3}
     shift 4 || true
     [ "$1" = "--" ] && shift
-    args=${@:---variants gemm6,gemm6}
+    args=${@:---variants gemm8,gemm8}
     cp mxq_amd/libmxq_hip.so abtmp/lib__restore.so
     for r in $(seq $rounds); do
       for v in $a $b; do

@@ -2,7 +2,7 @@
 """A/B timing of the GEMM kernel variants on the Llama-2-7B Linear shapes (GPU box).
 Interleaved rounds in ONE process (cdna guide rule 24); random data (rule 25).
 
-    python tools/gemm_bench.py [--m 2048] [--rounds 5] [--variants gemm1,gemm6]
+    python tools/gemm_bench.py [--m 2048] [--rounds 5] [--variants gemm1,gemm8]
 """
 import argparse
 import os
@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--m", type=int, default=2048)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--variants", default="gemm1,gemm6")
+    ap.add_argument("--variants", default="gemm1,gemm8")
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008", help="NxK list")
     args = ap.parse_args()
     dev = torch.device("cuda:0")

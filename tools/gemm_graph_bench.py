@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU-side time per launch of GEMM kernel variants / profiling builds, measured by replaying a hipGraph of
 20 launches (no host launch overhead in the number).
-    python tools/gemm_graph_bench.py --variants gemm1,gemm6 [--m 2048] [--shapes 4096x4096,...]"""
+    python tools/gemm_graph_bench.py --variants gemm1,gemm8 [--m 2048] [--shapes 4096x4096,...]"""
 import argparse
 import os
 import sys
@@ -15,7 +15,7 @@ from mxq_amd import packing  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=2048)
-    ap.add_argument("--variants", default="gemm1,gemm6")
+    ap.add_argument("--variants", default="gemm1,gemm8")
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008", help="NxK list")
     args = ap.parse_args()
     dev = torch.device("cuda:0")

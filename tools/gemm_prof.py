@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE GEMM kernel variant at ONE shape a few times (for rocprofv3 --pmc runs).
-    python3 tools/gemm_prof.py gemm6 2048 4096 4096 [iters]"""
+    python3 tools/gemm_prof.py gemm8 2048 4096 4096 [iters]"""
 import os
 import sys
 
