@@ -143,13 +143,14 @@ def main():
                 x = x_i if p.K == LS.INTERMEDIATE else x_hidden
                 packing.linear(x, p, out=(y_f[p.N] if p.N in y_f else y_i if p.N == LS.INTERMEDIATE else y_h), path="gemm")
 
-    # N > 1: the schedule is mxq_amd.pipeline.LayerPipeline's (the same object the gloo tests drive on CPU):
-    # per micro-batch recv from rank-1 -> this rank's layers -> send to rank+1
+    # N > 1: the schedule is mxq_amd.pipeline.LayerPipeline's (the same object the gloo tests drive on CPU): irecv of
+    # micro-batch b+1 posted before b is computed, isend of b's output from a ring slot under b+1's compute
     pipe = LayerPipeline(rank, world) if world > 1 else None
 
     def stage_fn(h):
         stage(h)
-        return h          # the hidden state that hops on (synthetic run: its values do not matter, its size does)
+        return y_h        # the stage's OUTPUT hops on (written last by the final layer's down_proj): the next stage's
+                          # GEMMs depend on this stage's GEMMs and on the transfer, as in a real layer pipeline
 
     def step():
         if pipe is None:

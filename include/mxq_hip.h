@@ -144,7 +144,10 @@ int mxq_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, 
 /* Decode-harness glue (BASELINE config 3), not part of the reference's hot path: rotary embedding
  * of q/k, KV-cache append at *pos and single-query attention for one token; one workgroup per
  * head, head_dim 128.  qkv fp16 [3*heads*128]; caches fp16 [heads][max_ctx][128]; pos int64[1]
- * (device); cos/sin f32 [max_ctx][64]; out fp16 [heads*128]. */
+ * (device); cos/sin f32 [max_ctx][64]; out fp16 [heads*128].
+ * Precondition: 0 <= *pos < max_ctx at the time the kernel runs (the caller tracks the position it increments
+ * on the device, e.g. mxq_amd/llama_decode.py's ContextWindow).  A position outside the cache is not written
+ * anywhere: that launch leaves the caches untouched and fills `out` with NaN. */
 int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                         const void* sin_t, void* out, int heads, int head_dim, int max_ctx, void* stream);
 

@@ -34,8 +34,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
     float* red = sc + max_ctx;
     float* o2 = red + 8;
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pos = (int)*pos_p;
+    const int64_t pos64 = *pos_p;
     const int hidden = heads * HD;
+    // Precondition (include/mxq_hip.h): 0 <= *pos < max_ctx.  The position lives in device memory (graph replay),
+    // so the launcher cannot check it: a position outside the cache must neither be written to the cache nor index
+    // the LDS score array.  The head's output is poisoned (NaN) instead, which the caller cannot miss downstream.
+    if (pos64 < 0 || pos64 >= max_ctx) {   // uniform over the workgroup: taken before any barrier
+        if (tid < HD) out[blockIdx.x * HD + tid] = 0x7E00;
+        return;
+    }
+    const int pos = (int)pos64;
     uint16_t* kc = k_cache + (int64_t)h * max_ctx * HD;
     uint16_t* vc = v_cache + (int64_t)h * max_ctx * HD;
 

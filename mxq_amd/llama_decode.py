@@ -25,6 +25,32 @@ from . import packing
 _concat_packed = packing.concat_packed
 
 
+class ContextWindow:
+    """Host-side mirror of the device-resident decode position.  The position tensor is advanced on the device
+    (graph replay), where nothing can raise; every host entry point that advances it goes through ``take`` first,
+    so a decode past the KV cache fails here instead of overrunning the cache (csrc/decode_ops.hip poisons its
+    output for such a position, but never writes outside the cache)."""
+
+    def __init__(self, max_ctx: int):
+        if max_ctx <= 0:
+            raise ValueError("max_ctx must be positive")
+        self.max_ctx, self.pos = int(max_ctx), 0
+
+    def take(self, n: int = 1) -> int:
+        """Reserve the next ``n`` positions; returns the first.  Raises if they do not fit the cache."""
+        if n < 0:
+            raise ValueError("cannot take a negative number of positions")
+        if self.pos + n > self.max_ctx:
+            raise RuntimeError(f"decode position {self.pos} + {n} exceeds the KV cache (max_ctx = {self.max_ctx}); "
+                               "reset() or build the stage with a larger max_ctx")
+        first = self.pos
+        self.pos += n
+        return first
+
+    def reset(self):
+        self.pos = 0
+
+
 class DecodeStage:
     def __init__(self, layers, dev, max_ctx: int = 512, hidden: int = LS.HIDDEN, inter: int = LS.INTERMEDIATE,
                  heads: int = 32, first: bool = True, last: bool = True, vocab: int = 32000, fused: bool = True):
@@ -53,6 +79,7 @@ class DecodeStage:
         ang = torch.arange(max_ctx, device=dev).float()[:, None] * inv[None, :]
         self.cos, self.sin = ang.cos(), ang.sin()                     # [max_ctx, hd/2]
         self.pos = torch.zeros(1, dtype=torch.int64, device=dev)      # device-resident position
+        self.window = ContextWindow(max_ctx)                          # its host-side mirror (bounds check)
         self.ctx_ids = torch.arange(max_ctx, device=dev)
         g = torch.Generator(device=dev).manual_seed(99)
         if first:
@@ -94,6 +121,8 @@ class DecodeStage:
 
     def step(self, h):
         """One token through this stage's layers.  h [1, hidden] fp16."""
+        if self.window.pos >= self.max_ctx:
+            raise RuntimeError(f"decode position {self.window.pos} is outside the KV cache (max_ctx = {self.max_ctx})")
         if self.fused:
             for i, (qkv, o, gu, down) in enumerate(self.w):
                 y = packing.linear_fused(h, qkv, 1, self.norm_w)                  # RMSNorm -> q|k|v
@@ -123,6 +152,7 @@ class DecodeStage:
         return h
 
     def advance(self):
+        self.window.take(1)
         self.pos += 1
 
     # -- hipGraph capture of one stage step --------------------------------------------------------
@@ -136,9 +166,11 @@ class DecodeStage:
             self._h_out.copy_(self.step(self._h_in))
             self.pos += 1
         self.pos.zero_()
+        self.window.reset()
         return self
 
     def step_graph(self, h):
+        self.window.take(1)                    # the replay advances the device position by one
         self._h_in.copy_(h)
         self._graph.replay()
         return self._h_out
@@ -161,10 +193,12 @@ class DecodeStage:
             one()
             self.pos += 1
         self.pos.zero_()
+        self.window.reset()
         return self
 
     def decode_tokens(self, token_buf: torch.Tensor, first_token: int, n_tokens: int):
         """Greedy decode with the graph of ``capture_token_loop``; returns the generated ids."""
+        self.window.take(n_tokens)             # every replay advances the device position by one
         token_buf.fill_(int(first_token))
         out = torch.zeros(n_tokens, dtype=token_buf.dtype, device=token_buf.device)
         for i in range(n_tokens):
@@ -173,6 +207,7 @@ class DecodeStage:
         return out.tolist()
 
     def reset(self):
+        self.window.reset()
         self.pos.zero_()
         self.k_cache.zero_()
         self.v_cache.zero_()

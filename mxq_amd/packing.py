@@ -30,22 +30,41 @@ def _stream(t: torch.Tensor) -> int:
 
 
 _WORKSPACES: Dict[tuple, torch.Tensor] = {}
+_WS_HEAD = 65536      # bytes of K-step counters at the head of a workspace (include/mxq_hip.h)
 
 
 def gemm_workspace(device: torch.device) -> torch.Tensor:
     """Scratch buffer of the stream-K prefill GEMM (include/mxq_hip.h: mxq_linear_f16_ws), one per
     (device, stream): launches on one stream run in order and may share it, launches on different
-    streams may not.  Its counter head is zeroed once here; the kernels leave it zeroed."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+    streams may not.  Its counter head must be zero when a launch starts; the kernels leave it zeroed.
+
+    Eager use: the head is zeroed once, when the buffer is created.  Under hipGraph capture the buffer handed out
+    (new or cached -- torch's capture stream keeps its handle across captures) gets a captured memset in front of
+    EVERY captured launch: a buffer first created under capture has never been zeroed for real until a replay
+    runs, and an earlier capture's memset belongs to a graph that may never be replayed.  Graphs captured on the
+    same capture stream share this buffer: replay them one at a time (or capture on distinct streams)."""
+    stream = torch.cuda.current_stream(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream)
     ws = _WORKSPACES.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if ws is None:
         nbytes = _lib.load().mxq_gemm_workspace_bytes()
-        # (under graph capture the stream is the capture's own: the buffer comes from the graph's private pool
-        # and the 64 KiB counter head is zeroed by a captured memset, i.e. again on every replay)
         ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        ws[:65536].zero_()
+        ws[:_WS_HEAD].zero_()
+    elif capturing:
+        ws[:_WS_HEAD].zero_()
     return ws
+
+
+def reset_gemm_workspace(device: Optional[torch.device] = None):
+    """Re-zero the counter heads of the cached stream-K workspaces (all devices, or one).  Needed only after a
+    GEMM launch was aborted mid-kernel (device reset, killed process sharing the buffer): the kernels themselves
+    always leave the counters zeroed.  Synchronises the device(s) involved."""
+    for (dev_index, _stream), ws in list(_WORKSPACES.items()):
+        if device is None or (device.index if device.index is not None else torch.cuda.current_device()) == dev_index:
+            torch.cuda.synchronize(dev_index)
+            ws[:_WS_HEAD].zero_()
+            torch.cuda.synchronize(dev_index)
 
 
 def _need_gpu(*ts: torch.Tensor):

@@ -5,10 +5,22 @@ The reference's only multi-GPU inference mode is accelerate's ``device_map="auto
 and the hidden state hops GPU -> GPU with ``.to(dev)`` inside ONE process.  The native
 counterpart: one process per GPU, rank ``r`` of ``G`` owns layers ``[L*r/G, L*(r+1)/G)``, and the
 only exchange is the ``[tokens, hidden]`` fp16 activation moving to the next stage with
-``torch.distributed`` point-to-point ``send``/``recv`` (backend "nccl" = RCCL over xGMI on ROCm;
+``torch.distributed`` point-to-point ``isend``/``irecv`` (backend "nccl" = RCCL over xGMI on ROCm;
 "gloo" in the CPU tests) plus, for greedy decode, the 8-byte next-token id going from the last
-stage back to the first.  No all-reduce / all-gather is needed, so the per-link ring bound of
-xGMI never enters.
+stage back to the first.  No all-reduce / all-gather / broadcast is needed, so the per-link ring bound
+of xGMI never enters.
+
+Schedule of ``run_microbatches`` (stage r, micro-batch b):
+
+    post irecv(b+1) into recv ring slot (b+1) % 2      <- before b is computed: the hop of b+1 flies under b
+    wait  irecv(b)
+    h = stage_fn(recv slot b % 2)
+    wait  isend(b-2) (frees send ring slot b % 2); copy h into it; isend(b)   <- flies under b+1's compute
+
+RCCL runs point-to-point transfers on its own stream, ordered against the compute stream by events at
+post / wait time, so "flies under" is real overlap on the GPU; the blocking ``send`` / ``recv`` of round 1
+made the compute stream wait for every hop.  The copy into the send ring (16.8 MB at 2048 tokens, ~4 us)
+decouples the transfer from whatever buffer the stage reuses for its next output.
 
 Nothing here touches the HIP library: the stage computation is a callable, so the schedule is
 unit-tested on CPU with gloo (tests/test_pipeline_gloo.py) and used unchanged with RCCL.
@@ -27,7 +39,10 @@ def layer_range(rank: int, world: int, n_layers: int) -> range:
 
 
 class LayerPipeline:
-    """Point-to-point activation pipeline between consecutive ranks of ``group``."""
+    """Point-to-point activation pipeline between consecutive ranks of ``group``.
+
+    ``rank`` / ``world`` are GROUP-relative; ``torch.distributed``'s ``src`` / ``dst`` are global ranks, so peers
+    are translated with ``dist.get_global_rank`` (a sub-group of a larger job addresses its own members)."""
 
     def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None):
         self.group = group
@@ -37,6 +52,12 @@ class LayerPipeline:
             rank = dist.get_rank(group) if world > 1 else 0
         self.rank, self.world = rank, world
 
+    def _peer(self, group_rank: int) -> int:
+        """Global rank of member ``group_rank`` of this pipeline's group."""
+        if self.group is None:
+            return group_rank
+        return dist.get_global_rank(self.group, group_rank)
+
     @property
     def is_first(self) -> bool:
         return self.rank == 0
@@ -45,33 +66,64 @@ class LayerPipeline:
     def is_last(self) -> bool:
         return self.rank == self.world - 1
 
-    # -- one hop ------------------------------------------------------------------------------
+    # -- one hop (blocking forms, kept for simple callers) ------------------------------------------
     def recv_hidden(self, buf: torch.Tensor) -> torch.Tensor:
         """Receive the previous stage's output into ``buf`` (no-op on the first stage)."""
         if self.world > 1 and not self.is_first:
-            dist.recv(buf, src=self.rank - 1, group=self.group)
+            dist.recv(buf, src=self._peer(self.rank - 1), group=self.group)
         return buf
 
     def send_hidden(self, h: torch.Tensor) -> None:
         """Send this stage's output to the next stage (no-op on the last stage)."""
         if self.world > 1 and not self.is_last:
-            dist.send(h.contiguous(), dst=self.rank + 1, group=self.group)
+            dist.send(h.contiguous(), dst=self._peer(self.rank + 1), group=self.group)
 
     # -- prefill-style streaming of micro-batches -------------------------------------------------
     def run_microbatches(self, stage_fn: Callable[[torch.Tensor], torch.Tensor], inputs: List[torch.Tensor],
                          recv_buf: torch.Tensor, collect: bool = True) -> List[torch.Tensor]:
-        """Stream ``inputs`` (used by the first stage; later stages only need their count and
-        shape) through the pipeline.  Stage ``r`` works on micro-batch ``b`` while stage ``r+1``
-        works on ``b-1``.  Returns the last stage's outputs (empty list elsewhere, or when
-        ``collect`` is False: a throughput run that does not keep them)."""
-        outs = []
-        for x in inputs:
-            h = x if self.is_first else self.recv_hidden(recv_buf)
-            h = stage_fn(h)
+        """Stream ``inputs`` (used by the first stage; later stages only need their count and shape) through the
+        pipeline with the overlapped schedule of the module docstring.  ``recv_buf`` gives shape / dtype / device
+        of the hidden state (it is slot 0 of the receive ring).  ``stage_fn(h)`` returns this stage's OUTPUT, which
+        is what hops on: stages are data-dependent.  Returns the last stage's outputs (empty list elsewhere, or
+        when ``collect`` is False: a throughput run that does not keep them)."""
+        n = len(inputs)
+        outs: List[torch.Tensor] = []
+        if self.world == 1:
+            for x in inputs:
+                h = stage_fn(x)
+                if collect:
+                    outs.append(h)
+            return outs
+        rbuf = [recv_buf, torch.empty_like(recv_buf)] if not self.is_first else None
+        sbuf = [None, None]                     # send ring, allocated from the first output's shape
+        rwork = [None, None]
+        swork = [None, None]
+        src = self._peer(self.rank - 1) if not self.is_first else None
+        dst = self._peer(self.rank + 1) if not self.is_last else None
+        if not self.is_first and n:
+            rwork[0] = dist.irecv(rbuf[0], src=src, group=self.group)
+        for b in range(n):
+            if not self.is_first:
+                if b + 1 < n:                   # slot (b+1) % 2 last held micro-batch b-1, consumed by stage_fn(b-1)
+                    rwork[(b + 1) % 2] = dist.irecv(rbuf[(b + 1) % 2], src=src, group=self.group)
+                rwork[b % 2].wait()
+                x = rbuf[b % 2]
+            else:
+                x = inputs[b]
+            h = stage_fn(x)
             if not self.is_last:
-                self.send_hidden(h)
+                s = b % 2
+                if swork[s] is not None:
+                    swork[s].wait()             # isend(b-2) done: its ring slot is free
+                if sbuf[s] is None:
+                    sbuf[s] = torch.empty_like(h, memory_format=torch.contiguous_format)
+                sbuf[s].copy_(h)
+                swork[s] = dist.isend(sbuf[s], dst=dst, group=self.group)
             elif collect:
-                outs.append(h.clone() if h is recv_buf else h)
+                outs.append(h.clone() if (rbuf is not None and any(h is r for r in rbuf)) else h)
+        for w in swork:
+            if w is not None:
+                w.wait()
         return outs
 
     # -- greedy decode ------------------------------------------------------------------------------
@@ -81,11 +133,13 @@ class LayerPipeline:
         """Batch-1 greedy decode of ``n_tokens`` tokens.
 
         first stage: ``embed_fn(token [1] int64) -> hidden``; every stage: ``stage_fn(hidden, step)``;
-        last stage: ``head_fn(hidden) -> next token [1] int64``, sent back to the first stage.
-        A batch-1 pipeline is sequential by nature (each token needs the previous one), so G
-        GPUs give memory capacity, not speed-up.  Returns the generated ids (same on every rank)."""
+        last stage: ``head_fn(hidden) -> next token [1] int64``, sent point-to-point to the first stage -- the only
+        rank that needs it (no collective on the critical path).  A batch-1 pipeline is sequential by nature
+        (each token needs the previous one), so G GPUs give memory capacity, not speed-up.
+        Returns the generated ids on the first and on the last stage, an empty list on the stages in between."""
         token_buf.fill_(int(first_token))
-        generated = torch.zeros(n_tokens, dtype=token_buf.dtype, device=token_buf.device)
+        keeps = self.is_first or self.is_last
+        generated = torch.zeros(n_tokens if keeps else 0, dtype=token_buf.dtype, device=token_buf.device)
         for step in range(n_tokens):
             if self.is_first:
                 h = embed_fn(token_buf)
@@ -94,11 +148,12 @@ class LayerPipeline:
             h = stage_fn(h, step)
             if self.is_last:
                 token_buf.copy_(head_fn(h).reshape(-1)[:1])
+                if self.world > 1:
+                    dist.send(token_buf, dst=self._peer(0), group=self.group)
             else:
                 self.send_hidden(h)
-            # next-token id: last stage -> everyone (8 bytes); a broadcast keeps every rank's
-            # bookkeeping identical and is latency-equivalent to the single send to rank 0
-            if self.world > 1:
-                dist.broadcast(token_buf, src=self.world - 1, group=self.group)
-            generated[step:step + 1].copy_(token_buf)     # stays on the device: no host sync per token
+                if self.is_first:
+                    dist.recv(token_buf, src=self._peer(self.world - 1), group=self.group)
+            if keeps:
+                generated[step:step + 1].copy_(token_buf)     # stays on the device: no host sync per token
         return generated.tolist()

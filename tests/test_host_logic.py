@@ -222,3 +222,20 @@ print("OK")
 ''' % (__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))),)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stderr[-2000:]
+
+
+def test_context_window_guards_the_kv_cache():
+    """decoding past max_ctx must fail on the host instead of overrunning the cache on the device."""
+    from mxq_amd.llama_decode import ContextWindow
+    w = ContextWindow(4)
+    assert [w.take(), w.take(2)] == [0, 1] and w.pos == 3
+    w.take(1)
+    with pytest.raises(RuntimeError, match="exceeds the KV cache"):
+        w.take(1)
+    assert w.pos == 4                       # a refused reservation leaves the position alone
+    w.reset()
+    assert w.take(4) == 0
+    with pytest.raises(RuntimeError):
+        w.take(1)
+    with pytest.raises(ValueError):
+        ContextWindow(0)

@@ -52,8 +52,9 @@ def _worker(rank, world, port, q):
         fn = _stage(Ws, layer_range(rank, world, N_LAYERS))
         xs = [torch.full((4, HID), float(b + 1)) / 7 for b in range(5)]
         outs = pipe.run_microbatches(fn, xs, torch.empty(4, HID))
-        # bench.py's N > 1 schedule: the stage hands its own input buffer on, nothing is collected
-        assert pipe.run_microbatches(lambda h: h, xs * 3, torch.empty(4, HID), collect=False) == []
+        # bench.py's N > 1 schedule: a reused output buffer hops on (the send ring must decouple it), nothing is collected
+        ybuf = torch.empty(4, HID)
+        assert pipe.run_microbatches(lambda h: ybuf.copy_(h * 2), xs * 3, torch.empty(4, HID), collect=False) == []
         gen = pipe.decode(3, 6, lambda t: emb.index_select(0, t), fn, lambda h: (h @ head.t()).argmax(-1),
                           torch.empty(1, HID), torch.zeros(1, dtype=torch.int64))
         q.put((rank, [o.clone() for o in outs], gen))
@@ -80,8 +81,50 @@ def test_pipeline_matches_single_process(world):
     ref_outs, ref_gen = _reference(6, 3)
     outs, gen = res[world - 1]
     assert len(outs) == 5 and all(torch.equal(a, b) for a, b in zip(outs, ref_outs))
-    assert all(res[r][1] == ref_gen for r in range(world))          # every rank tracks the same tokens
+    assert res[0][1] == ref_gen and res[world - 1][1] == ref_gen      # first and last stage track the tokens
+    assert all(res[r][1] == [] for r in range(1, world - 1))          # the stages in between never see them
     assert all(len(res[r][0]) == 0 for r in range(world - 1))
+
+
+def _worker_subgroup(rank, world, port, q):
+    """The pipeline lives in a SUB-GROUP (global ranks 1, 2 of a 3-rank job): group ranks differ from global ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grp = dist.new_group([1, 2])
+        out = None
+        if rank in (1, 2):
+            Ws, emb, head = _weights()
+            pipe = LayerPipeline(group=grp)
+            assert (pipe.rank, pipe.world) == (rank - 1, 2)
+            fn = _stage(Ws, layer_range(pipe.rank, 2, N_LAYERS))
+            xs = [torch.full((4, HID), float(b + 1)) / 7 for b in range(5)]
+            outs = pipe.run_microbatches(fn, xs, torch.empty(4, HID))
+            gen = pipe.decode(3, 6, lambda t: emb.index_select(0, t), fn, lambda h: (h @ head.t()).argmax(-1),
+                              torch.empty(1, HID), torch.zeros(1, dtype=torch.int64))
+            out = ([o.clone() for o in outs], gen)
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipeline_in_a_subgroup_addresses_its_own_members():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_subgroup, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_outs, ref_gen = _reference(6, 3)
+    assert res[0] is None
+    outs, gen = res[2]
+    assert len(outs) == 5 and all(torch.equal(a, b) for a, b in zip(outs, ref_outs))
+    assert gen == ref_gen and res[1][1] == ref_gen and res[1][0] == []
 
 
 def test_layer_range_partition():
