@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import packing
-from .quantizer import Quantizer
+from .quantizer import GroupView
 
 
 class MXQGPT:
@@ -55,17 +55,17 @@ class MXQGPT:
             self._params = packing.unpack(self.packed)
         return self._params
 
-    def quantizer(self, chunk: int, group: int) -> Quantizer:
+    def quantizer(self, chunk: int, group: int) -> GroupView:
         p, j = self.params(), 3 * chunk + group
         lo = chunk * 64 + group * 16
-        return Quantizer(2, p["codes2"][:, chunk * 48 + group * 16: chunk * 48 + group * 16 + 16], p["sc2"][:, j],
+        return GroupView(2, p["codes2"][:, chunk * 48 + group * 16: chunk * 48 + group * 16 + 16], p["sc2"][:, j],
                          p["zero2"][:, j], p["qs2"][:, j], p["qz2"][:, j], self.layer.weight.data[:, lo:lo + 16])
 
     @property
-    def quantizer_4b(self) -> Quantizer:
+    def quantizer_4b(self) -> GroupView:
         p = self.params()
         idx = torch.arange(self.columns, device=self.dev).reshape(-1, 64)[:, 48:].reshape(-1)
-        return Quantizer(4, p["codes4"], p["sc4"], p["zero4"], p["qs4"], p["qz4"], self.layer.weight.data[:, idx])
+        return GroupView(4, p["codes4"], p["sc4"], p["zero4"], p["qs4"], p["qz4"], self.layer.weight.data[:, idx])
 
     def free(self):
         self.seen = None

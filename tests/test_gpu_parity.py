@@ -145,13 +145,91 @@ def test_mxqgpt_driver_api(dev, g1):
     assert lin.weight.dtype == torch.float16
     assert np.array_equal(lin.weight.data.cpu().numpy().view(np.uint16), g1["w_deq"].view(np.uint16))
     q = gpt.quantizer(1, 2)
-    assert np.array_equal(q.quantize().cpu().numpy().astype(np.uint8), g1["codes2"][:, 48 + 32:48 + 48])
+    assert np.array_equal(q.codes().cpu().numpy().astype(np.uint8), g1["codes2"][:, 48 + 32:48 + 48])
     assert np.array_equal(q.scale.reshape(-1).cpu().numpy(), g1["scale2"][:, 5])
     assert np.array_equal(gpt.quantizer_4b.scale.reshape(-1).cpu().numpy(), g1["scale4"])
     ql = QuantLinear.from_packed(gpt.packed)
     gpt.free()
     x = torch.from_numpy(g1["x"]).to(dev)
     _check_gemm(ql(x).cpu().numpy(), g1["y32"], "QuantLinear on G1")
+
+
+def test_quantizer_reference_api_g8(dev):
+    """lib.quantizer.Quantizer used exactly as the reference's loop uses it (mxqgpt.py:417-428, :433-436):
+    configure -> find_params(W1, weight=True) -> quantize / quantize_dequantize, bit-exact against the reference's own
+    Quantizer outputs in golden G8 (2-bit group by group, 4-bit per row), including the constant group / row."""
+    from mxq_amd.lib.quantizer import Quantizer
+    from tests.conftest import load_golden
+    g8 = load_golden("g8_uniform.npz")
+    Wf = torch.from_numpy(g8["W"]).to(dev).float()
+    N, K = Wf.shape
+    for g in range(K // 16):
+        blk = Wf[:, 16 * g:16 * g + 16].clone()
+        q = Quantizer()
+        q.configure(bits=2, perchannel=True, sym=False, qq_scale_bits=4)
+        q.find_params(blk, weight=True)
+        assert q.scale.shape == (N, 1) and q.zero.shape == (N, 1) and int(q.maxq) == 3 and q.ready()
+        assert np.array_equal(q.quantize(blk).cpu().numpy().astype(np.uint8), g8["w2_codes"][:, 16 * g:16 * g + 16])
+        assert np.array_equal(q.quantize_dequantize(blk).half().cpu().numpy().view(np.uint16),
+                              g8["w2_wdeq"][:, 16 * g:16 * g + 16].view(np.uint16))
+        assert np.array_equal(q.quant_scale.reshape(-1).cpu().numpy().astype(np.uint8), g8["w2_sc"][:, g])
+        assert np.array_equal(q.zero.reshape(-1).cpu().numpy(), g8["w2_zero"][:, g])
+        assert np.array_equal(q.qq_scale.scale.reshape(-1).cpu().numpy(), g8["w2_qs"][:, g])
+        assert np.array_equal(q.qq_scale.zero.reshape(-1).cpu().numpy(), g8["w2_qz"][:, g])
+        # stored parameters applied to OTHER data: the reference's formula on the device (quantizer.py:14-20)
+        other = (blk * 1.7 + 0.003).contiguous()
+        ref = torch.clamp(torch.round(other.cpu() / q.scale.cpu().clamp_min(1e-9) + q.zero.cpu()), 0, 3)
+        assert torch.equal(q.quantize(other).cpu(), ref)
+        assert torch.equal(q.dequantize(q.quantize(other)).cpu(), q.scale.cpu() * (ref - q.zero.cpu()))
+    q = Quantizer()
+    q.configure(bits=4, perchannel=True, sym=False, qq_scale_bits=4)
+    q.find_params(Wf, weight=True)
+    assert int(q.maxq) == 15
+    assert np.array_equal(q.quantize(Wf).cpu().numpy().astype(np.uint8), g8["w4_codes"])
+    assert np.array_equal(q.quantize_dequantize(Wf).half().cpu().numpy().view(np.uint16), g8["w4_wdeq"].view(np.uint16))
+    assert np.array_equal(q.zero.cpu().numpy(), g8["w4_zero"])
+    assert np.array_equal(q.quant_scale.reshape(-1, 1).cpu().numpy().astype(np.uint8), g8["w4_sc"])
+    # a 4-bit arm whose width is not a multiple of the kernel's 64-column block (K/4 of a ragged K): padded internally
+    sub = Wf[:, :80].contiguous()
+    q2 = Quantizer()
+    q2.configure(bits=4, perchannel=True, sym=False, qq_scale_bits=4)
+    q2.find_params(sub, weight=True)
+    r = O.uniform_quantize(np.concatenate([sub.cpu().numpy(), np.repeat(sub.cpu().numpy()[:, -1:], 48, 1)], 1).astype(np.float32), "w4row")
+    assert np.array_equal(q2.quantize(sub).cpu().numpy().astype(np.uint8), r["codes"][:, :80])
+    # unsupported configurations refuse instead of approximating
+    with pytest.raises(NotImplementedError):
+        Quantizer().configure(bits=3, perchannel=True, sym=False, qq_scale_bits=4)
+    with pytest.raises(NotImplementedError):
+        Quantizer().configure(bits=2, perchannel=True, sym=True, qq_scale_bits=4)
+    with pytest.raises(ValueError):
+        q.find_params(Wf.cpu(), weight=True)
+
+
+def test_quantizer_reproduces_fasterquant_loop_g1(dev, g1):
+    """The reference's fasterquant loop written against lib.quantizer.Quantizer (3 two-bit groups per chunk + one
+    4-bit Quantizer over the gathered last-16 columns, mxqgpt.py:404-443) gives G1's codes and fp16 weight."""
+    from mxq_amd.lib.quantizer import Quantizer
+    W = torch.from_numpy(g1["W"]).to(dev).float()
+    W[:, torch.from_numpy(g1["dead"].astype(bool)).to(dev)] = 0        # mxqgpt.py:401-403 (the planted dead column)
+    N, K = W.shape
+    out = torch.zeros_like(W)
+    W4 = torch.cat([W[:, 64 * c + 48:64 * c + 64] for c in range(K // 64)], dim=1).contiguous()
+    for c in range(K // 64):
+        for g in range(3):
+            W1 = W[:, 64 * c + 16 * g:64 * c + 16 * g + 16].contiguous()
+            q = Quantizer()
+            q.configure(2, perchannel=True, sym=False, qq_scale_bits=4, round_zero=False)
+            q.find_params(W1, weight=True)
+            out[:, 64 * c + 16 * g:64 * c + 16 * g + 16] = q.quantize_dequantize(W1)
+            assert np.array_equal(q.quantize(W1).cpu().numpy().astype(np.uint8), g1["codes2"][:, 48 * c + 16 * g:48 * c + 16 * g + 16])
+    q4 = Quantizer()
+    q4.configure(4, perchannel=True, sym=False, qq_scale_bits=4, round_zero=False)
+    q4.find_params(W4, weight=True)
+    d4 = q4.quantize_dequantize(W4)
+    for c in range(K // 64):
+        out[:, 64 * c + 48:64 * c + 64] = d4[:, 16 * c:16 * c + 16]
+    assert np.array_equal(q4.quantize(W4).cpu().numpy().astype(np.uint8), g1["codes4"])
+    assert np.array_equal(out.half().cpu().numpy().view(np.uint16), g1["w_deq"].view(np.uint16))
 
 
 # ----------------------------------------------------------------------------------------
