@@ -419,6 +419,46 @@ def test_full_size_properties(dev, N, K):
     assert torch.equal(pk.qweight, p.qweight) and torch.equal(pk.rowmeta, p.rowmeta)
 
 
+@pytest.mark.parametrize("layout,N,K", [("mixed", 4096, 4096), ("mixed", 11008, 4096), ("mixed", 4096, 11008),
+                                        ("w2g16", 4096, 4096), ("w2g16", 4096, 11008),
+                                        ("w4row", 4096, 4096), ("w4row", 11008, 4096)])
+def test_config5_full_size_m32768(dev, layout, N, K):
+    """BASELINE configs[4]: batch 8 x seq 4096 = 32768 tokens, per weight layout (mixed 2/4, uniform W2 group 16,
+    uniform W4 per row).  Size-independent properties at the full size: (1) the GEMM equals the fp32 product on the
+    dequant kernel's weight (itself bit-exact against the oracle at the sizes the oracle can run) on every token
+    row, max-norm and Frobenius <= 1e-3; (2) 16 sampled rows against the ORACLE's weight (numpy restatement);
+    (3) the first and the last 2048 tokens agree bit for bit with the same rows run as their own launch (a tile's
+    result does not depend on where the persistent loop runs it; 2048 tokens is a launch without a stream-K split)."""
+    from mxq_amd import packing
+    M = 32768
+    g = torch.Generator(device="cpu").manual_seed(N * 3 + K + len(layout))
+    W16 = (torch.randn(N, K, generator=g) * 0.02).half()
+    W = W16.to(dev)
+    if layout == "mixed":
+        p = packing.quantize_pack(W)
+        wd = packing.dequant(p)
+    else:
+        p = packing.quantize_pack_uniform(W, layout)
+        wd = packing.expand_uniform(p, codes=False)[0]
+    x = torch.randn(M, K, generator=g).half().to(dev)
+    y = packing.linear_layout(x, p)
+    worst_max = worst_fro = 0.0
+    for r0 in range(0, M, 4096):                       # fp32 reference in slabs (keeps the fp32 copies small)
+        ref = x[r0:r0 + 4096].float() @ wd.float().t()
+        got = y[r0:r0 + 4096].float()
+        worst_max = max(worst_max, ((got - ref).abs().max() / ref.abs().max()).item())
+        worst_fro = max(worst_fro, ((got - ref).norm() / ref.norm()).item())
+    assert worst_max <= REL_TOL and worst_fro <= REL_TOL, (layout, N, K, worst_max, worst_fro)
+    rows = [0, 255, 256, 4095, 16384, 20000, 32767, 31999, 12345, 777, 1024, 8191, 8192, 30000, 2047, 2048]
+    w_or = (O.mxq_quantize(W16.numpy())["w_deq32"] if layout == "mixed"
+            else O.uniform_quantize(W16.numpy(), layout)["w_deq32"]).astype(np.float16)
+    assert np.array_equal(wd.cpu().numpy().view(np.uint16), w_or.view(np.uint16)), "dequant kernel vs oracle at full size"
+    _check_gemm(y[rows].cpu().numpy(), O.linear_ref(x[rows].cpu().numpy(), w_or), f"{layout} M=32768 rows vs oracle")
+    for r0 in (0, M - 2048):
+        alone = packing.linear_layout(x[r0:r0 + 2048].contiguous(), p)
+        assert torch.equal(alone, y[r0:r0 + 2048]), (layout, r0)
+
+
 def test_quantlinear_module(dev):
     from mxq_amd.quant_linear import QuantLinear
     lin = torch.nn.Linear(512, 256, bias=True).to(dev).half()
@@ -734,13 +774,14 @@ def test_activation_quantizer_backward_and_errors(dev):
 # ----------------------------------------------------------------------------------------
 # decode stage (config 3 harness): fused q/k/v and gate/up GEMVs vs a dense fp32 restatement
 # ----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("heads,fused", [(4, False), (2, True), (2, False)])
+@pytest.mark.parametrize("heads,fused", [(4, False), (2, True), (2, False), (32, True), (32, False)])
 def test_decode_stage_matches_dense_reference(dev, heads, fused):
     """fused = RMSNorm / SwiGLU / residual folded into the GEMV launches + the RoPE / cache /
     attention kernel (head_dim 128); unfused = torch ops around plain GEMVs."""
     from mxq_amd import packing
     from mxq_amd.llama_decode import DecodeStage
-    hidden, inter, ctx = 256, 704, 32
+    # heads == 32: the full Llama-2-7B layer shape (hidden 4096, intermediate 11008, 32 heads of 128), 2 layers
+    hidden, inter, ctx = (4096, 11008, 32) if heads == 32 else (256, 704, 32)
     st = DecodeStage(range(2), dev, max_ctx=ctx, hidden=hidden, inter=inter, heads=heads, vocab=64, fused=fused)
     assert st.fused == (fused and hidden // heads == 128)
     Wd = [[packing.dequant(p).float() for p in ws] for ws in st.w]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE GEMM kernel variant at ONE shape a few times (for rocprofv3 --pmc runs).
-    python3 tools/gemm_prof.py gemm8 2048 4096 4096 [iters]"""
+    python3 tools/gemm_prof.py gemm8 2048 4096 4096 [iters] [layout: mixed | w2g16 | w4row]"""
 import os
 import sys
 
@@ -11,12 +11,16 @@ from mxq_amd import packing  # noqa: E402
 
 variant, M, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+layout = sys.argv[6] if len(sys.argv) > 6 else "mixed"
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
-p = packing.quantize_pack(W)
+p = packing.quantize_pack(W) if layout == "mixed" else packing.quantize_pack_uniform(W, layout)
 x = torch.randn(M, K, generator=g, device=dev).half()
 out = torch.empty(M, N, device=dev, dtype=torch.float16)
 for _ in range(iters):
-    packing.linear(x, p, out=out, path=variant)
+    if layout == "mixed":
+        packing.linear(x, p, out=out, path=variant)
+    else:
+        packing.linear_layout(x, p, out=out)
 torch.cuda.synchronize()

@@ -2,7 +2,9 @@
 """BASELINE config 5: Llama-2-7B W2A16 vs W4A16 vs mixed-2/4 sweep at seq=4096 batch=8
 (M = 32768 tokens), 1 x MI355X.  For each arm and each of the three Linear shapes: kernel time
 (HIP events), TFLOP/s, fraction of the 2.5 PF fp16 MFMA peak, packed bits/weight; the per-layer
-and 32-layer totals; and PyTorch's fp16 GEMM (hipBLASLt) on the dequantised weight as reference.
+and 32-layer totals; and PyTorch's fp16 GEMM (hipBLASLt) on the dequantised weight as reference.  Every
+quantised arm is checked at the full size (<= 1e-3 max-norm and Frobenius against the fp32 product on the
+kernel-dequantised weight, 4096 sampled token rows) before its time is reported.
     python tools/sweep_config5.py [--m 32768] [--iters 3]"""
 import argparse
 import json
@@ -54,9 +56,22 @@ def main():
                 p = packing.quantize_pack(W) if arm == "mixed" else packing.quantize_pack_uniform(W, arm)
                 t = timed(lambda: packing.linear_layout(x, p, out=out), args.iters)
                 bpw = p.bits_per_weight()
+                # parity at the full size: fp32 product on the kernel-dequantised weight (bit-exact against the
+                # oracle in tests/), 4096 sampled token rows; both error norms of SURVEY.md 8c
+                wd = packing.dequant(p) if arm == "mixed" else packing.expand_uniform(p, codes=False)[0]
+                rows_ = torch.randint(0, M, (4096,), generator=g, device=dev)
+                ref = x[rows_].float() @ wd.float().t()
+                got = out[rows_].float()
+                err_max = ((got - ref).abs().max() / ref.abs().max()).item()
+                err_fro = ((got - ref).norm() / ref.norm()).item()
+                assert err_max <= 1e-3 and err_fro <= 1e-3, (arm, name, err_max, err_fro)
+                rows_err = {"max_rel": err_max, "fro_rel": err_fro}
+                del wd, ref, got
             fl = 2.0 * M * N * K
             rows.append({"linear": name, "N": N, "K": K, "ms": round(t * 1e3, 3), "TFLOPs": round(fl / t / 1e12, 1),
                          "mfma_frac": round(fl / t / 1e12 / PEAK, 3), "bits_per_weight": round(bpw, 3)})
+            if arm != "fp16-hipblaslt":
+                rows[-1].update({k: float(f"{v:.3g}") for k, v in rows_err.items()})
             layer_t += mult * t
             layer_f += mult * fl
             del W, x, out
