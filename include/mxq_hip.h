@@ -86,7 +86,12 @@ int mxq_dequant_f16(const void* qweight, const void* rowmeta, void* w16, int N, 
  * x, y, qweight must be 16-byte aligned; y must not alias x. */
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream);
-/* The two code paths of mxq_linear_f16, exposed for benchmarking / testing. */
+/* The code paths of mxq_linear_f16, exposed for benchmarking / testing: streaming GEMV (M <= 4), skinny MFMA kernel
+ * (4 < M <= 32: every packed byte read once, a lane dequantises the MFMA operand it owns; the reference re-reads the
+ * weights once per batch row, gemv_mxq_cuda.cu:261-262), prefill GEMM (M > 32).  mxq_skinny_f16 accepts 1 <= M <= 32
+ * and layout MXQ_LAYOUT_MIXED (0) or MXQ_LAYOUT_MIXEDC (3, compact metadata, below). */
+int mxq_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
+                   void* stream);
 int mxq_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                  void* stream);
 int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -119,7 +124,23 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
 #define MXQ_LAYOUT_MIXED 0
 #define MXQ_LAYOUT_W2G16 1
 #define MXQ_LAYOUT_W4ROW 2
+/* 3 = MIXEDC: the mixed layout with COMPACT metadata ("format v2", csrc/mxq_format.h): same codes / scale codes /
+ * (qs, qz), 2-bit zero-points stored as fp16 -> 480-B blocks, 3.75 bit/weight instead of 4.5.  The integer unpack
+ * stays bit-exact on the codes; the dequantised weight becomes fp16(scale * (q - float(fp16(zero)))), which moves
+ * the GEMM result by ~4e-4 relative (inside the 1e-3 budget).  The reference's own kernel
+ * format (gemv_mxq_cuda.cu:54-62, integer zeros) is coarser still and is served by mxq_gemv_proto_f16. */
+#define MXQ_LAYOUT_MIXEDC 3
 size_t mxq_qweight_bytes_layout(int N, int K, int layout);
+/* exact (layout 0, from mxq_quantize_pack / mxq_pack_codes) -> compact (layout 3) blocks; rowmeta is shared. */
+int mxq_compact(const void* qweight_exact, void* qweight_compact, int N, int K, void* stream);
+/* mxq_unpack / mxq_dequant_f16 / mxq_gemv_fused_f16 on a compact qweight (same arguments; zero2 comes back as the
+ * stored fp16 values widened to fp32).  GEMM / GEMV: mxq_gemm_f16_layout / mxq_gemv_f16_layout with layout 3. */
+int mxq_unpack_compact(const void* qweight, const void* rowmeta, uint8_t* codes2, uint8_t* sc2, float* zero2, float* qs2,
+                       float* qz2, uint8_t* codes4, uint8_t* sc4, float* zero4, float* qs4, float* qz4, int N, int K,
+                       void* stream);
+int mxq_dequant_f16_compact(const void* qweight, const void* rowmeta, void* w16, int N, int K, void* stream);
+int mxq_gemv_fused_f16_compact(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                               int prologue, const void* norm_w, float eps, const void* residual, void* stream);
 int mxq_quantize_pack_layout(const void* W, int w_dtype, void* qweight, void* rowmeta, int N, int K, int layout,
                              void* stream);
 /* Uniform layouts only: dequantise to fp16 [N, K] (w16, nullable) and / or integer-unpack (codes u8

@@ -33,6 +33,10 @@ SIGNATURES = {
     "mxq_pack_codes": (c_int, [c_void_p] * 12 + [c_int, c_int, c_void_p]),
     "mxq_unpack": (c_int, [c_void_p] * 12 + [c_int, c_int, c_void_p]),
     "mxq_dequant_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mxq_compact": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mxq_unpack_compact": (c_int, [c_void_p] * 12 + [c_int, c_int, c_void_p]),
+    "mxq_dequant_f16_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mxq_gemv_fused_f16_compact": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "mxq_linear_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "mxq_gemm_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "mxq_actquant_group_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -42,6 +46,7 @@ SIGNATURES = {
     "mxq_linear_f16_ws": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "mxq_gemm_f16_ws": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "mxq_gemv_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
+    "mxq_skinny_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_qweight_bytes_layout": (c_size_t, [c_int, c_int, c_int]),
     "mxq_quantize_pack_layout": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mxq_expand_layout": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),

@@ -3,7 +3,8 @@
 The reference saves the fake-quantised fp16 model with ``model.save_pretrained(args.save_model)``
 (mxq_quant/main.py:96-100), i.e. 16 bit/weight on disk for a 2.5-bit model; this is the packed
 counterpart: one ``model.safetensors`` holding the ordinary ``state_dict``
-(``<name>.qweight`` int32, ``<name>.rowmeta`` float32 [N, 4], ``<name>.fmt`` int32 (version, N, K),
+(``<name>.qweight`` int32, ``<name>.rowmeta`` float32 [N, 4], ``<name>.fmt`` int32 (version, N, K) with version 1 =
+exact metadata (4.5 bit/weight) or 2 = compact metadata (fp16 zero-points, 3.75 bit/weight),
 optional ``<name>.bias``; every non-quantised tensor as it is) plus ``mxq_config.json`` naming the
 quantised modules, so that ``load_packed`` can rebuild the module tree before ``load_state_dict``.
 """
@@ -31,7 +32,7 @@ def _set_submodule(root: nn.Module, dotted: str, new: nn.Module) -> None:
     setattr(parent, parts[-1], new)
 
 
-def pack_model(model: nn.Module, skip: Iterable[str] = ("lm_head",)) -> List[str]:
+def pack_model(model: nn.Module, skip: Iterable[str] = ("lm_head",), compact: bool = False) -> List[str]:
     """Replace every ``nn.Linear`` of ``model`` (on the GPU) by ``QuantLinear.from_linear`` -- the
     round-to-nearest MXQ quantisation of its weight -- except modules whose dotted name ends with an
     entry of ``skip`` (the reference quantises decoder layers only, prune.py:347,368).  Returns the
@@ -40,7 +41,7 @@ def pack_model(model: nn.Module, skip: Iterable[str] = ("lm_head",)) -> List[str
     names = [n for n, m in model.named_modules() if type(m) is nn.Linear and not any(n == s or n.endswith("." + s) for s in skip)]
     for n in names:
         lin = dict(model.named_modules())[n]
-        _set_submodule(model, n, QuantLinear.from_linear(lin))
+        _set_submodule(model, n, QuantLinear.from_linear(lin, compact=compact))
     return names
 
 
@@ -56,7 +57,8 @@ def save_packed(model: nn.Module, directory: str) -> str:
     if not q:
         raise ValueError("model holds no QuantLinear module: nothing packed to save")
     cfg = {"format": FORMAT, "format_version": 1,
-           "quantized": {n: {"in_features": m.in_features, "out_features": m.out_features, "bias": m.bias is not None}
+           "quantized": {n: {"in_features": m.in_features, "out_features": m.out_features, "bias": m.bias is not None,
+                             "metadata": "compact" if m.compact else "exact"}
                          for n, m in q.items()}}
     sd = {k: v.detach().contiguous().cpu() for k, v in model.state_dict().items()}
     save_file(sd, os.path.join(directory, WEIGHTS_NAME), metadata={"format": FORMAT})
@@ -86,11 +88,13 @@ def load_packed(model: nn.Module, directory: str, device: Optional[torch.device]
         if isinstance(old, nn.Linear) and (old.in_features, old.out_features) != (spec["in_features"], spec["out_features"]):
             raise ValueError(f"{n}: checkpoint is {spec['out_features']}x{spec['in_features']}, "
                              f"model has {old.out_features}x{old.in_features}")
-        _set_submodule(model, n, QuantLinear(spec["in_features"], spec["out_features"], bias=spec["bias"], device=dev))
+        _set_submodule(model, n, QuantLinear(spec["in_features"], spec["out_features"], bias=spec["bias"], device=dev,
+                                             compact=spec.get("metadata", "exact") == "compact"))
     sd = load_file(os.path.join(directory, WEIGHTS_NAME))
     for n, spec in cfg["quantized"].items():
         fmt = sd.get(n + ".fmt")
-        if fmt is None or fmt.tolist() != [1, spec["out_features"], spec["in_features"]]:
+        ver = 2 if spec.get("metadata", "exact") == "compact" else 1
+        if fmt is None or fmt.tolist() != [ver, spec["out_features"], spec["in_features"]]:
             raise ValueError(f"{n}: fmt header {None if fmt is None else fmt.tolist()} does not match mxq_config.json")
     model.load_state_dict(sd, strict=True)
     return model

@@ -52,15 +52,41 @@ int mxq_unpack(const void* qweight, const void* rowmeta, uint8_t* codes2, uint8_
         return MXQ_E_NULL;
     if (!shape_ok(N, K)) return MXQ_E_SHAPE;
     if (!aligned16(qweight) || !aligned16(rowmeta)) return MXQ_E_ALIGN;
-    return mxq_launch_unpack(qweight, rowmeta, codes2, sc2, zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4, N, K,
+    return mxq_launch_unpack(qweight, rowmeta, codes2, sc2, zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4, N, K, 0,
                              (hipStream_t)stream);
+}
+
+int mxq_unpack_compact(const void* qweight, const void* rowmeta, uint8_t* codes2, uint8_t* sc2, float* zero2,
+                       float* qs2, float* qz2, uint8_t* codes4, uint8_t* sc4, float* zero4, float* qs4, float* qz4,
+                       int N, int K, void* stream) {
+    if (!codes2 || !sc2 || !zero2 || !qs2 || !qz2 || !codes4 || !sc4 || !zero4 || !qs4 || !qz4 || !qweight ||
+        !rowmeta)
+        return MXQ_E_NULL;
+    if (!shape_ok(N, K)) return MXQ_E_SHAPE;
+    if (!aligned16(qweight) || !aligned16(rowmeta)) return MXQ_E_ALIGN;
+    return mxq_launch_unpack(qweight, rowmeta, codes2, sc2, zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4, N, K, 1,
+                             (hipStream_t)stream);
+}
+
+int mxq_compact(const void* qweight_exact, void* qweight_compact, int N, int K, void* stream) {
+    if (!qweight_exact || !qweight_compact) return MXQ_E_NULL;
+    if (!shape_ok(N, K)) return MXQ_E_SHAPE;
+    if (!aligned16(qweight_exact) || !aligned16(qweight_compact)) return MXQ_E_ALIGN;
+    return mxq_launch_compact(qweight_exact, qweight_compact, N, K, (hipStream_t)stream);
 }
 
 int mxq_dequant_f16(const void* qweight, const void* rowmeta, void* w16, int N, int K, void* stream) {
     if (!qweight || !rowmeta || !w16) return MXQ_E_NULL;
     if (!shape_ok(N, K)) return MXQ_E_SHAPE;
     if (!aligned16(qweight) || !aligned16(rowmeta) || !aligned16(w16)) return MXQ_E_ALIGN;
-    return mxq_launch_dequant_f16(qweight, rowmeta, w16, N, K, (hipStream_t)stream);
+    return mxq_launch_dequant_f16(qweight, rowmeta, w16, N, K, 0, (hipStream_t)stream);
+}
+
+int mxq_dequant_f16_compact(const void* qweight, const void* rowmeta, void* w16, int N, int K, void* stream) {
+    if (!qweight || !rowmeta || !w16) return MXQ_E_NULL;
+    if (!shape_ok(N, K)) return MXQ_E_SHAPE;
+    if (!aligned16(qweight) || !aligned16(rowmeta) || !aligned16(w16)) return MXQ_E_ALIGN;
+    return mxq_launch_dequant_f16(qweight, rowmeta, w16, N, K, 1, (hipStream_t)stream);
 }
 
 static int linear_check(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K) {
@@ -83,12 +109,28 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
     return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
 }
 
+int mxq_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
+                   void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    if (M > 32 || (layout != MXQ_LAYOUT_MIXED && layout != MXQ_LAYOUT_MIXEDC)) return MXQ_E_SHAPE;
+    return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
+}
+
 int mxq_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K, int prologue,
                        const void* norm_w, float eps, const void* residual, void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, 1, N, K)) return e;
     if (prologue < 0 || prologue > 2) return MXQ_E_SHAPE;
     if (prologue == 1 && !norm_w) return MXQ_E_NULL;
-    return mxq_launch_gemv_fused_f16(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual,
+    return mxq_launch_gemv_fused_f16(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual, 0,
+                                     (hipStream_t)stream);
+}
+
+int mxq_gemv_fused_f16_compact(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                               int prologue, const void* norm_w, float eps, const void* residual, void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, 1, N, K)) return e;
+    if (prologue < 0 || prologue > 2) return MXQ_E_SHAPE;
+    if (prologue == 1 && !norm_w) return MXQ_E_NULL;
+    return mxq_launch_gemv_fused_f16(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual, 1,
                                      (hipStream_t)stream);
 }
 
@@ -101,7 +143,9 @@ int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const voi
 }
 
 // ---- uniform layouts of the config-5 sweep ---------------------------------------------------
-static bool layout_ok(int l) { return l == MXQ_LAYOUT_MIXED || l == MXQ_LAYOUT_W2G16 || l == MXQ_LAYOUT_W4ROW; }
+static bool layout_ok(int l) {
+    return l == MXQ_LAYOUT_MIXED || l == MXQ_LAYOUT_W2G16 || l == MXQ_LAYOUT_W4ROW || l == MXQ_LAYOUT_MIXEDC;
+}
 
 size_t mxq_qweight_bytes_layout(int N, int K, int layout) {
     if (!shape_ok(N, K) || !layout_ok(layout)) return 0;
@@ -111,7 +155,8 @@ size_t mxq_qweight_bytes_layout(int N, int K, int layout) {
 int mxq_quantize_pack_layout(const void* W, int w_dtype, void* qweight, void* rowmeta, int N, int K, int layout,
                              void* stream) {
     if (!W || !qweight || !rowmeta) return MXQ_E_NULL;
-    if (!shape_ok(N, K) || !layout_ok(layout)) return MXQ_E_SHAPE;
+    // (compact metadata is derived from the exact form: mxq_quantize_pack, then mxq_compact)
+    if (!shape_ok(N, K) || !layout_ok(layout) || layout == MXQ_LAYOUT_MIXEDC) return MXQ_E_SHAPE;
     if (!dtype_ok(w_dtype)) return MXQ_E_DTYPE;
     if (!aligned16(W) || !aligned16(qweight) || !aligned16(rowmeta)) return MXQ_E_ALIGN;
     if (layout == MXQ_LAYOUT_MIXED)
@@ -147,6 +192,7 @@ int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void
                    void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+    if (M <= 32) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
     return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
 }
 
@@ -166,6 +212,7 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+    if (M <= 32) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
     return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

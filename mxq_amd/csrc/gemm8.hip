@@ -438,7 +438,7 @@ template <int LAYOUT>
 __device__ __forceinline__ void issue_bp(const Deq& c, int t) {
     // dequant wave d copies packed blocks 2d, 2d+1 (rows 32d .. 32d+31), 36 lanes each (32 for W4ROW);
     // the LDS stride stays 576 B for every layout (bank-conflict-free block spacing)
-    constexpr int BYTES = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : MXQ_BLK_BYTES;
+    constexpr int BYTES = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : LAYOUT == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
     char* dst = c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.d * 2 * BP_BLK;
     if (c.lane < BYTES / 16) {
         const uint32_t so = c.k0 + (uint32_t)t * BYTES;
@@ -469,15 +469,25 @@ __device__ __forceinline__ void load_pk(const Deq& c, int t, Pk& k) {
         for (int i = 0; i < 4; ++i) k.c[i] = blk[mxq_w4_c4(c.h * 2 + (i >> 1), i & 1, c.r)];
         return;
     }
-    k.scw = ((const uint16_t*)blk)[mxq_sc_u16(c.r)];
+    constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC, COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
+    k.scw = ((const uint16_t*)blk)[COMPACT ? mxqc_sc_u16(c.r) : mxq_sc_u16(c.r)];
     const int g0 = c.h * 2;   // first 2-bit group of this thread
-    k.c[0] = blk[(LAYOUT == MXQ_LAYOUT_MIXED ? mxq_c2(0, c.r) : mxq_w2_c2(0, c.r)) + g0 * 16];
-    k.z[0] = blk[(LAYOUT == MXQ_LAYOUT_MIXED ? mxq_z2(0, c.r) : mxq_w2_z2(0, c.r)) + g0 * 16];
-    k.qq[0] = *(const f32x2*)(blk + mxq_qq(0) + g0 * 2);
+    auto zero_of = [&](int g) -> uint32_t {   // fp32 bits of the group's zero-point (compact: widened from fp16 here)
+        if constexpr (COMPACT) {
+            const uint16_t zh = ((const uint16_t*)blk)[mxqc_z2_u16(0, c.r) + g * 16];
+            return __float_as_uint((float)__builtin_bit_cast(_Float16, zh));
+        } else {
+            return blk[(MIXED ? mxq_z2(0, c.r) : mxq_w2_z2(0, c.r)) + g * 16];
+        }
+    };
+    constexpr int QQ0 = COMPACT ? MXQC_OFF_QQ : MXQ_OFF_QQ;
+    k.c[0] = blk[(MIXED ? mxq_c2(0, c.r) : mxq_w2_c2(0, c.r)) + g0 * 16];
+    k.z[0] = zero_of(g0);
+    k.qq[0] = *(const f32x2*)(blk + QQ0 + g0 * 2);
     if (LAYOUT == MXQ_LAYOUT_W2G16 || c.h == 0) {
-        k.c[1] = blk[(LAYOUT == MXQ_LAYOUT_MIXED ? mxq_c2(1, c.r) : mxq_w2_c2(1, c.r)) + g0 * 16];
-        k.z[1] = blk[(LAYOUT == MXQ_LAYOUT_MIXED ? mxq_z2(1, c.r) : mxq_w2_z2(1, c.r)) + g0 * 16];
-        k.qq[1] = *(const f32x2*)(blk + mxq_qq(1) + g0 * 2);
+        k.c[1] = blk[(MIXED ? mxq_c2(1, c.r) : mxq_w2_c2(1, c.r)) + g0 * 16];
+        k.z[1] = zero_of(g0 + 1);
+        k.qq[1] = *(const f32x2*)(blk + QQ0 + g0 * 2 + 2);
     } else {
         k.c[2] = blk[mxq_c4(0, c.r)];
         k.c[3] = blk[mxq_c4(1, c.r)];
@@ -518,7 +528,7 @@ __device__ __forceinline__ void dequant_pk(const Deq& c, int t, const Pk& k) {
 template <int LAYOUT>
 __device__ __forceinline__ void deq_setup(Deq& c, char* smem, int wave, int lane, const uint32_t* __restrict__ qweight,
                                           int N, int K, int n0, int kt0, int nsteps) {
-    constexpr int BLK_B = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : MXQ_BLK_BYTES;
+    constexpr int BLK_B = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : LAYOUT == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
     const int NT_tile = K / BK;
     c.smem = smem;
     c.d = wave - N_MMA;
@@ -812,6 +822,7 @@ int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* 
         case MXQ_LAYOUT_MIXED: return launch8<0, MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
         case MXQ_LAYOUT_W2G16: return launch8<0, MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
         case MXQ_LAYOUT_W4ROW: return launch8<0, MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
+        case MXQ_LAYOUT_MIXEDC: return launch8<0, MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
     }
     return -1;
 }

@@ -55,9 +55,11 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     const int NC = K / 64, NC4 = (NC + 3) / 4;
 
     // packed operands of one (row, chunk): 13 registers (mixed layout), loaded straight from HBM
-    constexpr int NG2 = LAYOUT == MXQ_LAYOUT_MIXED ? 3 : LAYOUT == MXQ_LAYOUT_W2G16 ? 4 : 0;   // two-bit groups per chunk
-    constexpr int NW4 = LAYOUT == MXQ_LAYOUT_MIXED ? 2 : LAYOUT == MXQ_LAYOUT_W4ROW ? 8 : 0;   // four-bit code words per chunk
-    constexpr int BLK_DW = LAYOUT == MXQ_LAYOUT_W4ROW ? 128 : MXQ_BLK_DW;
+    constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC;   // exact / compact metadata
+    constexpr bool COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
+    constexpr int NG2 = MIXED ? 3 : LAYOUT == MXQ_LAYOUT_W2G16 ? 4 : 0;   // two-bit groups per chunk
+    constexpr int NW4 = MIXED ? 2 : LAYOUT == MXQ_LAYOUT_W4ROW ? 8 : 0;   // four-bit code words per chunk
+    constexpr int BLK_DW = LAYOUT == MXQ_LAYOUT_W4ROW ? 128 : COMPACT ? MXQC_BLK_DW : MXQ_BLK_DW;
     struct Tile {
         uint32_t c2w[NG2 ? NG2 : 1], z2w[NG2 ? NG2 : 1], c4w[NW4 ? NW4 : 1], scw;
         uint2 qq[NG2 ? NG2 : 1];
@@ -76,15 +78,20 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
             } else {
 #pragma unroll
                 for (int g = 0; g < NG2; ++g) {
-                    t.c2w[g] = tile[LAYOUT == MXQ_LAYOUT_MIXED ? mxq_c2(g, r) : mxq_w2_c2(g, r)];
-                    t.z2w[g] = tile[LAYOUT == MXQ_LAYOUT_MIXED ? mxq_z2(g, r) : mxq_w2_z2(g, r)];
-                    t.qq[g] = *(const uint2*)(tile + mxq_qq(g));      // SC / QQ sit at the same offsets in both layouts
+                    t.c2w[g] = tile[MIXED ? mxq_c2(g, r) : mxq_w2_c2(g, r)];
+                    if constexpr (COMPACT) {   // fp16 zero-point, widened once here (the arithmetic below is fp32 either way)
+                        const uint16_t zh = ((const uint16_t*)tile)[mxqc_z2_u16(g, r)];
+                        t.z2w[g] = __float_as_uint((float)__builtin_bit_cast(_Float16, zh));
+                    } else {
+                        t.z2w[g] = tile[MIXED ? mxq_z2(g, r) : mxq_w2_z2(g, r)];
+                    }
+                    t.qq[g] = *(const uint2*)(tile + (COMPACT ? mxqc_qq(g) : mxq_qq(g)));   // SC / QQ: same offsets in v1 and W2G16
                 }
-                if constexpr (LAYOUT == MXQ_LAYOUT_MIXED) {
+                if constexpr (MIXED) {
                     t.c4w[0] = tile[mxq_c4(0, r)];
                     t.c4w[1] = tile[mxq_c4(1, r)];
                 }
-                t.scw = ((const uint16_t*)tile)[mxq_sc_u16(r)];
+                t.scw = ((const uint16_t*)tile)[COMPACT ? mxqc_sc_u16(r) : mxq_sc_u16(r)];
             }
         }
         return t;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
             }
 #pragma unroll
             for (int q = 0; q < NW4 / 2; ++q) {      // 16 four-bit weights per pair of code words
-                constexpr int X0 = LAYOUT == MXQ_LAYOUT_MIXED ? 96 : 0;   // the mixed layout's quarter is the chunk's last
+                constexpr int X0 = MIXED ? 96 : 0;   // the mixed layout's quarter is the chunk's last
                 mxq_deq4x8(cur.c4w[2 * q], s4, z4, o);
                 mxq_deq4x8(cur.c4w[2 * q + 1], s4, z4, o + 4);
 #pragma unroll
@@ -256,24 +263,32 @@ int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* r
         case MXQ_LAYOUT_MIXED: return launch_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, stream);
         case MXQ_LAYOUT_W2G16: return launch_layout<MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, stream);
         case MXQ_LAYOUT_W4ROW: return launch_layout<MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_MIXEDC: return launch_layout<MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, stream);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+template <int LAYOUT>
+static int fused_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K, int prologue,
+                        const void* norm_w, float eps, const void* residual, hipStream_t stream) {
+    const bool big = N / 16 > 384;
+    switch (prologue) {
+        case 0:
+            return big ? launch_t<1, 512, 0, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
+                       : launch_t<1, 1024, 0, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
+        case 1:
+            return big ? launch_t<1, 512, 1, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
+                       : launch_t<1, 1024, 1, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
+        case 2:
+            return big ? launch_t<1, 512, 2, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
+                       : launch_t<1, 1024, 2, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
     }
     return (int)hipErrorInvalidValue;
 }
 
 int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
-                              int prologue, const void* norm_w, float eps, const void* residual,
+                              int prologue, const void* norm_w, float eps, const void* residual, int compact,
                               hipStream_t stream) {
-    const bool big = N / 16 > 384;
-    switch (prologue) {
-        case 0:
-            return big ? launch_t<1, 512, 0>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
-                       : launch_t<1, 1024, 0>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
-        case 1:
-            return big ? launch_t<1, 512, 1>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
-                       : launch_t<1, 1024, 1>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
-        case 2:
-            return big ? launch_t<1, 512, 2>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
-                       : launch_t<1, 1024, 2>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
-    }
-    return (int)hipErrorInvalidValue;
+    return compact ? fused_layout<MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual, stream)
+                   : fused_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual, stream);
 }

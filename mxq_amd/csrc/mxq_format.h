@@ -73,7 +73,56 @@ MXQ_HD int mxq_qq(int g) { return MXQ_OFF_QQ + g * 2; }
 #define MXQ_LAYOUT_MIXED 0
 #define MXQ_LAYOUT_W2G16 1
 #define MXQ_LAYOUT_W4ROW 2
-MXQ_HD int mxq_layout_blk_dw(int layout) { return layout == MXQ_LAYOUT_W4ROW ? 128 : 144; }
+#define MXQ_LAYOUT_MIXEDC 3   /* the mixed layout with COMPACT metadata, see below */
+
+// Compact metadata mode of the mixed layout ("format v2", SURVEY.md H2 / BASELINE.md section 3): the same codes,
+// scale codes and (qs, qz), but the 2-bit zero-points stored as fp16 instead of fp32.  Block = 120 dwords = 480 B
+// (3.75 bit/weight + rowmeta instead of 4.5):
+//   C2  [g:3][r:16] u32  @ dword   0     (as in v1)
+//   C4  [h:2][r:16] u32  @ dword  48     (as in v1)
+//   Z2H [g:3][r:16] f16  @ dword  80     fp16(zero-point), round-to-nearest-even
+//   SC  [r:16]      u16  @ dword 104
+//   QQ  [g:4][2]    f32  @ dword 112     slot 3 unused
+// The integer codes are those of the exact quantiser (computed with the fp32 zero-point), so the unpack stays
+// bit-exact on them; the dequantised weight is fp16(scale * (q - float(fp16(zero)))), which costs ~4.4e-4 of the
+// 1e-3 GEMM budget.  The 4-bit arm's per-row parameters (rowmeta) stay fp32.
+#define MXQC_BLK_DW 120
+#define MXQC_BLK_BYTES 480
+#define MXQC_OFF_Z2H 80   /* dword offset; the field is f16[3][16] */
+#define MXQC_OFF_SC 104   /* dword offset; the field is u16[16] */
+#define MXQC_OFF_QQ 112
+MXQ_HD int mxqc_z2_u16(int g, int r) { return MXQC_OFF_Z2H * 2 + g * 16 + r; }   // u16 index
+MXQ_HD int mxqc_sc_u16(int r) { return MXQC_OFF_SC * 2 + r; }                    // u16 index
+MXQ_HD int mxqc_qq(int g) { return MXQC_OFF_QQ + g * 2; }
+
+MXQ_HD int mxq_layout_blk_dw(int layout) {
+    return layout == MXQ_LAYOUT_W4ROW ? 128 : layout == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_DW : 144;
+}
+MXQ_HD bool mxq_layout_is_mixed(int layout) { return layout == MXQ_LAYOUT_MIXED || layout == MXQ_LAYOUT_MIXEDC; }
+
+#if defined(__HIPCC__) || defined(MXQ_HOST_HALF)
+// Field access of the two metadata modes of the mixed layout behind one interface (C2 / C4 sit at the same
+// offsets in both): zero-point as float, the row's scale-code word, the (qs, qz) dword offset.
+template <bool COMPACT>
+struct MxqMixed {
+    static constexpr int BLK_DW = COMPACT ? MXQC_BLK_DW : MXQ_BLK_DW;
+    static constexpr int BLK_BYTES = BLK_DW * 4;
+    static MXQ_HD uint32_t scw(const uint32_t* tile, int r) {
+        return ((const uint16_t*)tile)[COMPACT ? mxqc_sc_u16(r) : mxq_sc_u16(r)];
+    }
+    static MXQ_HD int qq(int g) { return COMPACT ? mxqc_qq(g) : mxq_qq(g); }
+#if defined(__HIPCC__)
+    static __device__ __forceinline__ float z2(const uint32_t* tile, int g, int r) {
+        if constexpr (COMPACT) {
+            const uint16_t h = ((const uint16_t*)tile)[mxqc_z2_u16(g, r)];
+            return (float)__builtin_bit_cast(_Float16, h);
+        } else {
+            return __builtin_bit_cast(float, tile[mxq_z2(g, r)]);
+        }
+    }
+#endif
+};
+#endif
 MXQ_HD int mxq_w2_c2(int g, int r) { return g * 16 + r; }
 MXQ_HD int mxq_w2_z2(int g, int r) { return 64 + g * 16 + r; }
 MXQ_HD int mxq_w4_c4(int q, int h, int r) { return (q * 2 + h) * 16 + r; }

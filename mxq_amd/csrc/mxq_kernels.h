@@ -15,8 +15,10 @@ int mxq_launch_pack_codes(const uint8_t* codes2, const uint8_t* sc2, const float
                           hipStream_t stream);
 int mxq_launch_unpack(const void* qweight, const void* rowmeta, uint8_t* codes2, uint8_t* sc2, float* zero2,
                       float* qs2, float* qz2, uint8_t* codes4, uint8_t* sc4, float* zero4, float* qs4, float* qz4,
-                      int N, int K, hipStream_t stream);
-int mxq_launch_dequant_f16(const void* qweight, const void* rowmeta, void* out, int N, int K, hipStream_t stream);
+                      int N, int K, int compact, hipStream_t stream);   // compact: the qweight is in MXQ_LAYOUT_MIXEDC
+int mxq_launch_dequant_f16(const void* qweight, const void* rowmeta, void* out, int N, int K, int compact,
+                           hipStream_t stream);
+int mxq_launch_compact(const void* qweight_exact, void* qweight_compact, int N, int K, hipStream_t stream);
 int mxq_launch_quantize_pack(const void* W, int dtype, const uint8_t* dead, void* qweight, void* rowmeta, int N,
                              int K, hipStream_t stream);
 int mxq_launch_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -31,6 +33,9 @@ int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* 
                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream);
+// skinny MFMA kernel, 1 <= M <= 32 (skinny.hip); layout MXQ_LAYOUT_MIXED or MXQ_LAYOUT_MIXEDC
+int mxq_launch_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                          int layout, hipStream_t stream);
 // v2 GEMV (gemv2.hip): 16-byte weight loads, M <= 8; teams: 0 = auto, else waves / 4 per workgroup (1, 2, 4)
 int mxq_launch_gemv2_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          int layout, int teams, hipStream_t stream);
@@ -44,7 +49,7 @@ int mxq_launch_quantize_uniform(const void* W, int dtype, void* qweight, void* r
 int mxq_launch_uniform_expand(const void* qweight, const void* rowmeta, void* w16, uint8_t* codes, uint8_t* sc,
                               float* zero, float* qs, float* qz, int N, int K, int layout, hipStream_t stream);
 int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
-                              int prologue, const void* norm_w, float eps, const void* residual,
+                              int prologue, const void* norm_w, float eps, const void* residual, int compact,
                               hipStream_t stream);
 int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                                const void* sin_t, void* out, int heads, int head_dim, int max_ctx,

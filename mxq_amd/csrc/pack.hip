@@ -37,6 +37,7 @@ __global__ void mxq_pack_codes_kernel(const uint8_t* __restrict__ codes2, const 
     if (c == 0) rowmeta[n] = make_float4(zero4[n], (float)sc4[n], qs4[n / 16], qz4[n / 16]);
 }
 
+template <bool COMPACT>
 __global__ void mxq_unpack_kernel(const uint32_t* __restrict__ qweight, const float4* __restrict__ rowmeta,
                                   uint8_t* __restrict__ codes2, uint8_t* __restrict__ sc2, float* __restrict__ zero2,
                                   float* __restrict__ qs2, float* __restrict__ qz2, uint8_t* __restrict__ codes4,
@@ -46,14 +47,31 @@ __global__ void mxq_unpack_kernel(const uint32_t* __restrict__ qweight, const fl
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)N * NC) return;
     const int n = (int)(idx / NC), c = (int)(idx % NC);
-    const uint32_t* tile = qweight + mxq_blk_index(n, c, K) * MXQ_BLK_DW;
+    typedef MxqMixed<COMPACT> F;
+    const uint32_t* tile = qweight + mxq_blk_index(n, c, K) * F::BLK_DW;
     const int r = n & 15;
-    mxq_unpack_row_chunk(tile, r, codes2 + (int64_t)n * NC * 48 + c * 48, sc2 + (int64_t)n * NC * 3 + c * 3,
-                         zero2 + (int64_t)n * NC * 3 + c * 3, codes4 + (int64_t)n * NC * 16 + c * 16);
+    if constexpr (!COMPACT) {
+        mxq_unpack_row_chunk(tile, r, codes2 + (int64_t)n * NC * 48 + c * 48, sc2 + (int64_t)n * NC * 3 + c * 3,
+                             zero2 + (int64_t)n * NC * 3 + c * 3, codes4 + (int64_t)n * NC * 16 + c * 16);
+    } else {   // same code words; zero-points widened from fp16, scale codes from the compact SC field
+        uint8_t* c2 = codes2 + (int64_t)n * NC * 48 + c * 48;
+        uint8_t* c4 = codes4 + (int64_t)n * NC * 16 + c * 16;
+        const uint32_t scw = F::scw(tile, r);
+        for (int g = 0; g < 3; ++g) {
+            const uint32_t w = tile[mxq_c2(g, r)];
+            for (int k = 0; k < 16; ++k) c2[g * 16 + k] = (uint8_t)mxq_code2(w, k);
+            zero2[(int64_t)n * NC * 3 + c * 3 + g] = F::z2(tile, g, r);
+            sc2[(int64_t)n * NC * 3 + c * 3 + g] = (uint8_t)((scw >> (4 * g)) & 15u);
+        }
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t w = tile[mxq_c4(h, r)];
+            for (int k = 0; k < 8; ++k) c4[h * 8 + k] = (uint8_t)mxq_code4(w, k);
+        }
+    }
     if (r == 0) {
         for (int g = 0; g < 3; ++g) {
-            qs2[(int64_t)(n / 16) * NC * 3 + c * 3 + g] = __uint_as_float(tile[mxq_qq(g)]);
-            qz2[(int64_t)(n / 16) * NC * 3 + c * 3 + g] = __uint_as_float(tile[mxq_qq(g) + 1]);
+            qs2[(int64_t)(n / 16) * NC * 3 + c * 3 + g] = __uint_as_float(tile[F::qq(g)]);
+            qz2[(int64_t)(n / 16) * NC * 3 + c * 3 + g] = __uint_as_float(tile[F::qq(g) + 1]);
         }
     }
     if (c == 0) {
@@ -72,6 +90,7 @@ __global__ void mxq_unpack_kernel(const uint32_t* __restrict__ qweight, const fl
 // One thread per (row, chunk quarter): 16 weights = 32 B.  Block = 256 threads covers
 // 16 rows x 4 chunks: thread -> (quarter, chunk slot, r).
 // ------------------------------------------------------------------------------------ //
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void mxq_dequant_f16_kernel(const uint32_t* __restrict__ qweight,
                                                               const float4* __restrict__ rowmeta,
                                                               uint16_t* __restrict__ out, int N, int K) {
@@ -81,13 +100,14 @@ __global__ __launch_bounds__(256) void mxq_dequant_f16_kernel(const uint32_t* __
     const int r = t & 15, cs = (t >> 4) & 3, qt = t >> 6;   // qt wave-uniform
     const int n = rb * 16 + r, c = c4 * 4 + cs;
     if (c >= NC) return;
-    const uint32_t* tile = qweight + ((int64_t)rb * NC + c) * MXQ_BLK_DW;
+    typedef MxqMixed<COMPACT> F;
+    const uint32_t* tile = qweight + ((int64_t)rb * NC + c) * F::BLK_DW;
     uint32_t o[8];
     if (qt < 3) {
         const uint32_t d = tile[mxq_c2(qt, r)];
-        const float z = __uint_as_float(tile[mxq_z2(qt, r)]);
-        const uint32_t scw = ((const uint16_t*)tile)[mxq_sc_u16(r)];
-        const float qs = __uint_as_float(tile[mxq_qq(qt)]), qz = __uint_as_float(tile[mxq_qq(qt) + 1]);
+        const float z = F::z2(tile, qt, r);
+        const uint32_t scw = F::scw(tile, r);
+        const float qs = __uint_as_float(tile[F::qq(qt)]), qz = __uint_as_float(tile[F::qq(qt) + 1]);
         mxq_deq2x16(d, mxq_scale(qs, qz, (scw >> (4 * qt)) & 15u), z, o);
     } else {
         const float4 m = rowmeta[n];
@@ -382,6 +402,28 @@ __global__ __launch_bounds__(256) void mxq_uniform_expand_kernel(const uint32_t*
 }
 
 // ------------------------------------------------------------------------------------ //
+// exact (v1, 576-B blocks) -> compact (480-B blocks) metadata: a byte shuffle plus one fp16 rounding
+// per 2-bit zero-point.  One thread per dword of the compact block; utility kernel, not on the timed path.
+// ------------------------------------------------------------------------------------ //
+__global__ __launch_bounds__(128) void mxq_compact_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                          int64_t blocks) {
+    const int64_t b = blockIdx.x;
+    const int t = threadIdx.x;
+    if (b >= blocks || t >= MXQC_BLK_DW) return;
+    const uint32_t* s = src + b * MXQ_BLK_DW;
+    uint32_t v;
+    if (t < MXQ_OFF_Z2) v = s[t];                                   // C2, C4: verbatim
+    else if (t < MXQC_OFF_SC) {                                     // Z2H: two fp16 zero-points per dword
+        const int i = (t - MXQC_OFF_Z2H) * 2;                       // index into [g][r] (48 entries)
+        const _Float16 h0 = (_Float16)__uint_as_float(s[MXQ_OFF_Z2 + i]);
+        const _Float16 h1 = (_Float16)__uint_as_float(s[MXQ_OFF_Z2 + i + 1]);
+        v = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+    } else if (t < MXQC_OFF_QQ) v = s[MXQ_OFF_SC + (t - MXQC_OFF_SC)];
+    else v = s[MXQ_OFF_QQ + (t - MXQC_OFF_QQ)];
+    dst[b * MXQC_BLK_DW + t] = v;
+}
+
+// ------------------------------------------------------------------------------------ //
 // launchers
 // ------------------------------------------------------------------------------------ //
 int mxq_launch_pack_codes(const uint8_t* codes2, const uint8_t* sc2, const float* zero2, const float* qs2,
@@ -397,18 +439,35 @@ int mxq_launch_pack_codes(const uint8_t* codes2, const uint8_t* sc2, const float
 
 int mxq_launch_unpack(const void* qweight, const void* rowmeta, uint8_t* codes2, uint8_t* sc2, float* zero2,
                       float* qs2, float* qz2, uint8_t* codes4, uint8_t* sc4, float* zero4, float* qs4, float* qz4,
-                      int N, int K, hipStream_t stream) {
+                      int N, int K, int compact, hipStream_t stream) {
     const int64_t total = (int64_t)N * (K / 64);
-    mxq_unpack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(
-        (const uint32_t*)qweight, (const float4*)rowmeta, codes2, sc2, zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4,
-        N, K);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (compact)
+        mxq_unpack_kernel<true><<<grid, 256, 0, stream>>>((const uint32_t*)qweight, (const float4*)rowmeta, codes2, sc2,
+                                                          zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4, N, K);
+    else
+        mxq_unpack_kernel<false><<<grid, 256, 0, stream>>>((const uint32_t*)qweight, (const float4*)rowmeta, codes2, sc2,
+                                                           zero2, qs2, qz2, codes4, sc4, zero4, qs4, qz4, N, K);
     return (int)hipGetLastError();
 }
 
-int mxq_launch_dequant_f16(const void* qweight, const void* rowmeta, void* out, int N, int K, hipStream_t stream) {
+int mxq_launch_dequant_f16(const void* qweight, const void* rowmeta, void* out, int N, int K, int compact,
+                           hipStream_t stream) {
     const unsigned grid = (unsigned)((N / 16) * ((K / 64 + 3) / 4));
-    mxq_dequant_f16_kernel<<<grid, 256, 0, stream>>>((const uint32_t*)qweight, (const float4*)rowmeta,
-                                                     (uint16_t*)out, N, K);
+    if (compact)
+        mxq_dequant_f16_kernel<true><<<grid, 256, 0, stream>>>((const uint32_t*)qweight, (const float4*)rowmeta,
+                                                               (uint16_t*)out, N, K);
+    else
+        mxq_dequant_f16_kernel<false><<<grid, 256, 0, stream>>>((const uint32_t*)qweight, (const float4*)rowmeta,
+                                                                (uint16_t*)out, N, K);
+    return (int)hipGetLastError();
+}
+
+int mxq_launch_compact(const void* qweight_exact, void* qweight_compact, int N, int K, hipStream_t stream) {
+    const int64_t blocks = (int64_t)(N / 16) * (K / 64);
+    if (blocks >= ((int64_t)1 << 31)) return (int)hipErrorInvalidValue;
+    mxq_compact_kernel<<<(unsigned)blocks, 128, 0, stream>>>((const uint32_t*)qweight_exact, (uint32_t*)qweight_compact,
+                                                             blocks);
     return (int)hipGetLastError();
 }
 

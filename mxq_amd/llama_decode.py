@@ -53,10 +53,11 @@ class ContextWindow:
 
 class DecodeStage:
     def __init__(self, layers, dev, max_ctx: int = 512, hidden: int = LS.HIDDEN, inter: int = LS.INTERMEDIATE,
-                 heads: int = 32, first: bool = True, last: bool = True, vocab: int = 32000, fused: bool = True):
+                 heads: int = 32, first: bool = True, last: bool = True, vocab: int = 32000, fused: bool = True,
+                 compact: bool = False):
         self.layers, self.dev, self.max_ctx = list(layers), dev, max_ctx
         self.hidden, self.inter, self.heads, self.hd = hidden, inter, heads, hidden // heads
-        self.first, self.last = first, last
+        self.first, self.last, self.compact = first, last, compact
         # fused: RMSNorm / SwiGLU / residual folded into the GEMV launches and one RoPE + cache-append
         # + attention kernel per layer (5 launches per layer); otherwise plain torch ops around 4 GEMVs
         self.fused = fused and self.hd == 128
@@ -65,7 +66,7 @@ class DecodeStage:
             def mk(idx, N, K):
                 g = torch.Generator(device=dev).manual_seed(1000 * li + idx)
                 W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
-                return packing.quantize_pack(W)
+                return packing.quantize_pack(W, compact_meta=compact)     # compact: fp16 zero-points, 3.75 bit/weight
             qkv = _concat_packed([mk(0, hidden, hidden), mk(1, hidden, hidden), mk(2, hidden, hidden)])
             o = mk(3, hidden, hidden)
             gu = _concat_packed([mk(4, inter, hidden), mk(5, inter, hidden)])

@@ -85,11 +85,13 @@ def qweight_bytes(N: int, K: int) -> int:
 
 @dataclass
 class PackedMXQ:
-    """qweight: int32 [N/16 * K/64 * 144] (576-B blocks); rowmeta: float32 [N, 4]."""
+    """qweight: int32 [N/16 * K/64 * 144] (576-B blocks, exact metadata) or [N/16 * K/64 * 120] (480-B blocks,
+    ``compact``: fp16 zero-points, csrc/mxq_format.h MXQ_LAYOUT_MIXEDC); rowmeta: float32 [N, 4]."""
     qweight: torch.Tensor
     rowmeta: torch.Tensor
     N: int
     K: int
+    compact: bool = False
 
     @property
     def device(self):
@@ -107,10 +109,26 @@ def concat_packed(ps) -> PackedMXQ:
     row-block-major, so this is a plain concatenation of the block arrays and of the row metadata, and one
     launch then computes all the stacked Linears of a shared input."""
     ps = list(ps)
-    if not ps or any(p.K != ps[0].K for p in ps):
-        raise ValueError("concat_packed needs packed weights with the same in_features")
+    if not ps or any(p.K != ps[0].K or p.compact != ps[0].compact for p in ps):
+        raise ValueError("concat_packed needs packed weights with the same in_features and metadata mode")
     return PackedMXQ(torch.cat([p.qweight for p in ps]), torch.cat([p.rowmeta for p in ps]),
-                     sum(p.N for p in ps), ps[0].K)
+                     sum(p.N for p in ps), ps[0].K, ps[0].compact)
+
+
+def compact(p: PackedMXQ) -> PackedMXQ:
+    """Exact -> compact metadata (format "v2": the 2-bit zero-points as fp16; 3.75 instead of 4.5 bit/weight).  The
+    integer codes, scale codes and (qs, qz) are unchanged, so ``unpack`` stays bit-exact on them; the dequantised
+    weight moves by at most the fp16 rounding of a zero-point times its scale, the GEMM result by ~4e-4 relative
+    (inside the 1e-3 budget: tests).  ``rowmeta`` is shared with ``p``."""
+    if p.compact:
+        return p
+    _need_gpu(p.qweight)
+    lib = _lib.load()
+    nbytes = lib.mxq_qweight_bytes_layout(p.N, p.K, 3)
+    q = torch.empty(nbytes // 4, dtype=torch.int32, device=p.device)
+    with torch.cuda.device(p.device):
+        _lib.check(lib.mxq_compact(p.qweight.data_ptr(), q.data_ptr(), p.N, p.K, _stream(q)), "mxq_compact")
+    return PackedMXQ(q, p.rowmeta, p.N, p.K, True)
 
 
 def _alloc(N: int, K: int, device) -> PackedMXQ:
@@ -121,8 +139,9 @@ def _alloc(N: int, K: int, device) -> PackedMXQ:
                      torch.empty((N, 4), dtype=torch.float32, device=device), N, K)
 
 
-def quantize_pack(W: torch.Tensor, dead: Optional[torch.Tensor] = None) -> PackedMXQ:
-    """MXQ-quantise W [N, K] (fp16 / bf16 / fp32) on device and return the packed form."""
+def quantize_pack(W: torch.Tensor, dead: Optional[torch.Tensor] = None, compact_meta: bool = False) -> PackedMXQ:
+    """MXQ-quantise W [N, K] (fp16 / bf16 / fp32) on device and return the packed form (``compact_meta``: in the
+    compact metadata mode, see ``compact``)."""
     _need_gpu(W, dead)
     if W.dim() != 2:
         raise ValueError("weight must be 2-D [out_features, in_features]")
@@ -142,7 +161,7 @@ def quantize_pack(W: torch.Tensor, dead: Optional[torch.Tensor] = None) -> Packe
     with torch.cuda.device(W.device):
         _lib.check(lib.mxq_quantize_pack(W.data_ptr(), _TORCH2CODE[W.dtype], dead_p, p.qweight.data_ptr(),
                                          p.rowmeta.data_ptr(), N, K, _stream(W)), "mxq_quantize_pack")
-    return p
+    return compact(p) if compact_meta else p
 
 
 def _param_shapes(N: int, K: int) -> Dict[str, tuple]:
@@ -178,9 +197,10 @@ def unpack(p: PackedMXQ) -> Dict[str, torch.Tensor]:
     _need_gpu(p.qweight)
     out = {k: torch.empty(shape, dtype=dt, device=p.device) for k, (shape, dt) in _param_shapes(p.N, p.K).items()}
     lib = _lib.load()
+    fn = lib.mxq_unpack_compact if p.compact else lib.mxq_unpack
     with torch.cuda.device(p.device):
-        _lib.check(lib.mxq_unpack(p.qweight.data_ptr(), p.rowmeta.data_ptr(), *[out[k].data_ptr() for k in PARAM_KEYS],
-                                  p.N, p.K, _stream(p.qweight)), "mxq_unpack")
+        _lib.check(fn(p.qweight.data_ptr(), p.rowmeta.data_ptr(), *[out[k].data_ptr() for k in PARAM_KEYS],
+                      p.N, p.K, _stream(p.qweight)), "mxq_unpack")
     return out
 
 
@@ -189,9 +209,10 @@ def dequant(p: PackedMXQ) -> torch.Tensor:
     _need_gpu(p.qweight)
     out = torch.empty((p.N, p.K), dtype=torch.float16, device=p.device)
     lib = _lib.load()
+    fn = lib.mxq_dequant_f16_compact if p.compact else lib.mxq_dequant_f16
     with torch.cuda.device(p.device):
-        _lib.check(lib.mxq_dequant_f16(p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), p.N, p.K,
-                                       _stream(out)), "mxq_dequant_f16")
+        _lib.check(fn(p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), p.N, p.K, _stream(out)),
+                   "mxq_dequant_f16")
     return out
 
 
@@ -201,7 +222,8 @@ GEMM_PATHS = {"gemm": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9}   # include/mxq_hip
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
     """y = x @ dequant(p).T for x [..., K] fp16 -> [..., N] fp16 (fp32 accumulation).
 
-    path: "auto" (GEMV kernel for <= 4 tokens, MFMA GEMM otherwise), "gemm", "gemv", or an explicit GEMM
+    path: "auto" (GEMV kernel for <= 4 tokens, skinny MFMA kernel for 5..32, prefill GEMM beyond), "gemm", "gemv",
+    "skinny" (1..32 tokens), or an explicit GEMM
     kernel: "gemm1" (128x128 tile), "gemm8" (256x128 tile, wave-specialised, persistent, stream-K tail), "gemm9"
     (gemm8 splitting its tail whenever that is structurally possible: tests)."""
     _need_gpu(x, p.qweight)
@@ -221,6 +243,17 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         return out.reshape(*x.shape[:-1], p.N)
     lib = _lib.load()
     args = (x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K)
+    if path == "skinny" or (p.compact and path == "auto" and 4 < M <= 32):
+        with torch.cuda.device(x.device):
+            _lib.check(lib.mxq_skinny_f16(*args, 3 if p.compact else 0, _stream(x2)), "mxq_skinny_f16")
+        return out.reshape(*x.shape[:-1], p.N)
+    if p.compact:      # compact metadata: the layout entry points (same kernels, other field offsets)
+        if path not in ("auto", "gemm", "gemv", "gemm8"):
+            raise ValueError(f"path {path!r} is not available for compact metadata")
+        with torch.cuda.device(x.device):
+            fn = lib.mxq_gemv_f16_layout if path == "gemv" or (path == "auto" and M <= 4) else lib.mxq_gemm_f16_layout
+            _lib.check(fn(*args, 3, _stream(x2)), f"mxq_linear_f16[{path}, compact]")
+        return out.reshape(*x.shape[:-1], p.N)
     with torch.cuda.device(x.device):
         if path == "gemv":
             rc = lib.mxq_gemv_f16(*args, _stream(x2))
@@ -255,11 +288,12 @@ def linear_fused(x: torch.Tensor, p: PackedMXQ, prologue: int = 0, norm_w: Optio
     x = x.contiguous()
     out = torch.empty((1, p.N), dtype=torch.float16, device=x.device)
     lib = _lib.load()
+    fused = lib.mxq_gemv_fused_f16_compact if p.compact else lib.mxq_gemv_fused_f16
     with torch.cuda.device(x.device):
-        _lib.check(lib.mxq_gemv_fused_f16(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(),
-                                          p.N, p.K, int(prologue), norm_w.data_ptr() if norm_w is not None else None,
-                                          float(eps), residual.contiguous().data_ptr() if residual is not None else None,
-                                          _stream(x)), "mxq_gemv_fused_f16")
+        _lib.check(fused(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(),
+                         p.N, p.K, int(prologue), norm_w.data_ptr() if norm_w is not None else None,
+                         float(eps), residual.contiguous().data_ptr() if residual is not None else None,
+                         _stream(x)), "mxq_gemv_fused_f16")
     return out
 
 

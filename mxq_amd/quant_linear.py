@@ -6,7 +6,8 @@ around its CUDA prototype; this is the module the name
 ``QuantLinear`` in BASELINE.json maps to on the inference side.  ``nas_quant``
 (mxq_quant/lib/prune.py:409-414) can swap it in after ``MXQGPT.fasterquant``.
 
-state_dict: ``qweight`` int32 [N/16 * K/64 * 144], ``rowmeta`` float32 [N, 4],
+state_dict: ``qweight`` int32 [N/16 * K/64 * 144] (format version 1, exact metadata) or [N/16 * K/64 * 120]
+(version 2, compact metadata: fp16 zero-points, 3.75 bit/weight), ``rowmeta`` float32 [N, 4],
 ``fmt`` int32 [3] = (format version, N, K), optional ``bias`` float16 [N].
 """
 from __future__ import annotations
@@ -20,14 +21,15 @@ from . import packing
 
 
 class QuantLinear(nn.Module):
-    def __init__(self, in_features: int, out_features: int, bias: bool = False, device=None):
+    def __init__(self, in_features: int, out_features: int, bias: bool = False, device=None, compact: bool = False):
         super().__init__()
         packing.check_shape(out_features, in_features)
-        self.in_features, self.out_features = in_features, out_features
-        nq = packing.qweight_bytes(out_features, in_features) // 4
+        self.in_features, self.out_features, self.compact = in_features, out_features, bool(compact)
+        nq = packing.qweight_bytes(out_features, in_features) // 4 * (120 if compact else 144) // 144
         self.register_buffer("qweight", torch.zeros(nq, dtype=torch.int32, device=device))
         self.register_buffer("rowmeta", torch.zeros((out_features, 4), dtype=torch.float32, device=device))
-        self.register_buffer("fmt", torch.tensor([1, out_features, in_features], dtype=torch.int32, device=device))
+        self.register_buffer("fmt", torch.tensor([2 if compact else 1, out_features, in_features], dtype=torch.int32,
+                                                 device=device))
         if bias:
             self.register_buffer("bias", torch.zeros(out_features, dtype=torch.float16, device=device))
         else:
@@ -36,18 +38,18 @@ class QuantLinear(nn.Module):
     # -- construction -------------------------------------------------------------------
     @classmethod
     def from_packed(cls, p: packing.PackedMXQ, bias: Optional[torch.Tensor] = None) -> "QuantLinear":
-        m = cls(p.K, p.N, bias=bias is not None, device=p.device)
+        m = cls(p.K, p.N, bias=bias is not None, device=p.device, compact=p.compact)
         m.qweight, m.rowmeta = p.qweight, p.rowmeta
         if bias is not None:
             m.bias = bias.detach().to(device=p.device, dtype=torch.float16)
         return m
 
     @classmethod
-    def from_linear(cls, linear: nn.Linear, dead: Optional[torch.Tensor] = None) -> "QuantLinear":
+    def from_linear(cls, linear: nn.Linear, dead: Optional[torch.Tensor] = None, compact: bool = False) -> "QuantLinear":
         """MXQ-quantise ``linear.weight`` (fp16 / bf16 / fp32, on the GPU) and pack it.
         ``dead``: optional bool [in_features] mask of never-activated input channels
-        (diag(H) == 0, mxqgpt.py:401-403)."""
-        p = packing.quantize_pack(linear.weight.data, dead)
+        (diag(H) == 0, mxqgpt.py:401-403).  ``compact``: compact metadata (packing.compact)."""
+        p = packing.quantize_pack(linear.weight.data, dead, compact_meta=compact)
         return cls.from_packed(p, linear.bias.data if linear.bias is not None else None)
 
     @classmethod
@@ -63,7 +65,7 @@ class QuantLinear(nn.Module):
 
     # -- views ----------------------------------------------------------------------------
     def packed(self) -> packing.PackedMXQ:
-        return packing.PackedMXQ(self.qweight, self.rowmeta, self.out_features, self.in_features)
+        return packing.PackedMXQ(self.qweight, self.rowmeta, self.out_features, self.in_features, self.compact)
 
     def dequantize(self) -> torch.Tensor:
         """fp16 [out, in] weight, bit-identical to the reference's fake-quant write-back."""
@@ -77,4 +79,5 @@ class QuantLinear(nn.Module):
 
     def extra_repr(self) -> str:
         return (f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, "
-                f"format=mxq-v1 (48x2b+16x4b per 64), {self.packed().bits_per_weight():.2f} bit/weight")
+                f"format=mxq-v{2 if self.compact else 1} (48x2b+16x4b per 64, {'compact' if self.compact else 'exact'} "
+                f"metadata), {self.packed().bits_per_weight():.2f} bit/weight")

@@ -392,6 +392,59 @@ def test_gemv_vs_oracle(dev, M, N, K):
     _check_gemm(y, O.linear_ref(x.numpy(), w16), f"gemv {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M", [1, 5, 8, 16, 17, 32])
+@pytest.mark.parametrize("N,K", [(64, 256), (256, 704), (4096, 4096), (11008, 4096), (4096, 11008)])
+@pytest.mark.parametrize("compact", [False, True])
+def test_skinny_mfma_vs_oracle(dev, M, N, K, compact):
+    """csrc/skinny.hip (4 < M <= 32, also callable down to 1 token): against the oracle's weight, exact and compact
+    metadata, ragged K (704 = 11 chunks over 16 waves), the three Llama shapes; the automatic dispatch picks it for
+    5..32 tokens; rows agree with the GEMV / GEMM paths to accumulation order."""
+    from mxq_amd import packing
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    W16 = (torch.randn(N, K, generator=g) * 0.02).half()
+    x = torch.randn(M, K, generator=g).half()
+    if N * K <= 256 * 704:
+        ref = O.mxq_quantize(W16.numpy())
+        w16 = O.mxq_dequant(O.mxq_compact_params(ref) if compact else ref).astype(np.float16)
+    else:                                   # Llama shapes: the dequant kernel's weight (bit-exact vs the oracle in other tests)
+        w16 = None
+    p = packing.quantize_pack(W16.to(dev), compact_meta=compact)
+    y = packing.linear(x.to(dev), p, path="skinny")
+    if w16 is None:
+        w16 = packing.dequant(p).cpu().numpy()
+    _check_gemm(y.cpu().numpy(), O.linear_ref(x.numpy(), w16), f"skinny {M}x{N}x{K} compact={compact}")
+    if 4 < M <= 32:
+        assert torch.equal(packing.linear(x.to(dev), p), y), "auto dispatch should be the skinny kernel here"
+    other = packing.linear(x.to(dev), p, path="gemv" if M <= 4 else "gemm").float()
+    assert ((other - y.float()).abs().max() / other.abs().max()).item() <= REL_TOL
+
+
+def test_skinny_integer_exact_and_nonfinite(dev):
+    """Small-integer weights / activations: every partial sum is exact, so a wrong lane -> (row, k) mapping of the
+    register-built MFMA operands shows as an exact mismatch; and a NaN activation poisons its own token only."""
+    from mxq_amd import packing
+    N, K, M = 64, 512, 19
+    rng = np.random.default_rng(11)
+    p = O.mxq_quantize(np.zeros((N, K), np.float16))
+    p["codes2"] = rng.integers(0, 4, (N, K // 64 * 48), dtype=np.uint8)
+    p["codes4"] = rng.integers(0, 16, (N, K // 4), dtype=np.uint8)
+    p["sc2"][:] = 1; p["qs2"][:] = 1.0; p["qz2"][:] = 0.0; p["zero2"][:] = 1.0     # w = q - 1
+    p["sc4"][:] = 1; p["qs4"][:] = 1.0; p["qz4"][:] = 0.0; p["zero4"][:] = 7.0     # w = q - 7
+    w = O.mxq_dequant(p)
+    x = rng.integers(-2, 3, (M, K)).astype(np.float16)
+    pk = packing.pack_codes(_to_dev(p, dev), N, K)
+    yref = x.astype(np.float32) @ w.T
+    for pp in (pk, packing.compact(pk)):                     # integer zero-points are exact in fp16 too
+        y = packing.linear(torch.from_numpy(x).to(dev), pp, path="skinny").cpu().numpy().astype(np.float32)
+        assert np.array_equal(y, yref)
+    xt = torch.from_numpy(x).to(dev)
+    xt[3, 100] = float("nan")
+    y = packing.linear(xt, pk, path="skinny")
+    assert torch.isnan(y[3]).all() and torch.isfinite(y[[i for i in range(M) if i != 3]]).all()
+    with pytest.raises(ValueError):
+        packing.linear(torch.zeros(33, K, dtype=torch.float16, device=dev), pk, path="skinny")
+
+
 @pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])
 def test_full_size_properties(dev, N, K):
     """BASELINE config 2 shapes (M = 2048).  The oracle is too slow here, so use
@@ -457,6 +510,81 @@ def test_config5_full_size_m32768(dev, layout, N, K):
     for r0 in (0, M - 2048):
         alone = packing.linear_layout(x[r0:r0 + 2048].contiguous(), p)
         assert torch.equal(alone, y[r0:r0 + 2048]), (layout, r0)
+
+
+# ----------------------------------------------------------------------------------------
+# compact metadata mode (format v2: fp16 zero-points, 3.75 bit/weight)
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,K", [(64, 256), (256, 704), (1024, 4096)])
+def test_compact_pack_unpack_dequant(dev, N, K):
+    """Compact blocks: the integer unpack is bit-exact on the codes / scale codes / (qs, qz) of the EXACT quantiser;
+    the zero-points come back as fp16(zero); the dequant kernel is bit-exact against the oracle's restatement of
+    the compact parameter set; 3.75 bit/weight + rowmeta."""
+    from mxq_amd import packing
+    g = torch.Generator().manual_seed(N + K)
+    W16 = (torch.randn(N, K, generator=g) * 0.02).half()
+    ref = O.mxq_quantize(W16.numpy())
+    cref = O.mxq_compact_params(ref)
+    pe = packing.quantize_pack(W16.to(dev))
+    pc = packing.compact(pe)
+    assert pc.compact and pc.qweight.numel() * 4 == (N // 16) * (K // 64) * 480 and packing.compact(pc) is pc
+    assert abs(pc.bits_per_weight() - (3.75 + 128.0 / K)) < 1e-6
+    got = {k: v.cpu().numpy() for k, v in packing.unpack(pc).items()}
+    for k in packing.PARAM_KEYS:
+        assert np.array_equal(got[k], cref[k]), k
+    for k in ("codes2", "codes4", "sc2", "sc4", "qs2", "qz2", "qs4", "qz4", "zero4"):
+        assert np.array_equal(got[k], ref[k]), k                         # untouched by the compaction
+    wc = packing.dequant(pc).cpu().numpy()
+    assert np.array_equal(wc.view(np.uint16), O.mxq_dequant(cref).astype(np.float16).view(np.uint16))
+    # quantize_pack(compact_meta=True) is the same thing in one call
+    assert torch.equal(packing.quantize_pack(W16.to(dev), compact_meta=True).qweight, pc.qweight)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 256), (3, 256, 704), (4, 4096, 4096), (128, 256, 512), (300, 144, 192),
+                                   (2048, 4096, 4096), (2048, 11008, 4096), (2048, 4096, 11008), (1, 4096, 11008)])
+def test_compact_linear_within_budget_of_exact_reference(dev, M, N, K):
+    """GEMM / GEMV on compact blocks against the EXACT reference weight (what the reference's Python path produces):
+    <= 1e-3 in max-norm and Frobenius, the bar of north_star; and against the compact weight itself, where only the
+    accumulation differs."""
+    from mxq_amd import packing
+    g = torch.Generator().manual_seed(M + N + K)
+    W = (torch.randn(N, K, generator=g) * 0.02).half().to(dev)
+    pe = packing.quantize_pack(W)
+    pc = packing.compact(pe)
+    x = torch.randn(M, K, generator=g).half().to(dev)
+    y = packing.linear(x, pc).float()
+    exact = x.float() @ packing.dequant(pe).float().t()
+    own = x.float() @ packing.dequant(pc).float().t()
+    for ref, what in ((exact, "exact reference"), (own, "compact weight")):
+        err_max = ((y - ref).abs().max() / ref.abs().max()).item()
+        err_fro = ((y - ref).norm() / ref.norm()).item()
+        assert err_max <= REL_TOL and err_fro <= REL_TOL, (what, M, N, K, err_max, err_fro)
+    if M <= 4:
+        assert torch.equal(packing.linear(x, pc, path="gemv").float(), y)
+
+
+def test_compact_checkpoint_and_fused_decode(dev, tmp_path):
+    """Compact QuantLinears round-trip through the packed checkpoint (fmt version 2), and the decode stage's fused
+    GEMVs (RMSNorm / SwiGLU / residual) run on compact blocks."""
+    from mxq_amd import checkpoint, packing
+    from mxq_amd.llama_decode import DecodeStage
+    from mxq_amd.quant_linear import QuantLinear
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(256, 128, bias=False), torch.nn.Linear(128, 64, bias=True)).to(dev).half()
+    names = checkpoint.pack_model(model, skip=(), compact=True)
+    assert len(names) == 2 and all(isinstance(m, QuantLinear) and m.compact for m in model)
+    x = torch.randn(5, 256, device=dev).half()
+    y = model(x)
+    checkpoint.save_packed(model, str(tmp_path))
+    fresh = torch.nn.Sequential(torch.nn.Linear(256, 128, bias=False), torch.nn.Linear(128, 64, bias=True)).to(dev).half()
+    checkpoint.load_packed(fresh, str(tmp_path))
+    assert all(m.compact and int(m.fmt[0]) == 2 for m in fresh) and torch.equal(fresh(x), y)
+    st_c = DecodeStage(range(1), dev, max_ctx=8, hidden=256, inter=704, heads=2, vocab=64, compact=True)
+    st_e = DecodeStage(range(1), dev, max_ctx=8, hidden=256, inter=704, heads=2, vocab=64)
+    assert st_c.packed_bytes() < 0.86 * st_e.packed_bytes()
+    h = torch.randn(1, 256, device=dev).half()
+    a, b = st_c.step(h).float(), st_e.step(h).float()
+    assert ((a - b).abs().max() / b.abs().max()).item() < 2e-2          # fp16 activations end to end
 
 
 def test_quantlinear_module(dev):

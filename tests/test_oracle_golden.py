@@ -148,3 +148,19 @@ def test_g9_activation_quantizers_16bit(dt):
         x = torch.from_numpy(g9[key + "_x"].view(np.int16)).view(tdt)
         y = Q.apply(x, clip, int(bits[1:]), bool(int(lw)))
         assert np.array_equal(y.view(torch.int16).numpy().view(np.uint16), g9[key + "_y"]), key
+
+
+def test_compact_metadata_stays_inside_the_gemm_budget():
+    """CPU statement of the compact mode's cost: rounding the 2-bit zero-points to fp16 leaves the
+    codes alone and moves y = x . W'^T by well under the 1e-3 budget against the exact reference weight."""
+    rng = np.random.default_rng(3)
+    W = (rng.standard_normal((256, 1024)) * 0.02).astype(np.float16)
+    p = O.mxq_quantize(W)
+    c = O.mxq_compact_params(p)
+    assert all(np.array_equal(p[k], c[k]) for k in ("codes2", "codes4", "sc2", "sc4")) and not np.array_equal(p["zero2"], c["zero2"])
+    x = rng.standard_normal((64, 1024)).astype(np.float16)
+    y_exact = O.linear_ref(x, O.mxq_dequant(p).astype(np.float16))
+    y_comp = O.linear_ref(x, O.mxq_dequant(c).astype(np.float16))
+    err_fro = np.linalg.norm(y_comp - y_exact) / np.linalg.norm(y_exact)
+    err_max = np.abs(y_comp - y_exact).max() / np.abs(y_exact).max()
+    assert err_fro < 6e-4 and err_max < 8e-4, (err_fro, err_max)
