@@ -231,11 +231,25 @@ int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, i
     return (int)hipGetLastError();
 }
 
+// Workgroup size by row-block count: every workgroup should be resident at once (a second, partial round of
+// workgroups costs a whole workgroup lifetime).  <= 384 row blocks: 16 waves (one workgroup per CU, every load of a
+// K = 4096 row block in flight at once); <= 768: 8 waves (3 per CU at ~68 VGPRs); more (fused gate|up: 1376): 4 waves
+// (7 per CU = 1792 slots), each wave then walks 4+ tiles with the next one's loads in flight.
+__host__ inline int gemv_threads(int N, int forced) {
+    if (forced) return forced;
+    const int rbs = N / 16;
+    return rbs <= 384 ? 1024 : rbs <= 768 ? 512 : 256;
+}
+
 template <int MB, int LAYOUT = MXQ_LAYOUT_MIXED>
-int launch(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream) {
-    if (N / 16 <= 384)
-        return launch_t<MB, 1024, 0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
-    return launch_t<MB, 512, 0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
+int launch(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream,
+           int threads = 0) {
+    switch (gemv_threads(N, threads)) {
+        case 1024: return launch_t<MB, 1024, 0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
+        case 512: return launch_t<MB, 512, 0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
+        case 256: return launch_t<MB, 256, 0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
+    }
+    return (int)hipErrorInvalidValue;
 }
 
 template <int LAYOUT>
@@ -271,18 +285,17 @@ int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* r
 template <int LAYOUT>
 static int fused_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K, int prologue,
                         const void* norm_w, float eps, const void* residual, hipStream_t stream) {
-    const bool big = N / 16 > 384;
+    const int th = gemv_threads(N, 0);
+#define MXQ_FUSED(PRO)                                                                                                   \
+    (th == 1024 ? launch_t<1, 1024, PRO, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)         \
+     : th == 512 ? launch_t<1, 512, PRO, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)         \
+                 : launch_t<1, 256, PRO, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream))
     switch (prologue) {
-        case 0:
-            return big ? launch_t<1, 512, 0, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
-                       : launch_t<1, 1024, 0, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
-        case 1:
-            return big ? launch_t<1, 512, 1, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
-                       : launch_t<1, 1024, 1, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
-        case 2:
-            return big ? launch_t<1, 512, 2, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)
-                       : launch_t<1, 1024, 2, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream);
+        case 0: return MXQ_FUSED(0);
+        case 1: return MXQ_FUSED(1);
+        case 2: return MXQ_FUSED(2);
     }
+#undef MXQ_FUSED
     return (int)hipErrorInvalidValue;
 }
 
@@ -292,3 +305,12 @@ int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* ro
     return compact ? fused_layout<MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual, stream)
                    : fused_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual, stream);
 }
+
+#ifdef MXQ_PROFILING
+// A/B entry for tools/ (correct results): explicit workgroup size (256 / 512 / 1024 threads), M = 1
+extern "C" int mxq_prof_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                 int threads, void* stream) {
+    if (M != 1) return -1;
+    return launch<1>(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream, threads);
+}
+#endif

@@ -35,6 +35,9 @@ def main():
     fn2 = prof.mxq_prof_gemv2_f16
     fn2.restype = ctypes.c_int
     fn2.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    fn1 = prof.mxq_prof_gemv_f16          # v1 kernel with an explicit workgroup size: "v1:256" / "v1:512" / "v1:1024"
+    fn1.restype = ctypes.c_int
+    fn1.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
     variants = args.variants.split(",")
     M = args.m
     report = []
@@ -57,6 +60,16 @@ def main():
                 calls = [(lambda w=w: torch.matmul(x, w.t(), out=out)) for w in wds]
             elif v == "v1":
                 calls = [(lambda p=p: packing.linear(x, p, out=out, path="gemv")) for p in ws]
+            elif v.startswith("v1:"):
+                th = int(v.split(":")[1])
+
+                def mk1(p):
+                    def call():
+                        rc = fn1(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, N, K, th,
+                                 torch.cuda.current_stream().cuda_stream)
+                        assert rc == 0, (v, rc)
+                    return call
+                calls = [mk1(p) for p in ws]
             else:
                 teams = int(v.split(":")[1])
 

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--ctx", type=int, default=512)
     ap.add_argument("--layers", type=int, default=LS.N_LAYERS)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--compact", action="store_true", help="compact metadata mode (fp16 zero-points, 3.75 bit/weight); "
+                                                           "default: exact metadata (4.5 bit/weight)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -38,7 +40,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     pipe = LayerPipeline(rank, world)
     stage = DecodeStage(layer_range(rank, world, args.layers), dev, max_ctx=args.ctx, first=pipe.is_first,
-                        last=pipe.is_last)
+                        last=pipe.is_last, compact=args.compact)
     if not args.no_graph:
         stage.capture()
     hbuf = torch.zeros(1, LS.HIDDEN, device=dev, dtype=torch.float16)
@@ -77,6 +79,7 @@ def main():
                           "tokens_per_s": round(args.tokens / dt, 1), "ms_per_token": round(dt / args.tokens * 1e3, 3),
                           "packed_weight_GB_per_token": round(bytes_tok.item() / 1e9, 3),
                           "weight_stream_GBps": round(bytes_tok.item() / (dt / args.tokens) / 1e9, 1),
+                          "metadata_mode": "compact (fp16 zero-points)" if args.compact else "exact (fp32 zero-points)",
                           "hipgraph": not args.no_graph, "first_tokens": toks[:8]}), flush=True)
     if world > 1:
         dist.barrier()
