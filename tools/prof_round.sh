@@ -1,9 +1,11 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/prof_round.sh <tag>     ->  gpurun_out/<tag>_*  (summarise with tools/prof_summary.py / pmc_summary.py)
-# --pmc passes are separate runs with --kernel-trace only (never combined with the hip/hsa trace domains).
+#   bash tools/prof_round.sh <tag>     ->  gpurun_out/<tag>_*  (summarise with tools/prof_summary.py / pmc_summary.py /
+#   traffic_json.py here afterwards, copy the summaries into profiles/)
+# --pmc passes are separate runs with --kernel-trace only (never combined with the hip/hsa trace domains); the
+# program itself follows "--" (no env / bash -c hop: the profiler's library has initialised the GPU by then).
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 export TMPDIR=/tmp
@@ -17,9 +19,21 @@ for shape in "4096 4096" "11008 4096" "4096 11008"; do
   done
   echo "traffic $1x$2 done"
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/${TAG}_pmc_sq1 -- python3 $R/tools/gemm_prof.py gemm 2048 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/${TAG}_pmc_sq2 -- python3 $R/tools/gemm_prof.py gemm 2048 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_sq1 -- python3 $R/tools/gemm_prof.py gemm 2048 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
+rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $OUT/${TAG}_pmc_sq2 -- python3 $R/tools/gemm_prof.py gemm 2048 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
 echo "sq counters done"
+# BASELINE configs[4] arms at M = 32768: FETCH / WRITE / MFMA-busy per weight layout (4096^2 Linear)
+for lay in mixed w2g16 w4row; do
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_c5_${lay}_FETCH -- python3 $R/tools/gemm_prof.py gemm 32768 4096 4096 4 $lay > /dev/null 2>> $OUT/${TAG}_pmc.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_c5_${lay}_WRITE -- python3 $R/tools/gemm_prof.py gemm 32768 4096 4096 4 $lay > /dev/null 2>> $OUT/${TAG}_pmc.err
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_c5_${lay}_SQ -- python3 $R/tools/gemm_prof.py gemm 32768 4096 4096 4 $lay > /dev/null 2>> $OUT/${TAG}_pmc.err
+  echo "config 5 $lay done"
+done
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_hbm_FETCH -- python3 $R/tools/hbm_prof.py > /dev/null 2>> $OUT/${TAG}_pmc.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_hbm_WRITE -- python3 $R/tools/hbm_prof.py > /dev/null 2>> $OUT/${TAG}_pmc.err
+echo "hbm kernels done"
 cd $R
 python3 tools/kernels_bench.py > $OUT/${TAG}_kernels_bench.txt 2>&1
 echo "kernels bench done"
+python3 tools/sweep_config5.py > $OUT/${TAG}_config5_sweep.log 2>&1
+echo "config 5 sweep done"
