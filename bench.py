@@ -61,8 +61,14 @@ def cpu_baseline(dev, budget_s=12.0):
     """Config 1 of BASELINE.json on the host cores: one [4096, 4096] MXQ Linear, batch 1 x
     seq 128 -> dequant (fp32 scale*(q-zero), fp16 cast) + F.linear per call."""
     from oracle import cpu_linear
-    # the 1-GPU box gives this job a 16-core CPU share; more torch threads than that only thrash
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    # Thread pool = the cores this process may actually run on (its affinity mask; the 1-GPU box gives the job a
+    # 16-core share of a 256-CPU host), capped at 16: more torch threads than cores only thrash, and a pool sized
+    # from os.cpu_count() made the round-1 number box-dependent.
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, cores)))
     N = K = 4096
     M = 128
     g = torch.Generator(device=dev).manual_seed(0)
@@ -83,6 +89,7 @@ def cpu_baseline(dev, budget_s=12.0):
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(2.0 * M * N * K / med / 1e12, 5), "unit": "TFLOP/s", "cores": torch.get_num_threads(),
+            "affinity_cpus": cores,
             "kind": "port", "tokens_per_s": round(M / med, 1), "ms_per_call": round(med * 1e3, 3),
             "iters": len(times), "host_cpus": os.cpu_count(), "gpu_vs_cpu_max_rel_err": rel,
             "sample": "config 1: one 4096x4096 MXQ Linear, M=128 tokens, dequant(fp32)+F.linear per call "

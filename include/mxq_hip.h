@@ -117,6 +117,16 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
 int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Hoisted-dequant mode of the same Linear, for launches that cover many token tiles (batch x seq >= ~8k tokens, e.g.
+ * BASELINE configs[4]): the fused kernel dequantises each 128 x 64 weight tile once per 256 tokens; here the bit-exact
+ * dequant kernel writes fp16 weights into `w16_scratch` (>= mxq_hoist_scratch_bytes(N, K) = 2*N*K bytes of device
+ * memory, 16-byte aligned, overwritten) ONCE and the MFMA kernel streams fp16 tiles from it -- same products, same
+ * summation order, results bit-identical to mxq_gemm_f16_layout.  The scratch is transient (nothing is cached
+ * between calls); layout as below (0 mixed, 1 W2G16, 2 W4ROW, 3 mixed with compact metadata). */
+size_t mxq_hoist_scratch_bytes(int N, int K);
+int mxq_linear_f16_hoisted(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                           int layout, void* w16_scratch, size_t scratch_bytes, void* stream);
+
 /* Uniform-bit-width layouts for the W2A16 / W4A16 / mixed sweep (BASELINE config 5); the mixed
  * layout is layout 0.  1 = W2G16: Quantizer(bits=2, qq_scale_bits=4) on every 16-column group
  * (quantizer.py:61-147), 4.5 bit/weight; 2 = W4ROW: Quantizer(bits=4, qq_scale_bits=4) per row

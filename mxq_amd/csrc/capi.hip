@@ -188,6 +188,25 @@ int mxq_gemm_f16_layout(const void* x, const void* qweight, const void* rowmeta,
     return mxq_launch_gemm8_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, nullptr, 0, (hipStream_t)stream);
 }
 
+size_t mxq_hoist_scratch_bytes(int N, int K) { return shape_ok(N, K) ? (size_t)N * K * 2 : 0; }
+
+int mxq_linear_f16_hoisted(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                           int layout, void* w16_scratch, size_t scratch_bytes, void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    if (!layout_ok(layout)) return MXQ_E_SHAPE;
+    if (!w16_scratch) return MXQ_E_NULL;
+    if (!aligned16(w16_scratch)) return MXQ_E_ALIGN;
+    if (scratch_bytes < (size_t)N * K * 2) return MXQ_E_SHAPE;
+    int e;
+    if (layout == MXQ_LAYOUT_MIXED || layout == MXQ_LAYOUT_MIXEDC)
+        e = mxq_launch_dequant_f16(qweight, rowmeta, w16_scratch, N, K, layout == MXQ_LAYOUT_MIXEDC, (hipStream_t)stream);
+    else
+        e = mxq_launch_uniform_expand(qweight, rowmeta, w16_scratch, nullptr, nullptr, nullptr, nullptr, nullptr, N, K,
+                                      layout, (hipStream_t)stream);
+    if (e) return e;
+    return mxq_launch_gemm8_dense_f16(x, w16_scratch, y, M, N, K, (hipStream_t)stream);
+}
+
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;

@@ -59,6 +59,10 @@ constexpr int OFF_BP = OFF_A + A_SLOTS * A_STAGE;
 constexpr int OFF_W = (OFF_BP + BP_SLOTS * BP_STAGE + 255) / 256 * 256;
 constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;
 static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+// hoisted-dequant mode: the packed ring and the W16 double buffer make room for a 3-slot ring of fp16 weight tiles
+constexpr int OFF_WD = OFF_BP, WD_SLOTS = 3;
+static_assert(OFF_WD + WD_SLOTS * W_STAGE <= SMEM_BYTES, "dense weight ring fits the same LDS");
+constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K] matrix (never part of the C ABI)
 
 // profiling-only switches (template parameter ABL; product build = 0)
 constexpr int ABL_NO_MFMA = 2, ABL_NO_DEQ = 4, ABL_NO_XDMA = 1, ABL_NO_STORE = 256;
@@ -131,10 +135,13 @@ __device__ __forceinline__ int sk_bound(int u, int S, int units) { return (int)(
 // ------------------------------------------------------------------------------------------------
 typedef half8 Frag4[4];
 
+// DENSE: the weight tile is a 3-slot ring of fp16 tiles filled by LDS-DMA (hoisted-dequant mode, below) instead of the
+// double buffer the dequant waves write
+template <bool DENSE>
 __device__ __forceinline__ void load_frags(const char* smem, int t, int kk, int wm, int wn, int fr, int fq, Frag4& wf,
                                            Frag4& xf) {
     const char* a_base = smem + OFF_A + (t % A_SLOTS) * A_STAGE;
-    const char* w_base = smem + OFF_W + (t & 1) * W_STAGE;
+    const char* w_base = DENSE ? smem + OFF_WD + (t % WD_SLOTS) * W_STAGE : smem + OFF_W + (t & 1) * W_STAGE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(w_base + swz(wn * 64 + i * 16 + fr, kk * 4 + fq));
 #pragma unroll
@@ -182,7 +189,7 @@ __device__ __forceinline__ u64t stamp() {
 
 // One K-step t >= 1: MFMAs of (t-1, kk=1) and (t, kk=0), fragment reads of step t, and -- ISSUE -- the x DMAs of
 // step t+2 (slot (t+2) % 3 was last read in step t-1), spread behind groups of MFMAs.
-template <int ABL, bool ISSUE>
+template <int ABL, bool ISSUE, bool DENSE>
 __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, int wn, int fr, int fq, const XDma& xd,
                                          f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1, Frag4& xf1,
                                          Stamps& st) {
@@ -190,7 +197,7 @@ __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, in
     if constexpr ((ABL & EXP_STAMPS) != 0) t0 = stamp();
     mfma_rows<0, 1, ABL>(acc, wf1, xf1);
     MXQ_FENCE();
-    load_frags(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
+    load_frags<DENSE>(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
     MXQ_FENCE();
     mfma_rows<1, 2, ABL>(acc, wf1, xf1);
     MXQ_FENCE();
@@ -198,7 +205,7 @@ __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, in
     MXQ_FENCE();
     mfma_rows<2, 4, ABL>(acc, wf1, xf1);
     MXQ_FENCE();
-    load_frags(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
+    load_frags<DENSE>(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
     MXQ_FENCE();
     mfma_rows<0, 2, ABL>(acc, wf0, xf0);
     MXQ_FENCE();
@@ -321,7 +328,7 @@ __device__ __forceinline__ void mma_prologue_issue(const XDma& xd, char* smem, i
 // sit in between, so the first wait is a full one).  After the last barrier, BEFORE the final 16 MFMAs and the
 // output, `next(...)` runs: the persistent loop issues the next tile's prologue DMAs there, which then fly under
 // this tile's epilogue.
-template <int ABL, class Next>
+template <int ABL, bool DENSE, class Next>
 __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int NT, const XDma& xd, bool pre,
                                             uint16_t* __restrict__ y, int M, int N, int m0, int n0, int NT_tile,
                                             const SkSeg& sk, Next&& next) {
@@ -340,8 +347,8 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
     __builtin_amdgcn_s_barrier();   // prologue barrier 2: W16(0) written by the dequant waves
 
     // step 0: no previous half
-    load_frags(smem, 0, 0, wm, wn, fr, fq, wf0, xf0);
-    load_frags(smem, 0, 1, wm, wn, fr, fq, wf1, xf1);
+    load_frags<DENSE>(smem, 0, 0, wm, wn, fr, fq, wf0, xf0);
+    load_frags<DENSE>(smem, 0, 1, wm, wn, fr, fq, wf1, xf1);
     if (NT > 2) {
         if constexpr (!(ABL & ABL_NO_XDMA)) issue_x<0, 4>(xd, smem, wave, 2);
         mfma_rows<0, 4, ABL>(acc, wf0, xf0);
@@ -354,14 +361,14 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
 
     int t = 1;
     Stamps st = {0, 0, 0, 0};
-    for (; t + 2 < NT; ++t) mma_step<ABL, true>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
+    for (; t + 2 < NT; ++t) mma_step<ABL, true, DENSE>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
     if constexpr ((ABL & EXP_STAMPS) != 0) {   // this workgroup's wave: {work, wait, barrier, steps} cycle sums
         if (lane == 0 && sk.ws) {
             u64t* d = (u64t*)sk.ws + ((int64_t)blockIdx.x * (N_MMA + N_DEQ) + wave) * 4;
             d[0] = st.work; d[1] = st.wait; d[2] = st.bar; d[3] = st.n;
         }
     }
-    for (; t < NT; ++t) mma_step<ABL, false>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
+    for (; t < NT; ++t) mma_step<ABL, false, DENSE>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
     next();                                  // the ring is idle from here on
     mfma_rows<0, 4, ABL>(acc, wf1, xf1);     // (NT-1, kk=1)
 
@@ -612,6 +619,64 @@ __device__ __forceinline__ void deq_segment(Deq& c, int wave, int lane, const fl
     next();   // the rings are idle from here on
 }
 
+// ------------------------------------------------------------------------------------------------
+// hoisted-dequant mode: waves 8-11 are plain DMA waves for an fp16 weight tile
+// ------------------------------------------------------------------------------------------------
+// When a launch covers many token tiles (M >= 8192), dequantising the same 128 x 64 weight tile once per 256 tokens
+// is the dominant avoidable cost: the dequant is then HOISTED out of the token loop -- the bit-exact dequant kernel
+// (pack.hip) writes fp16 weights into a scratch buffer once, and this kernel's waves 8-11 stream its tiles into a
+// 3-slot LDS ring (4 DMAs of 8 full 128-B rows per wave and K-step, source chunks XOR-swizzled like the x tile) two
+// steps ahead, exactly as the MFMA waves stream x.  Same MFMA loop, same barriers, same epilogue; the products and
+// their summation order are those of the fused mode, so the two modes agree bit for bit.
+struct WDma {
+    rsrc_t rsrc;         // weight rows n0 .. of this tile (range-checked: rows beyond N read as zeros)
+    uint32_t voff[4];
+    uint32_t k0;
+    int d, NT;
+};
+__device__ __forceinline__ void wdma_setup(WDma& w, const uint16_t* __restrict__ w16, int N, int K, int n0, int kt0,
+                                           int nsteps, int wave, int lane) {
+    const int rows = N - n0 < BN ? N - n0 : BN;
+    w.rsrc = make_rsrc(w16 + (int64_t)n0 * K, (uint32_t)rows * (uint32_t)K * 2u);
+    w.k0 = (uint32_t)kt0 * (BK * 2);
+    w.d = wave - N_MMA;
+    w.NT = nsteps;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = w.d * 32 + i * 8 + (lane >> 3);
+        w.voff[i] = (uint32_t)row * (uint32_t)K * 2u + ((((uint32_t)lane & 7u) ^ ((uint32_t)row & 7u)) << 4);
+    }
+}
+__device__ __forceinline__ void issue_w(const WDma& w, char* smem, int t) {
+    char* dst = smem + OFF_WD + (t % WD_SLOTS) * W_STAGE + w.d * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bufdma16(w.rsrc, w.voff[i], w.k0 + (uint32_t)t * (BK * 2), dst + i * 1024);
+}
+__device__ __forceinline__ void wdma_prologue_issue(const WDma& w, char* smem) {
+    issue_w(w, smem, 0);
+    if (w.NT > 1) issue_w(w, smem, 1);
+}
+// barrier-for-barrier the twin of deq_segment (prologue barriers 1, 2, then one per K-step)
+template <class Next>
+__device__ __forceinline__ void wdma_segment(const WDma& w, char* smem, bool pre, Next&& next) {
+    if (!pre) wdma_prologue_issue(w, smem);
+    if (w.NT > 1 && !pre) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    int t = 0;
+    for (; t + 2 < w.NT; ++t) {
+        issue_w(w, smem, t + 2);                                   // slot (t+2) % 3 was last read in step t-1
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // this step's 4 DMAs stay in flight
+        __builtin_amdgcn_s_barrier();
+    }
+    for (; t < w.NT; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    next();
+}
+
 #define MXQ_LANE_ID(ln) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln))
 
 // grid = dp_grid persistent workgroups, which deal the first dp_tiles tiles round-robin (tile = block + k * dp_grid:
@@ -660,10 +725,28 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
                 const int m0 = tm * BM, n0 = tn * BN;
                 const bool more = tile + dp_grid < dp_tiles;
                 if (more) tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
-                mma_segment<ABL>(smem, wave, ln, NT, cur, true, y, M, N, m0, n0, NT, sk, [&] {
+                mma_segment<ABL, LAYOUT == LAYOUT_DENSE16>(smem, wave, ln, NT, cur, true, y, M, N, m0, n0, NT, sk, [&] {
                     if (more) {
                         xdma_setup(nxt, x, M, K, tm * BM, 0, wave, ln);
                         mma_prologue_issue<ABL>(nxt, smem, wave, NT);
+                    }
+                });
+                cur = nxt;
+            }
+        } else if constexpr (LAYOUT == LAYOUT_DENSE16) {
+            int ln;
+            MXQ_LANE_ID(ln);
+            WDma cur, nxt;
+            wdma_setup(cur, (const uint16_t*)qweight, N, K, tn * BN, 0, NT, wave, ln);
+            wdma_prologue_issue(cur, smem);
+            for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
+                MXQ_LANE_ID(ln);
+                const bool more = tile + dp_grid < dp_tiles;
+                if (more) tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
+                wdma_segment(cur, smem, true, [&] {
+                    if (more) {
+                        wdma_setup(nxt, (const uint16_t*)qweight, N, K, tn * BN, 0, NT, wave, ln);
+                        wdma_prologue_issue(nxt, smem);
                     }
                 });
                 cur = nxt;
@@ -711,7 +794,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             MXQ_LANE_ID(ln);
             XDma xd;
             xdma_setup(xd, x, M, K, tm * BM, pos - sk.j * NT, wave, ln);
-            mma_segment<ABL>(smem, wave, ln, end - pos, xd, false, y, M, N, tm * BM, tn * BN, NT, sk, nothing);
+            mma_segment<ABL, LAYOUT == LAYOUT_DENSE16>(smem, wave, ln, end - pos, xd, false, y, M, N, tm * BM, tn * BN, NT, sk, nothing);
             if (end - pos != NT) {
                 if (sk.first) { pj0 = sk.j; pn0 = end - pos; }
                 else { pj1 = sk.j; pn1 = end - pos; }
@@ -751,9 +834,15 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
             int ln;
             MXQ_LANE_ID(ln);
-            Deq c;
-            deq_setup<LAYOUT>(c, smem, wave, ln, qweight, N, K, tn * BN, pos - j * NT, end - pos);
-            deq_segment<ABL, LAYOUT>(c, wave, ln, rowmeta, N, tn * BN, false, (u64t*)ws, nothing);
+            if constexpr (LAYOUT == LAYOUT_DENSE16) {
+                WDma w;
+                wdma_setup(w, (const uint16_t*)qweight, N, K, tn * BN, pos - j * NT, end - pos, wave, ln);
+                wdma_segment(w, smem, false, nothing);
+            } else {
+                Deq c;
+                deq_setup<LAYOUT>(c, smem, wave, ln, qweight, N, K, tn * BN, pos - j * NT, end - pos);
+                deq_segment<ABL, LAYOUT>(c, wave, ln, rowmeta, N, tn * BN, false, (u64t*)ws, nothing);
+            }
             pos = end;
         }
     }
@@ -825,6 +914,11 @@ int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* 
         case MXQ_LAYOUT_MIXEDC: return launch8<0, MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
     }
     return -1;
+}
+
+// hoisted-dequant mode: w16 = dense fp16 [N, K] weight (the dequant kernel's output); same tiles, no stream-K tail
+int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, hipStream_t stream) {
+    return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, false, stream);
 }
 
 #ifdef MXQ_PROFILING

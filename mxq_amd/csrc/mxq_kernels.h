@@ -29,6 +29,8 @@ size_t mxq_gemm8_workspace_bytes();
 int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          void* workspace, size_t ws_bytes, int force,
                          hipStream_t stream);   // 256x128 tile: MFMA waves stream x, dedicated waves dequantise; stream-K tail with a workspace (gemm8.hip); force: split even when it does not pay
+int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K,
+                               hipStream_t stream);   // hoisted-dequant mode: w16 = dense fp16 [N, K] weight
 int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -36,12 +38,6 @@ int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta,
 // skinny MFMA kernel, 1 <= M <= 32 (skinny.hip); layout MXQ_LAYOUT_MIXED or MXQ_LAYOUT_MIXEDC
 int mxq_launch_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                           int layout, hipStream_t stream);
-// v2 GEMV (gemv2.hip): 16-byte weight loads, M <= 8; teams: 0 = auto, else waves / 4 per workgroup (1, 2, 4)
-int mxq_launch_gemv2_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         int layout, int teams, hipStream_t stream);
-int mxq_launch_gemv2_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
-                               int prologue, const void* norm_w, float eps, const void* residual, int teams,
-                               hipStream_t stream);
 int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
                                int K, int layout, hipStream_t stream);
 int mxq_launch_quantize_uniform(const void* W, int dtype, void* qweight, void* rowmeta, int N, int K, int layout,

@@ -91,7 +91,7 @@ def test_gemm8_main_loops_keep_dma_in_flight():
         assert sum(bool(re.match(r"\s+v_(?!mfma)", l)) for l in lp) <= 12, "VALU work crept into the MFMA waves' loop"
 
 
-@pytest.mark.parametrize("src", ["gemm.hip", "gemm8.hip", "gemv.hip", "gemv2.hip", "fakequant.hip", "actquant.hip", "pack.hip"])
+@pytest.mark.parametrize("src", ["gemm.hip", "gemm8.hip", "gemv.hip", "skinny.hip", "fakequant.hip", "actquant.hip", "pack.hip"])
 def test_no_spills_no_scratch(src):
     s = _asm(src)
     for m in re.finditer(r"\.vgpr_spill_count:\s+(\d+)", s):

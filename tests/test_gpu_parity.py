@@ -512,6 +512,35 @@ def test_config5_full_size_m32768(dev, layout, N, K):
         assert torch.equal(alone, y[r0:r0 + 2048]), (layout, r0)
 
 
+@pytest.mark.parametrize("layout", ["mixed", "mixedc", "w2g16", "w4row"])
+@pytest.mark.parametrize("M,N,K", [(300, 144, 192), (2048, 4096, 4096), (8192, 1024, 11008), (4100, 4224, 1024)])
+def test_hoisted_dequant_mode_is_bit_identical_to_the_fused_gemm(dev, layout, M, N, K):
+    """mxq_linear_f16_hoisted (dequant kernel once into a scratch buffer + the MFMA kernel on fp16 tiles) multiplies
+    the same fp16 weights in the same order as the fused kernel: the outputs are bit-identical, on every layout,
+    with ragged M / N edges; "auto" takes the hoisted mode from HOIST_MIN_TOKENS tokens on."""
+    from mxq_amd import packing
+    g = torch.Generator().manual_seed(M + N + K)
+    W = (torch.randn(N, K, generator=g) * 0.02).half().to(dev)
+    x = torch.randn(M, K, generator=g).half().to(dev)
+    if layout in ("mixed", "mixedc"):
+        p = packing.quantize_pack(W, compact_meta=layout == "mixedc")
+        wd = packing.dequant(p)
+    else:
+        p = packing.quantize_pack_uniform(W, layout)
+        wd = packing.expand_uniform(p, codes=False)[0]
+    fused = packing.linear_layout(x, p, path="fused" if layout.startswith("mixed") else "gemm") if M < packing.HOIST_MIN_TOKENS \
+        else None
+    hoisted = packing.linear_layout(x, p, path="hoist")
+    ref = x.float() @ wd.float().t()
+    assert ((hoisted.float() - ref).abs().max() / ref.abs().max()).item() <= REL_TOL
+    if fused is not None and M % 256 == 0 and (M // 256) * ((N + 127) // 128) % 256 == 0:
+        assert torch.equal(hoisted, fused)                  # no stream-K split involved: same summation order
+    elif fused is not None:
+        assert ((hoisted.float() - fused.float()).abs().max() / ref.abs().max()).item() <= REL_TOL
+    if M >= packing.HOIST_MIN_TOKENS:
+        assert torch.equal(packing.linear_layout(x, p, path="auto"), hoisted)
+
+
 # ----------------------------------------------------------------------------------------
 # compact metadata mode (format v2: fp16 zero-points, 3.75 bit/weight)
 # ----------------------------------------------------------------------------------------

@@ -115,7 +115,7 @@ def test_packed_checkpoint_roundtrip_and_errors(tmp_path):
     cfg = json.load(open(os.path.join(d, "mxq_config.json")))
     assert cfg["format"] == "mxq-v1" and set(cfg["quantized"]) == {f"layers.{i}.{n}" for i in (0, 1) for n in
                                                                   ("attn.q_proj", "attn.o_proj", "mlp.0", "mlp.2")}
-    assert cfg["quantized"]["layers.0.attn.o_proj"] == {"in_features": 64, "out_features": 64, "bias": True}
+    assert cfg["quantized"]["layers.0.attn.o_proj"] == {"in_features": 64, "out_features": 64, "bias": True, "metadata": "exact"}
     fresh = torch.nn.ModuleDict({"layers": torch.nn.ModuleList([_Block(), _Block()]), "lm_head": torch.nn.Linear(64, 32, bias=False)})
     checkpoint.load_packed(fresh, d)
     assert isinstance(fresh["layers"][1].mlp[2], QuantLinear) and type(fresh["lm_head"]) is torch.nn.Linear

@@ -47,6 +47,10 @@ def make_call(v, x, p, wd, out):
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (v, rc)
         return call
+    if v == "hoist":
+        return lambda: packing.linear_hoisted(x, p, out=out)
+    if v == "fused":
+        return lambda: packing.linear(x, p, out=out, path="fused")
     return lambda: packing.linear(x, p, out=out, path=v)
 
 
@@ -57,6 +61,7 @@ def main():
     ap.add_argument("--variants", default="gemm8,torch")
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008", help="NxK list")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--reps", type=int, default=20, help="launches per graph")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     variants = args.variants.split(",")
@@ -80,7 +85,7 @@ def main():
                 assert err < 1e-3, (v, N, K, err)
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
-                for _ in range(20):
+                for _ in range(args.reps):
                     call()
             graphs[v] = gr
         ts = {v: [] for v in variants}
@@ -92,7 +97,7 @@ def main():
                 graphs[v].replay()
                 e1.record()
                 torch.cuda.synchronize()
-                ts[v].append(e0.elapsed_time(e1) / 20 * 1e3)
+                ts[v].append(e0.elapsed_time(e1) / args.reps * 1e3)
         fl = 2.0 * M * N * K
         row = {"M": M, "N": N, "K": K}
         parts = []

@@ -1,3 +1,10 @@
+// EXPERIMENT RECORD (round 2) -- not part of the product library, not built by the Makefile.
+// Outcome: correct (<= 1e-3 vs the dequantised weight on all five Llama GEMV shapes) but 8-25 % SLOWER than gemv.hip
+// (4096^2: 6.9 vs 5.5 us; fused gate|up 22016 x 4096: 18.7 vs 16.8 us; gpurun_out/r2_gemv1.log).  tools/probes/
+// stream_probe.hip then showed why the premise was wrong: the 4-byte-load pattern of gemv.hip already streams at the
+// rate of an ideal 16-byte grid-stride read (5.2-5.4 TB/s loads-only); what the GEMV lacks is overlap between its
+// ~230 VALU ops per tile and the load latency, not load width.
+//
 // Decode-path GEMV / skinny product (M <= 8 tokens), v2: 16-byte weight loads, activations shared by 4 rows.
 //
 //   y[m, n] = sum_k x[m, k] * fp16(scale * (q - zero))[n, k], fp32 accumulate, fp16 out.
