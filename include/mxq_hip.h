@@ -182,6 +182,13 @@ int mxq_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, 
 int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                         const void* sin_t, void* out, int heads, int head_dim, int max_ctx, void* stream);
 
+/* Decode-harness glue, no reference counterpart: a loads-only pass over [p, p + bytes) (p 16-byte aligned; the tail
+ * bytes % 16 is skipped) that pulls the range through the memory-side Infinity Cache.  Launched on a side stream
+ * under the current GEMV, it keeps the HBM streaming while that GEMV is in its arithmetic phase, and the NEXT GEMV
+ * finds its weights in the cache.  `sink` (nullable) is a scratch word the kernel may write; nothing else is
+ * written. */
+int mxq_prefetch(const void* p, size_t bytes, int workgroups, void* sink, void* stream);
+
 /* MXAsymQuantizer.forward (utils_quant.py:316-462; 2-D, layerwise=False branch):
  * fake-quantise w[rows, cols] of `dtype` into out (same shape/dtype), bit-identical to
  * the reference in fp32 / bf16 / fp16.  cols % 64 == 0. */

@@ -142,6 +142,13 @@ int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const voi
                                       (hipStream_t)stream);
 }
 
+int mxq_prefetch(const void* p, size_t bytes, int workgroups, void* sink, void* stream) {
+    if (!p) return MXQ_E_NULL;
+    if (((uintptr_t)p & 15) != 0) return MXQ_E_ALIGN;
+    if (workgroups <= 0 || workgroups > 65536) return MXQ_E_SHAPE;
+    return mxq_launch_prefetch(p, bytes, workgroups, sink, (hipStream_t)stream);
+}
+
 // ---- uniform layouts of the config-5 sweep ---------------------------------------------------
 static bool layout_ok(int l) {
     return l == MXQ_LAYOUT_MIXED || l == MXQ_LAYOUT_W2G16 || l == MXQ_LAYOUT_W4ROW || l == MXQ_LAYOUT_MIXEDC;

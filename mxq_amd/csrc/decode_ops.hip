@@ -133,7 +133,29 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
     }
 }
 
+// Infinity-Cache prefetch: a loads-only pass over a byte range.  The decode GEMVs are a chain of dependent launches
+// that each spend part of their time in arithmetic with the HBM idle; a prefetch of the NEXT launches' weights, running
+// on a side stream under the current one, keeps the HBM streaming and leaves the weights in the 256 MiB memory-side
+// cache, from where the GEMV's loads return sooner.  16 bytes per lane and load, 4 loads in flight per lane.
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, size_t n16, uint32_t* sink) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc ^= a.x ^ b.y ^ c.z ^ d.w;
+    }
+    for (; i < n16; i += stride) acc ^= p[i].x;
+    if (sink != nullptr && acc == 0x5bd1e995u) *sink = acc;      // keeps the loads alive; sink is a scratch word
+}
+
 }   // namespace
+
+int mxq_launch_prefetch(const void* p, size_t bytes, int workgroups, void* sink, hipStream_t stream) {
+    if (bytes < 16) return 0;
+    prefetch_kernel<<<workgroups, 256, 0, stream>>>((const uint4*)p, bytes / 16, (uint32_t*)sink);
+    return (int)hipGetLastError();
+}
 
 int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                                const void* sin_t, void* out, int heads, int head_dim, int max_ctx,

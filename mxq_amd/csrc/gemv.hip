@@ -1,17 +1,36 @@
-// Decode-path GEMV / skinny GEMM (M <= 4) on the v1 packed format:
-//   y[m, n] = sum_k x[m, k] * fp16(scale * (q - zero))[n, k], fp32 accumulate, fp16 out.
+// Decode-path GEMV (M <= 4 tokens) on the packed formats:
+//   y[m, n] = sum_k x[m, k] * (scale * (q - zero))[n, k], fp32 accumulate, fp16 out.
 //
-// Native counterpart of the reference's fused unpack+dot kernel
-// gemv_mxq_kernel_g16_v0 (mxq_quant/cuda_kernel/csrc/quantization/gemv_mxq_cuda.cu:39-208)
-// -- same idea (never materialise fp16 weights in memory), different everything else:
-//   * HBM-bound: every packed byte is read exactly once; a wave consumes 4 consecutive
-//     16x64 blocks (2304 contiguous bytes) per iteration, straight to VGPRs
-//     (no LDS round trip for weights; cdna guide section 5, "GEMV / M <= 16" row).
-//   * one workgroup per 16-row block (N/16 >= 256 workgroups for Llama shapes), 16 waves
-//     split K; lane -> (row r = lane & 15, chunk slot cs = lane >> 4).
-//   * activations are staged once per workgroup in LDS as fp16 and read as broadcast
-//     ds_read_b128; products use v_dot2_f32_f16 on the LUT-selected fp16 pairs.
-//   * wave64 reduction: 2 xor-shuffles over the 4 chunk slots, then 16 waves through LDS.
+// Native counterpart of the reference's fused unpack+dot kernel gemv_mxq_kernel_g16_v0
+// (mxq_quant/cuda_kernel/csrc/quantization/gemv_mxq_cuda.cu:39-208) -- same idea (never materialise fp16 weights in
+// memory), different everything else.  What round 2's measurements say bounds this kernel, and what the structure
+// does about each (tools/gemv_stamps.py, tools/ab_gemv.py, tools/probes/stream_probe.hip):
+//   * Not the HBM peak: a loads-only kernel in this access pattern streams 5.2-5.4 TB/s, weights served from the
+//     Infinity Cache instead of HBM made the round-1 kernel only ~15 % faster, and halving its VALU work only ~7 %.
+//   * Round trips: a wave that loads a tile, waits, computes, loads the next ... pays one loaded HBM latency
+//     (2.5-4 us with every workgroup's requests queued at once) per tile, and the workgroup's prologue (activation
+//     staging + barrier) waited for the first tile as well, because vector-memory loads retire in order (vmcnt).
+//     So: each wave keeps TWO tiles in flight while it computes a third (three register sets, rotated by unrolling
+//     -- no copies, a copy would wait for its load); the activation loads are issued BEFORE the first tiles, so the
+//     staging waits for them alone; and nothing on the hot path branches around a load -- a branch makes the
+//     compiler's wait counts conservative, i.e. a drain.  Instead: tiles are read through a buffer descriptor that
+//     spans exactly the row block's K range (a tile index past the end returns zeros and costs no memory traffic),
+//     and threads with nothing to stage write to a dummy LDS slot.
+//   * Fewer, longer waves: 2 / 4 / 8 waves per workgroup by row-block count (every workgroup resident, ~2-3 k waves
+//     on the chip, 2-8 tiles each) instead of 16 waves with one tile.
+//   * VALU: the integer CODES go into v_dot2_f32_f16 and the group's scale / zero-point are applied to the group's
+//     16-term sum,
+//         sum_k x_k s (q_k - z)  =  s * (sum_k q_k x_k)  -  s z * (sum_k x_k),
+//     with the per-group activation sums computed once per workgroup next to the staged activations.  A code becomes
+//     an fp16 operand without a conversion: OR-ed into the top mantissa bits of 1.0 it reads 1 + q/4 (2-bit) or
+//     1 + q/16 (4-bit), i.e. one shift and one v_and_or_b32 per TWO weights (the byte-spread code words put
+//     elements k and k + 2 sixteen bits apart; the staged activations are permuted to (x0, x2, x1, x3) per four to
+//     match).  ~120 VALU ops per 64 weights instead of ~230 for building the exact fp16 weights first (LUT +
+//     4 v_perm per 4 weights).  The result is the fp32 sum over the UNROUNDED weights s (q - z): it differs from
+//     the sum over the reference's fp16-rounded weights by the fp16 rounding of each weight (2^-11 relative,
+//     independent per weight), ~1e-5 of the output scale at K = 4096 -- far inside the path's 1e-3 tolerance.
+// One workgroup per 16-row block; lane -> (row r = lane & 15, chunk slot cs = lane >> 4); a wave consumes 4
+// consecutive 16x64 blocks (2304 contiguous bytes) per tile, straight to VGPRs; waves split K by tiles.
 #include <hip/hip_runtime.h>
 
 #include "mxq_dequant.h"
@@ -23,23 +42,79 @@ namespace {
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 
-__device__ __forceinline__ float dot8(const uint32_t* w, const uint4 xa, float acc) {
-    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[0]), __builtin_bit_cast(half2v, xa.x), acc, false);
-    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[1]), __builtin_bit_cast(half2v, xa.y), acc, false);
-    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[2]), __builtin_bit_cast(half2v, xa.z), acc, false);
-    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w[3]), __builtin_bit_cast(half2v, xa.w), acc, false);
+__device__ __forceinline__ float dot2(uint32_t w, uint32_t x, float acc) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w), __builtin_bit_cast(half2v, x), acc, false);
+}
+
+// (a & m) | o in one op (the mask in an SGPR, the fp16 ones in a VGPR: gfx9 VOP3 takes no literals, and left to itself
+// the compiler emits v_and + v_or)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t o) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(o));
+    return r;
+}
+
+// sum_k (1 + q_k / 4) x_k over the 16 two-bit codes of byte-spread word d.  Element k sits at bit 8 (k & 3) +
+// 2 (k >> 2): field f of bytes (0, 2) = elements (4f, 4f + 2) lands in mantissa bits 9:8 of the two fp16 lanes
+// with one shift, bytes (1, 3) = elements (4f + 1, 4f + 3) likewise.  xa / xb: the group's 16 activations in the
+// staged order (x0, x2, x1, x3 | x4, x6, x5, x7 | ...).
+__device__ __forceinline__ float codedot2x16(uint32_t d, const uint4 xa, const uint4 xb, float acc) {
+    constexpr uint32_t M = 0x03000300u, ONE = 0x3C003C00u;
+    acc = dot2(and_or(d << 8, M, ONE), xa.x, acc);
+    acc = dot2(and_or(d, M, ONE), xa.y, acc);
+    acc = dot2(and_or(d << 6, M, ONE), xa.z, acc);
+    acc = dot2(and_or(d >> 2, M, ONE), xa.w, acc);
+    acc = dot2(and_or(d << 4, M, ONE), xb.x, acc);
+    acc = dot2(and_or(d >> 4, M, ONE), xb.y, acc);
+    acc = dot2(and_or(d << 2, M, ONE), xb.z, acc);
+    acc = dot2(and_or(d >> 6, M, ONE), xb.w, acc);
     return acc;
 }
 
-// GEMV_THREADS: 1024 (16 waves: one 16x256 tile per wave at K = 4096, every load in flight at
-// once) when there are few row blocks, 512 when N/16 alone oversubscribes the chip.
+// sum_k (1 + q_k / 16) x_k over the 8 four-bit codes of byte-spread word d (element k at bit 8 (k & 3) + 4 (k >> 2));
+// xa: the 8 activations in the staged order
+__device__ __forceinline__ float codedot4x8(uint32_t d, const uint4 xa, float acc) {
+    constexpr uint32_t M = 0x03C003C0u, ONE = 0x3C003C00u;
+    acc = dot2(and_or(d << 6, M, ONE), xa.x, acc);
+    acc = dot2(and_or(d >> 2, M, ONE), xa.y, acc);
+    acc = dot2(and_or(d << 2, M, ONE), xa.z, acc);
+    acc = dot2(and_or(d >> 6, M, ONE), xa.w, acc);
+    return acc;
+}
+
+// 8 fp16 activations (x0 .. x7) -> the staged order (x0, x2, x1, x3, x4, x6, x5, x7) and their fp32 sum
+__device__ __forceinline__ uint4 stage8(const uint4 v, float& sum) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 h = __builtin_bit_cast(h8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += (float)h[j];
+    uint4 o;
+    o.x = __builtin_amdgcn_perm(v.y, v.x, 0x05040100u);
+    o.y = __builtin_amdgcn_perm(v.y, v.x, 0x07060302u);
+    o.z = __builtin_amdgcn_perm(v.w, v.z, 0x05040100u);
+    o.w = __builtin_amdgcn_perm(v.w, v.z, 0x07060302u);
+    return o;
+}
+
+#ifdef MXQ_PROFILING
+// phase stamps of every workgroup (tools/gemv_stamps.py): [workgroup][4] = start, activations staged, weight loop
+// done, result stored; 100 MHz wall clock (comparable across CUs)
+__device__ unsigned long long* g_gemv_stamps = nullptr;
+#define GEMV_STAMP(i)                                                                            \
+    if (g_gemv_stamps != nullptr && threadIdx.x == 0) g_gemv_stamps[blockIdx.x * 4 + (i)] = wall_clock64();
+#else
+#define GEMV_STAMP(i)
+#endif
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
 // PRO: prologue fused into the activation staging (decode, M = 1 only):
-//   0 = none; 1 = RMSNorm: x <- fp16(x * rsqrt(mean(x^2) + eps)) * norm_w (every workgroup
-//   recomputes the 4096-element reduction -- cheaper than a separate launch);
+//   0 = none; 1 = RMSNorm: x <- fp16(x * norm_w), and the row's scalar rsqrt(mean(x^2) + eps) -- linear in the
+//   output -- multiplies the 16 results at the end (so the staging does not wait for the reduction);
 //   2 = SwiGLU gate: the input row is [2K] = (gate, up) and x <- fp16(silu(gate)) * up.
 // residual (nullable): y <- residual + W.x (the decoder layer's skip connection).
-// LAYOUT: MXQ_LAYOUT_MIXED (3 two-bit groups + the 4-bit quarter per chunk), MXQ_LAYOUT_W2G16 (4 two-bit groups)
-// or MXQ_LAYOUT_W4ROW (4 four-bit quarters, scale / zero per row from rowmeta): csrc/mxq_format.h.
+// LAYOUT: MXQ_LAYOUT_MIXED / MIXEDC (3 two-bit groups + the 4-bit quarter per chunk; exact / compact metadata),
+// MXQ_LAYOUT_W2G16 (4 two-bit groups) or MXQ_LAYOUT_W4ROW (4 four-bit quarters, scale / zero per row from rowmeta).
 template <int MB, int GEMV_THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED>
 __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16_t* __restrict__ x,
                                                                      const uint32_t* __restrict__ qweight,
@@ -47,154 +122,202 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
                                                                      uint16_t* __restrict__ y, int M, int N, int K,
                                                                      const uint16_t* __restrict__ norm_w, float eps,
                                                                      const uint16_t* __restrict__ residual) {
-    constexpr int GEMV_WAVES = GEMV_THREADS / 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // MB*K halfs, then reduction scratch
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, cs = lane >> 4;
-    const int rb = blockIdx.x;
-    const int NC = K / 64, NC4 = (NC + 3) / 4;
-
-    // packed operands of one (row, chunk): 13 registers (mixed layout), loaded straight from HBM
+    constexpr int W = GEMV_THREADS / 64;
     constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC;   // exact / compact metadata
     constexpr bool COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
     constexpr int NG2 = MIXED ? 3 : LAYOUT == MXQ_LAYOUT_W2G16 ? 4 : 0;   // two-bit groups per chunk
     constexpr int NW4 = MIXED ? 2 : LAYOUT == MXQ_LAYOUT_W4ROW ? 8 : 0;   // four-bit code words per chunk
     constexpr int BLK_DW = LAYOUT == MXQ_LAYOUT_W4ROW ? 128 : COMPACT ? MXQC_BLK_DW : MXQ_BLK_DW;
+    // LDS: x [MB][K] fp16 (code-dot order) | xsum [MB][K/16] f32 | red [W][MB][16] f32 | wsum [W] f32 | dummy slots
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, cs = lane >> 4;
+    const int rb = blockIdx.x;
+    const int NC = K / 64, NC4 = (NC + 3) / 4, NG = K / 16;
+    GEMV_STAMP(0)
+
+    float* xsum = (float*)(smem + (size_t)MB * K * 2);
+    float* red = xsum + MB * NG;
+    float* wsum = red + W * MB * 16;
+    char* dummy = (char*)(wsum + W);                    // [64 lanes][32 B] + [64] f32: where idle threads "stage"
+
+    // ---- activation loads first (L2-resident, small), 2 staging steps hoisted; branch-free (clamped addresses)
+    struct Act {
+        h8 a0, a1;     // 16 activations (one scale group)
+        h8 b0, b1;     // PRO 1: their RMSNorm weights; PRO 2: the up projection (a = gate)
+    };
+    auto load_act = [&](int i) {
+        Act t;
+        const int ic = min(i, MB * NG - 1);
+        const int m = ic / NG, g = ic % NG;
+        const uint16_t* xr = x + (int64_t)min(m, M - 1) * K + g * 16;      // PRO != 0: one token, m == 0
+        t.a0 = *(const h8*)xr;
+        t.a1 = *(const h8*)(xr + 8);
+        if constexpr (PRO == 1) {
+            t.b0 = *(const h8*)(norm_w + g * 16);
+            t.b1 = *(const h8*)(norm_w + g * 16 + 8);
+        }
+        if constexpr (PRO == 2) {
+            t.b0 = *(const h8*)(xr + K);
+            t.b1 = *(const h8*)(xr + K + 8);
+        }
+        return t;                                       // (nothing here may USE a loaded value: that would be a wait)
+    };
+    const Act act0 = load_act(tid), act1 = load_act(tid + GEMV_THREADS);
+
+    // ---- the first two weight tiles right behind them.  A tile = 4 consecutive blocks (one per chunk slot).
     struct Tile {
         uint32_t c2w[NG2 ? NG2 : 1], z2w[NG2 ? NG2 : 1], c4w[NW4 ? NW4 : 1], scw;
         uint2 qq[NG2 ? NG2 : 1];
     };
-    const uint32_t* tiles = qweight + (int64_t)rb * NC * BLK_DW;
-    auto load_tile = [&](int c4) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(qweight + (int64_t)rb * NC * BLK_DW), 0, NC * BLK_DW * 4, 0x00020000);
+    const int lane_off = (cs * BLK_DW) * 4;             // byte offset of the lane's block inside a tile
+    auto load_tile = [&](int c4) {                      // c4 >= NC4 or a chunk >= NC: out of range = zeros, no traffic
         Tile t = {};
-        const int chunk = c4 * 4 + cs;
-        if (chunk < NC) {   // ragged tail: K/64 not a multiple of 4
-            // the wave reads 4 consecutive blocks = 2304 contiguous bytes; each load touches
-            // four 64-B segments (one per chunk slot)
-            const uint32_t* tile = tiles + (int64_t)chunk * BLK_DW;
-            if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
+        const int so = c4 * (4 * BLK_DW * 4);           // wave-uniform
+        auto dw = [&](int idx) { return __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off + idx * 4, so, 0); };
+        if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) t.c4w[i] = tile[mxq_w4_c4(i >> 1, i & 1, r)];
-            } else {
+            for (int i = 0; i < 8; ++i) t.c4w[i] = dw(mxq_w4_c4(i >> 1, i & 1, r));
+        } else {
 #pragma unroll
-                for (int g = 0; g < NG2; ++g) {
-                    t.c2w[g] = tile[MIXED ? mxq_c2(g, r) : mxq_w2_c2(g, r)];
-                    if constexpr (COMPACT) {   // fp16 zero-point, widened once here (the arithmetic below is fp32 either way)
-                        const uint16_t zh = ((const uint16_t*)tile)[mxqc_z2_u16(g, r)];
-                        t.z2w[g] = __float_as_uint((float)__builtin_bit_cast(_Float16, zh));
-                    } else {
-                        t.z2w[g] = tile[MIXED ? mxq_z2(g, r) : mxq_w2_z2(g, r)];
-                    }
-                    t.qq[g] = *(const uint2*)(tile + (COMPACT ? mxqc_qq(g) : mxq_qq(g)));   // SC / QQ: same offsets in v1 and W2G16
-                }
-                if constexpr (MIXED) {
-                    t.c4w[0] = tile[mxq_c4(0, r)];
-                    t.c4w[1] = tile[mxq_c4(1, r)];
-                }
-                t.scw = ((const uint16_t*)tile)[COMPACT ? mxqc_sc_u16(r) : mxq_sc_u16(r)];
+            for (int g = 0; g < NG2; ++g) {
+                t.c2w[g] = dw(MIXED ? mxq_c2(g, r) : mxq_w2_c2(g, r));
+                if constexpr (COMPACT)                  // fp16 zero-point (widened where it is used)
+                    t.z2w[g] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane_off + mxqc_z2_u16(g, r) * 2, so, 0);
+                else
+                    t.z2w[g] = dw(MIXED ? mxq_z2(g, r) : mxq_w2_z2(g, r));
+                const int q = COMPACT ? mxqc_qq(g) : mxq_qq(g);     // SC / QQ: same offsets in v1 and W2G16
+                t.qq[g] = make_uint2(dw(q), dw(q + 1));
             }
+            if constexpr (MIXED) {
+                t.c4w[0] = dw(mxq_c4(0, r));
+                t.c4w[1] = dw(mxq_c4(1, r));
+            }
+            t.scw = __builtin_amdgcn_raw_buffer_load_b16(rs, lane_off + (COMPACT ? mxqc_sc_u16(r) : mxq_sc_u16(r)) * 2, so, 0);
         }
         return t;
     };
-
-    // the weight stream is started BEFORE the activations are staged, so the HBM latency of
-    // the first tile overlaps the x copy and the barrier
-    Tile cur = load_tile(wave);
+    // (the sched_barriers pin the issue order the wait counts are computed from: activations, row metadata, all of
+    // tile 0, all of tile 1, and only then the staging arithmetic -- left alone, the scheduler sinks a tile-0 load
+    // behind tile 1, and the loop's first wait then covers most of tile 1 in EVERY iteration)
     const float4 rm = rowmeta[rb * 16 + r];
+    __builtin_amdgcn_sched_barrier(0);
+    Tile T0 = load_tile(wave);
+    __builtin_amdgcn_sched_barrier(0);
+    Tile T1 = load_tile(wave + W), T2;
+    __builtin_amdgcn_sched_barrier(0);
 
-    // stage x[0..MB) in LDS (rows beyond M are zero)
-    if constexpr (PRO == 0) {
-        const int vec_per_row = K / 8;
-        for (int i = tid; i < MB * vec_per_row; i += GEMV_THREADS) {
-            const int m = i / vec_per_row, v = i % vec_per_row;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (m < M) val = *(const uint4*)(x + (int64_t)m * K + v * 8);
-            *(uint4*)(smem + (size_t)i * 16) = val;
-        }
-    } else {
-        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-        float* wsum = (float*)(smem + (size_t)K * 2);   // reduction scratch (reused by the final reduce)
-        float ss = 0.f;
-        for (int v = tid; v < K / 8; v += GEMV_THREADS) {
-            h8 a = *(const h8*)(x + v * 8);
-            if constexpr (PRO == 2) {
-                const h8 u = *(const h8*)(x + K + v * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float g = (float)a[j];
-                    a[j] = (_Float16)(g / (1.0f + __expf(-g))) * u[j];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ss += (float)a[j] * (float)a[j];
-            }
-            *(h8*)(smem + (size_t)v * 16) = a;
+    // ---- stage the activations: code-dot order + per-group fp32 sums; idle threads write to their dummy slot
+    float ss = 0.f;
+    auto stage_act = [&](int i, Act t) {
+        const bool live = i < MB * NG;                  // i = m * NG + g: rows are K * 2 = NG * 32 bytes
+        if (MB > 1 && min(i, MB * NG - 1) / NG >= M) {  // rows beyond M are staged as zeros (select, not branch)
+            const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            t.a0 = zero;
+            t.a1 = zero;
         }
         if constexpr (PRO == 1) {
+            float sq = 0.f;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            if (lane == 0) wsum[wave] = ss;
-            __syncthreads();
-            float tot = 0.f;
+            for (int j = 0; j < 8; ++j) sq += (float)t.a0[j] * (float)t.a0[j] + (float)t.a1[j] * (float)t.a1[j];
+            ss += live ? sq : 0.f;                      // (an idle thread holds a clamped copy of the last group)
 #pragma unroll
-            for (int w = 0; w < GEMV_WAVES; ++w) tot += wsum[w];
-            const float inv = rsqrtf(tot / (float)K + eps);
-            for (int v = tid; v < K / 8; v += GEMV_THREADS) {
-                h8 a = *(h8*)(smem + (size_t)v * 16);
-                const h8 g = *(const h8*)(norm_w + v * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a[j] = (_Float16)((float)a[j] * inv) * g[j];
-                *(h8*)(smem + (size_t)v * 16) = a;
+            for (int j = 0; j < 8; ++j) {
+                t.a0[j] = t.a0[j] * t.b0[j];
+                t.a1[j] = t.a1[j] * t.b1[j];
             }
         }
+        if constexpr (PRO == 2) {                      // SwiGLU: x <- fp16(silu(gate)) * up
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g0 = (float)t.a0[j], g1 = (float)t.a1[j];
+                t.a0[j] = (_Float16)(g0 / (1.0f + __expf(-g0))) * t.b0[j];
+                t.a1[j] = (_Float16)(g1 / (1.0f + __expf(-g1))) * t.b1[j];
+            }
+        }
+        float sum = 0.f;
+        const uint4 o0 = stage8(__builtin_bit_cast(uint4, t.a0), sum);
+        const uint4 o1 = stage8(__builtin_bit_cast(uint4, t.a1), sum);
+        char* dst = live ? smem + (size_t)i * 32 : dummy + lane * 32;
+        float* sdst = live ? xsum + i : (float*)(dummy + 64 * 32) + lane;
+        *(uint4*)dst = o0;
+        *(uint4*)(dst + 16) = o1;
+        *sdst = sum;
+    };
+    stage_act(tid, act0);
+    stage_act(tid + GEMV_THREADS, act1);
+    for (int i = tid + 2 * GEMV_THREADS; i < MB * NG; i += GEMV_THREADS) stage_act(i, load_act(i));   // M > 1 / odd shapes
+    if constexpr (PRO == 1) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (lane == 0) wsum[wave] = ss;
     }
     const float s4 = mxq_scale(rm.z, rm.w, (uint32_t)rm.y), z4 = rm.x;
     __syncthreads();
+    GEMV_STAMP(1)
 
-    float acc[MB];
+    // P: sum_g s_g * D'_g,  Q: sum_g s_g (1 + z_g / 4) X_g   (two-bit groups; y = 4 (P - Q))
+    // R: sum D'4 over every four-bit quarter of the row, X4: sum of their activation sums (y += 16 s4 (R - (1 + z4 / 16) X4))
+    float P[MB], Q[MB], R[MB], X4[MB];
 #pragma unroll
-    for (int m = 0; m < MB; ++m) acc[m] = 0.f;
-
-    for (int c4 = wave; c4 < NC4; c4 += GEMV_WAVES) {
-        Tile nxt = {};
-        if (c4 + GEMV_WAVES < NC4) nxt = load_tile(c4 + GEMV_WAVES);   // next tile in flight during the math
+    for (int m = 0; m < MB; ++m) P[m] = Q[m] = R[m] = X4[m] = 0.f;
+    auto compute = [&](int c4, const Tile& t) {
         const int chunk = c4 * 4 + cs;
-        if (chunk < NC) {
+        if (chunk < NC) {                               // no memory ops inside: the wait counts stay exact
             const char* xk = smem + (size_t)chunk * 128;
-            uint32_t o[8];
+            const float* xg = xsum + chunk * 4;
 #pragma unroll
             for (int g = 0; g < NG2; ++g) {
-                mxq_deq2x16(cur.c2w[g],
-                            mxq_scale(__uint_as_float(cur.qq[g].x), __uint_as_float(cur.qq[g].y),
-                                      (cur.scw >> (4 * g)) & 15u),
-                            __uint_as_float(cur.z2w[g]), o);
+                const float s = mxq_scale(__uint_as_float(t.qq[g].x), __uint_as_float(t.qq[g].y),
+                                          (t.scw >> (4 * g)) & 15u);
+                float z;
+                if constexpr (COMPACT) z = (float)__builtin_bit_cast(_Float16, (uint16_t)t.z2w[g]);
+                else z = __uint_as_float(t.z2w[g]);
+                const float sz = s * __builtin_fmaf(z, 0.25f, 1.0f);
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
                     const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + g * 32);
                     const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + g * 32 + 16);
-                    acc[m] = dot8(o, xa, acc[m]);
-                    acc[m] = dot8(o + 4, xb, acc[m]);
+                    P[m] = __builtin_fmaf(s, codedot2x16(t.c2w[g], xa, xb, 0.f), P[m]);
+                    Q[m] = __builtin_fmaf(sz, xg[m * NG + g], Q[m]);
                 }
             }
 #pragma unroll
             for (int q = 0; q < NW4 / 2; ++q) {      // 16 four-bit weights per pair of code words
-                constexpr int X0 = MIXED ? 96 : 0;   // the mixed layout's quarter is the chunk's last
-                mxq_deq4x8(cur.c4w[2 * q], s4, z4, o);
-                mxq_deq4x8(cur.c4w[2 * q + 1], s4, z4, o + 4);
+                constexpr int G0 = MIXED ? 3 : 0;    // the mixed layout's quarter is the chunk's last
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
-                    const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + X0 + q * 32);
-                    const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + X0 + q * 32 + 16);
-                    acc[m] = dot8(o, xa, acc[m]);
-                    acc[m] = dot8(o + 4, xb, acc[m]);
+                    const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + (G0 + q) * 32);
+                    const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + (G0 + q) * 32 + 16);
+                    R[m] = codedot4x8(t.c4w[2 * q], xa, R[m]);
+                    R[m] = codedot4x8(t.c4w[2 * q + 1], xb, R[m]);
+                    X4[m] += xg[m * NG + G0 + q];
                 }
             }
         }
-        cur = nxt;
+    };
+    // two tiles in flight while a third is computed; the register sets rotate by unrolling (no copies)
+    for (int c4 = wave; c4 < NC4; c4 += 3 * W) {
+        T2 = load_tile(c4 + 2 * W);
+        compute(c4, T0);
+        T0 = load_tile(c4 + 3 * W);
+        compute(c4 + W, T1);
+        T1 = load_tile(c4 + 4 * W);
+        compute(c4 + 2 * W, T2);
+    }
+    GEMV_STAMP(2)
+    float acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        acc[m] = 0.f;
+        if constexpr (NG2 > 0) acc[m] = 4.0f * (P[m] - Q[m]);
+        if constexpr (NW4 > 0) acc[m] += 16.0f * s4 * (R[m] - __builtin_fmaf(z4, 0.0625f, 1.0f) * X4[m]);
     }
 
     // reduce over the 4 chunk slots of the wave, then over waves
-    float* red = (float*)(smem + (size_t)MB * K * 2);   // [GEMV_WAVES][MB][16]
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
         float v = acc[m];
@@ -207,19 +330,27 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
         const int m = tid >> 4, rr = tid & 15;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < GEMV_WAVES; ++w) v += red[(w * MB + m) * 16 + rr];
+        for (int w = 0; w < W; ++w) v += red[(w * MB + m) * 16 + rr];
+        if constexpr (PRO == 1) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < W; ++w) tot += wsum[w];
+            v *= rsqrtf(tot / (float)K + eps);
+        }
         if (m < M) {
             _Float16 h = (_Float16)v;
             if (residual) h = __builtin_bit_cast(_Float16, residual[(int64_t)m * N + rb * 16 + rr]) + h;
             y[(int64_t)m * N + rb * 16 + rr] = __builtin_bit_cast(uint16_t, h);
         }
     }
+    GEMV_STAMP(3)
 }
 
 template <int MB, int THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED>
 int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
              const void* norm_w, float eps, const void* residual, hipStream_t stream) {
-    const size_t smem = (size_t)MB * K * 2 + (size_t)(THREADS / 64) * MB * 16 * 4;
+    constexpr int W = THREADS / 64;
+    const size_t smem = (size_t)MB * K * 2 + (size_t)MB * (K / 16) * 4 + (size_t)W * (MB * 16 + 1) * 4 + 64 * 32 + 64 * 4;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -231,25 +362,28 @@ int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, i
     return (int)hipGetLastError();
 }
 
-// Workgroup size by row-block count: every workgroup should be resident at once (a second, partial round of
-// workgroups costs a whole workgroup lifetime).  <= 384 row blocks: 16 waves (one workgroup per CU, every load of a
-// K = 4096 row block in flight at once); <= 768: 8 waves (3 per CU at ~68 VGPRs); more (fused gate|up: 1376): 4 waves
-// (7 per CU = 1792 slots), each wave then walks 4+ tiles with the next one's loads in flight.
+// Waves per workgroup by row-block count: every workgroup resident at once (~5 waves per SIMD at ~90 VGPRs), some
+// 2-3 thousand waves on the chip, each with several tiles to pipeline.  <= 384 row blocks (N = 4096): 8 waves (K = 4096:
+// 2 tiles each, all in flight from the start; K = 11008: 5-6 each); <= 768 (q|k|v): 4 waves; more (gate|up: 1376): 2.
 __host__ inline int gemv_threads(int N, int forced) {
     if (forced) return forced;
     const int rbs = N / 16;
-    return rbs <= 384 ? 1024 : rbs <= 768 ? 512 : 256;
+    return rbs <= 384 ? 512 : rbs <= 768 ? 256 : 128;
 }
+
+#define MXQ_GEMV_DISPATCH(MB, PRO, LAYOUT, TH)                                                                          \
+    ((TH) == 512   ? launch_t<MB, 512, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
+     : (TH) == 256 ? launch_t<MB, 256, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
+     : (TH) == 128 ? launch_t<MB, 128, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
+                   : (int)hipErrorInvalidValue)
 
 template <int MB, int LAYOUT = MXQ_LAYOUT_MIXED>
 int launch(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream,
            int threads = 0) {
-    switch (gemv_threads(N, threads)) {
-        case 1024: return launch_t<MB, 1024, 0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
-        case 512: return launch_t<MB, 512, 0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
-        case 256: return launch_t<MB, 256, 0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0.f, nullptr, stream);
-    }
-    return (int)hipErrorInvalidValue;
+    const void *norm_w = nullptr, *residual = nullptr;
+    const float eps = 0.f;
+    const int th = gemv_threads(N, threads);
+    return MXQ_GEMV_DISPATCH(MB, 0, LAYOUT, th);
 }
 
 template <int LAYOUT>
@@ -265,10 +399,7 @@ int launch_layout(const void* x, const void* qweight, const void* rowmeta, void*
 
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream) {
-    if (M == 1) return launch<1>(x, qweight, rowmeta, y, M, N, K, stream);
-    if (M == 2) return launch<2>(x, qweight, rowmeta, y, M, N, K, stream);
-    if (M <= 4) return launch<4>(x, qweight, rowmeta, y, M, N, K, stream);
-    return (int)hipErrorInvalidValue;
+    return launch_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, stream);
 }
 
 int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -284,18 +415,13 @@ int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* r
 
 template <int LAYOUT>
 static int fused_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K, int prologue,
-                        const void* norm_w, float eps, const void* residual, hipStream_t stream) {
-    const int th = gemv_threads(N, 0);
-#define MXQ_FUSED(PRO)                                                                                                   \
-    (th == 1024 ? launch_t<1, 1024, PRO, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)         \
-     : th == 512 ? launch_t<1, 512, PRO, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream)         \
-                 : launch_t<1, 256, PRO, LAYOUT>(x, qweight, rowmeta, y, 1, N, K, norm_w, eps, residual, stream))
+                        const void* norm_w, float eps, const void* residual, hipStream_t stream, int threads = 0) {
+    const int th = gemv_threads(N, threads), M = 1;
     switch (prologue) {
-        case 0: return MXQ_FUSED(0);
-        case 1: return MXQ_FUSED(1);
-        case 2: return MXQ_FUSED(2);
+        case 0: return MXQ_GEMV_DISPATCH(1, 0, LAYOUT, th);
+        case 1: return MXQ_GEMV_DISPATCH(1, 1, LAYOUT, th);
+        case 2: return MXQ_GEMV_DISPATCH(1, 2, LAYOUT, th);
     }
-#undef MXQ_FUSED
     return (int)hipErrorInvalidValue;
 }
 
@@ -307,7 +433,18 @@ int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* ro
 }
 
 #ifdef MXQ_PROFILING
-// A/B entry for tools/ (correct results): explicit workgroup size (256 / 512 / 1024 threads), M = 1
+// tools/gemv_stamps.py: point the kernels of THIS library at a device buffer of 4 stamps per workgroup (NULL: off),
+// and a fused one-token launch (prologue 0 / 1 / 2, explicit workgroup size or 0) through this library's kernels
+extern "C" int mxq_prof_gemv_set_stamps(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemv_stamps), &p, sizeof(p));
+}
+extern "C" int mxq_prof_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                                       int prologue, const void* norm_w, float eps, const void* residual, int threads,
+                                       void* stream) {
+    return fused_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual,
+                                          (hipStream_t)stream, threads);
+}
+// A/B entry for tools/ (correct results): explicit workgroup size (128 / 256 / 512 threads), M = 1
 extern "C" int mxq_prof_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                  int threads, void* stream) {
     if (M != 1) return -1;

@@ -6,6 +6,7 @@ would otherwise serve the replays), variants interleaved over several rounds.
     python tools/ab_gemv.py [--m 1] [--variants v1,v2:0,v2:2,v2:4] [--shapes 4096x4096,...]
 
 variants: v1 = the product GEMV (mxq_gemv_f16), v1:T = the same with T threads per workgroup (libmxq_hip_prof.so),
+lib:PATH = mxq_gemv_f16 of another build of libmxq_hip.so (repo-relative path),
 v2:T = tools/experiments/gemv2.hip with T teams per workgroup (a 16-byte-load remap that measured ~10 % SLOWER: kept
 as a record, not built by default), torch = fp16 torch matmul on the dequantised weight.  Every variant is checked against the
 fp32 product on the bit-exact dequantised weight (<= 1e-3)."""
@@ -29,6 +30,8 @@ def main():
     ap.add_argument("--variants", default="v1,v1:256,v1:512,v1:1024,torch")
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008,12288x4096,22016x4096", help="NxK list")
     ap.add_argument("--mb", type=float, default=640.0, help="distinct packed bytes per graph (MB)")
+    ap.add_argument("--repeat", type=int, default=1, help="walk the distinct weights this many times per graph (with a "
+                    "small --mb: cache-resident weights without the graph-launch overhead dominating)")
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -60,6 +63,19 @@ def main():
                 if wds is None:
                     wds = [wd] + [wd.clone() for _ in range(min(nw, int(args.mb * 1e6 / (N * K * 2)) + 1) - 1)]
                 calls = [(lambda w=w: torch.matmul(x, w.t(), out=out)) for w in wds]
+            elif v.startswith("lib:"):      # another build of the product library (e.g. abtmp/libmxq_hip_before.so)
+                other = ctypes.CDLL(os.path.join(ROOT, v[4:]))
+                fo = other.mxq_gemv_f16
+                fo.restype = ctypes.c_int
+                fo.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+
+                def mko(p):
+                    def call():
+                        rc = fo(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, N, K,
+                                torch.cuda.current_stream().cuda_stream)
+                        assert rc == 0, (v, rc)
+                    return call
+                calls = [mko(p) for p in ws]
             elif v == "v1":
                 calls = [(lambda p=p: packing.linear(x, p, out=out, path="gemv")) for p in ws]
             elif v.startswith("v1:"):
@@ -88,9 +104,10 @@ def main():
             assert err < 1e-3, (v, N, K, err)
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
-                for c in calls:
-                    c()
-            graphs[v] = (gr, len(calls))
+                for _ in range(args.repeat):
+                    for c in calls:
+                        c()
+            graphs[v] = (gr, len(calls) * args.repeat)
         ts = {v: [] for v in variants}
         for _ in range(args.rounds):
             for v in variants:
