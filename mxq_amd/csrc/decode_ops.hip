@@ -21,6 +21,14 @@ __device__ __forceinline__ uint16_t f2h(float f) {
 
 // qkv: [3 * heads * HD] fp16 (q | k | v); caches: [heads][max_ctx][HD] fp16; cos/sin: [max_ctx][HD/2] f32;
 // out: [heads * HD] fp16.  Rotate-half convention, as mxq_amd/llama_decode.py.
+//
+// The launch is latency-bound (32 workgroups, a few KB each), so what counts is the number of DEPENDENT memory round
+// trips.  Round 1's kernel had four (position -> q/k/v + cos/sin -> K rows -> V rows, ~5.6 us per layer); here
+// everything that does not need the position is issued with it: q/k/v of the head and, speculatively, the first 64
+// K rows (4 lanes per key) and the first 64 V rows (16 key groups x 4) of the cache -- rows at or beyond the position
+// are loaded (inside the allocation: clamped to max_ctx) and ignored.  Only cos/sin of the position (an L2-resident
+// table) is a second trip, and contexts beyond 64 keys continue with ordinary loads.  The new key / value take part
+// from LDS, not through the cache they are appended to.
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t* __restrict__ qkv,
                                                                   uint16_t* __restrict__ k_cache,
                                                                   uint16_t* __restrict__ v_cache,
@@ -28,14 +36,37 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
                                                                   const float* __restrict__ cos_t,
                                                                   const float* __restrict__ sin_t,
                                                                   uint16_t* __restrict__ out, int heads, int max_ctx) {
-    extern __shared__ float sm[];          // q[HD], scores[max_ctx], red[8], o2[16*HD]
+    extern __shared__ float sm[];          // q[HD], knew[HD], vnew[HD], scores[max_ctx], red[8], o2[16*HD]
     float* q_s = sm;
-    float* sc = sm + HD;
+    float* k_s = sm + HD;
+    float* v_s = sm + 2 * HD;
+    float* sc = sm + 3 * HD;
     float* red = sc + max_ctx;
     float* o2 = red + 8;
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t pos64 = *pos_p;
     const int hidden = heads * HD;
+    uint16_t* kc = k_cache + (int64_t)h * max_ctx * HD;
+    uint16_t* vc = v_cache + (int64_t)h * max_ctx * HD;
+
+    // ---- round trip 1: position, this head's q / k / v, speculative K and V rows
+    const int64_t pos64 = *pos_p;
+    const int d = tid & (HD - 1), d2 = d & (HD / 2 - 1);
+    const uint16_t* qh = qkv + h * HD;
+    const uint16_t* kh = qkv + hidden + h * HD;
+    const uint16_t q1h = qh[d2], q2h = qh[d2 + HD / 2], k1h = kh[d2], k2h = kh[d2 + HD / 2];
+    const uint16_t vh = qkv[2 * hidden + h * HD + d];
+    const int part = tid & 3, kj = tid >> 2;                   // scores: 4 lanes per key (32 dims each)
+    uint4 kspec[4];
+    {
+        const uint4* kr = (const uint4*)(kc + (int64_t)min(kj, max_ctx - 1) * HD + part * 32);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) kspec[v] = kr[v];
+    }
+    const int dg = tid & 15, kg = tid >> 4;                    // P.V: 16 key groups x 16 lanes of 8 dims
+    uint4 vspec[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vspec[i] = *(const uint4*)(vc + (int64_t)min(kg + 16 * i, max_ctx - 1) * HD + dg * 8);
+
     // Precondition (include/mxq_hip.h): 0 <= *pos < max_ctx.  The position lives in device memory (graph replay),
     // so the launcher cannot check it: a position outside the cache must neither be written to the cache nor index
     // the LDS score array.  The head's output is poisoned (NaN) instead, which the caller cannot miss downstream.
@@ -44,39 +75,48 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
         return;
     }
     const int pos = (int)pos64;
-    uint16_t* kc = k_cache + (int64_t)h * max_ctx * HD;
-    uint16_t* vc = v_cache + (int64_t)h * max_ctx * HD;
 
-    // RoPE on q and k of this head; append k, v at `pos`
+    // ---- round trip 2 (L2-resident table): cos / sin of the position; RoPE on q and k; append k, v at `pos`
     if (tid < HD) {
-        const int d = tid, d2 = d & (HD / 2 - 1);
         const float c = cos_t[(int64_t)pos * (HD / 2) + d2], s = sin_t[(int64_t)pos * (HD / 2) + d2];
-        const uint16_t* qh = qkv + h * HD;
-        const uint16_t* kh = qkv + hidden + h * HD;
-        const float q1 = h2f(qh[d2]), q2 = h2f(qh[d2 + HD / 2]);
-        const float k1 = h2f(kh[d2]), k2 = h2f(kh[d2 + HD / 2]);
+        const float q1 = h2f(q1h), q2 = h2f(q2h), k1 = h2f(k1h), k2 = h2f(k2h);
         const float qr = d < HD / 2 ? q1 * c - q2 * s : q2 * c + q1 * s;
         const float kr = d < HD / 2 ? k1 * c - k2 * s : k2 * c + k1 * s;
         q_s[d] = h2f(f2h(qr));                       // the fp16 rounding the torch path applies
-        kc[(int64_t)pos * HD + d] = f2h(kr);
-        vc[(int64_t)pos * HD + d] = qkv[2 * hidden + h * HD + d];
+        const uint16_t krh = f2h(kr);
+        k_s[d] = h2f(krh);
+        v_s[d] = h2f(vh);
+        kc[(int64_t)pos * HD + d] = krh;
+        vc[(int64_t)pos * HD + d] = vh;
     }
     __syncthreads();
 
-    // scores: 4 lanes per key (32 dims each)
+    // scores: 4 lanes per key (32 dims each); key j < pos from the cache (the first 64 already in registers), key pos
+    // from LDS
     const float scale = rsqrtf((float)HD);
-    const int part = tid & 3;
-    for (int j = tid >> 2; j <= pos; j += ATT_THREADS / 4) {
-        const uint4* kr = (const uint4*)(kc + (int64_t)j * HD + part * 32);
+    for (int j = kj; j <= pos; j += ATT_THREADS / 4) {
         float acc = 0.f;
+        if (j == pos) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const uint4 w = kr[v];
-            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+            for (int e = 0; e < 32; ++e) acc += q_s[part * 32 + e] * k_s[part * 32 + e];
+        } else {
+            uint4 kw[4];
+            if (j == kj) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc += q_s[part * 32 + v * 8 + 2 * e] * h2f((uint16_t)(ws[e] & 0xFFFF));
-                acc += q_s[part * 32 + v * 8 + 2 * e + 1] * h2f((uint16_t)(ws[e] >> 16));
+                for (int v = 0; v < 4; ++v) kw[v] = kspec[v];
+            } else {
+                const uint4* kr = (const uint4*)(kc + (int64_t)j * HD + part * 32);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) kw[v] = kr[v];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const uint32_t ws[4] = {kw[v].x, kw[v].y, kw[v].z, kw[v].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc += q_s[part * 32 + v * 8 + 2 * e] * h2f((uint16_t)(ws[e] & 0xFFFF));
+                    acc += q_s[part * 32 + v * 8 + 2 * e + 1] * h2f((uint16_t)(ws[e] >> 16));
+                }
             }
         }
         acc += __shfl_xor(acc, 1, 64);
@@ -108,18 +148,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
 
     // out[d] = sum_j p_j * V[j][d]: 16 key groups x 16 lanes of 8 dims (one 256-B V row per 16 lanes and load);
     // a thread walks keys kg, kg + 16, ... so position 64 is 4 iterations deep instead of 32
-    const int dg = tid & 15, kg = tid >> 4;
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    for (int j = kg; j <= pos; j += 16) {
+    for (int j = kg, i = 0; j <= pos; j += 16, ++i) {
         const float p = h2f(f2h(sc[j] * inv));
-        const uint4 w = *(const uint4*)(vc + (int64_t)j * HD + dg * 8);
-        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        if (j == pos) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o[2 * e] += p * h2f((uint16_t)(ws[e] & 0xFFFF));
-            o[2 * e + 1] += p * h2f((uint16_t)(ws[e] >> 16));
+            for (int e = 0; e < 8; ++e) o[e] += p * v_s[dg * 8 + e];
+        } else {
+            uint4 w;
+            if (i < 4) w = i == 0 ? vspec[0] : i == 1 ? vspec[1] : i == 2 ? vspec[2] : vspec[3];
+            else w = *(const uint4*)(vc + (int64_t)j * HD + dg * 8);
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[2 * e] += p * h2f((uint16_t)(ws[e] & 0xFFFF));
+                o[2 * e + 1] += p * h2f((uint16_t)(ws[e] >> 16));
+            }
         }
     }
 #pragma unroll
@@ -161,7 +207,7 @@ int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, co
                                const void* sin_t, void* out, int heads, int head_dim, int max_ctx,
                                hipStream_t stream) {
     if (head_dim != HD) return (int)hipErrorInvalidValue;
-    const size_t smem = (size_t)(HD + max_ctx + 8 + 16 * HD) * 4;
+    const size_t smem = (size_t)(3 * HD + max_ctx + 8 + 16 * HD) * 4;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)smem);
