@@ -45,12 +45,13 @@ __device__ __forceinline__ void quant_vec(const float (&v)[T::VEC], float alpha,
     bool slow = !T::HAS_FAST_DIV;
     if constexpr (T::HAS_FAST_DIV) {
         const float r = __builtin_amdgcn_rcpf(e);
+        uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             xn[j] = xs[j] * r;
-            slow |= T::near_boundary(xn[j]);
+            key = min(key, T::boundary_key(xn[j]));
         }
-        slow = __any(slow);
+        slow = __any(key < T::KEY_LIMIT);
     }
     if (slow) {
 #pragma unroll
@@ -80,6 +81,9 @@ __device__ __forceinline__ void quant_vec(const float (&v)[T::VEC], float alpha,
 // its 16-B loads in flight, the 4-bit-arm min/max comes from registers (combined across the row's waves
 // through LDS when WPR > 1) and so do the group min/max; then everything is quantised and stored.  HBM sees
 // exactly one read and one write per element and no second pass exists.
+// (Round 2 tried to overlap a wave's arithmetic with the next row's loads -- a second register set, then an LDS-DMA
+// prefetch: both slower, profiles/r02_fakequant_pipe_ab.txt.  At ~30 VALU ops per element the kernel is co-limited
+// by VALU issue and HBM, and occupancy is worth more than the prefetch.)
 template <typename T, bool FASTQ, int NI, int WPR>
 __global__ __launch_bounds__(256) void mxq_fakequant_fwd_reg_kernel(const void* __restrict__ w,
                                                                     void* __restrict__ out, int rows, int cols,
@@ -100,15 +104,27 @@ __global__ __launch_bounds__(256) void mxq_fakequant_fwd_reg_kernel(const void* 
         raw[i] = make_uint4(0, 0, 0, 0);
         if (active && e0 < part) raw[i] = T::load_raw(w, base + e0);
     }
+    // min / max of every 16-column group (kept for the quantisation below); the 4-bit arm's row-wide min / max is the
+    // min / max over the groups of the is4 lanes -- no separate pass over the row
+    float gmn[NI], gmx[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int e0 = (i * 64 + lane) * VEC;
-        if (active && e0 < part && is4) {
-            float t[VEC];
-            T::unpack(raw[i], t);
+        float t[VEC];
+        T::unpack(raw[i], t);
+        float mn = t[0], mx = t[0];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { mn4 = fminf(mn4, t[j]); mx4 = fmaxf(mx4, t[j]); }
+        for (int j = 1; j < VEC; ++j) { mn = fminf(mn, t[j]); mx = fmaxf(mx, t[j]); }
+#pragma unroll
+        for (int o = 1; o < LPG; o <<= 1) {
+            mn = fminf(mn, __shfl_xor(mn, o, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         }
+        gmn[i] = mn;
+        gmx[i] = mx;
+        const bool in4 = active && e0 < part && is4;
+        mn4 = fminf(mn4, in4 ? mn : INFINITY);
+        mx4 = fmaxf(mx4, in4 ? mx : -INFINITY);
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -137,14 +153,7 @@ __global__ __launch_bounds__(256) void mxq_fakequant_fwd_reg_kernel(const void* 
         if (e0 < part) {   // a 16-column group is never split by the part end (part % 64 == 0)
             float vi[VEC];
             T::unpack(raw[i], vi);
-            float mn = vi[0], mx = vi[0];
-#pragma unroll
-            for (int j = 1; j < VEC; ++j) { mn = fminf(mn, vi[j]); mx = fmaxf(mx, vi[j]); }
-#pragma unroll
-            for (int o = 1; o < LPG; o <<= 1) {
-                mn = fminf(mn, __shfl_xor(mn, o, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            }
+            const float mn = gmn[i], mx = gmx[i];
             float o[VEC];
             quant_vec<T, FASTQ>(vi, is4 ? alpha4 : T::rnd(mx - mn), is4 ? mn4 : mn, is4 ? 15.0f : L2, o);
             T::store(out, base + e0, o);

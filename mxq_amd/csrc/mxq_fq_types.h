@@ -12,12 +12,17 @@ struct F32 {
     __device__ static __forceinline__ float rnd(float x) { return x; }
     __device__ static __forceinline__ void rnd2(float&, float&) {}
     __device__ static __forceinline__ bool near_boundary(float) { return true; }
+    __device__ static __forceinline__ uint32_t boundary_key(float) { return 0u; }
+    static constexpr uint32_t KEY_LIMIT = 1u;
     static constexpr bool HAS_FAST_DIV = false;   // fp32 results are not re-rounded: always the IEEE divide
     __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const float*)p + e); }
     __device__ static __forceinline__ void unpack(const uint4 a, float v[4]) {
         v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.y); v[2] = __uint_as_float(a.z); v[3] = __uint_as_float(a.w);
     }
     __device__ static __forceinline__ void load(const void* p, int64_t e, float v[4]) { unpack(load_raw(p, e), v); }
+    __device__ static __forceinline__ uint4 pack(const float v[4]) {
+        return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    }
     __device__ static __forceinline__ void store(void* p, int64_t e, const float v[4]) {
         *(float4*)((float*)p + e) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -43,6 +48,10 @@ struct BF16 {
     __device__ static __forceinline__ bool near_boundary(float a) {
         return ((__float_as_uint(a) + 0x8004u) & 0xFFF8u) == 0u;   // low 16 bits in [0x7FFC, 0x8003]
     }
+    // the same test as an unsigned key that can be min-reduced over many values before ONE compare:
+    // near_boundary(a)  <=>  boundary_key(a) < KEY_LIMIT   (one v_lshl_add_u32 per value, one v_min3_u32 per two)
+    __device__ static __forceinline__ uint32_t boundary_key(float a) { return (__float_as_uint(a) << 16) + 0x80040000u; }
+    static constexpr uint32_t KEY_LIMIT = 0x00080000u;
     static constexpr bool HAS_FAST_DIV = true;
     __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const uint16_t*)p + e); }
     __device__ static __forceinline__ void unpack(const uint4 a, float v[8]) {
@@ -54,12 +63,15 @@ struct BF16 {
         }
     }
     __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) { unpack(load_raw(p, e), v); }
-    __device__ static __forceinline__ void store(void* p, int64_t e, const float v[8]) {
+    __device__ static __forceinline__ uint4 pack(const float v[8]) {      // values already rounded to bf16
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             w[i] = (__float_as_uint(v[2 * i]) >> 16) | (__float_as_uint(v[2 * i + 1]) & 0xFFFF0000u);
-        *(uint4*)((uint16_t*)p + e) = make_uint4(w[0], w[1], w[2], w[3]);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __device__ static __forceinline__ void store(void* p, int64_t e, const float v[8]) {
+        *(uint4*)((uint16_t*)p + e) = pack(v);
     }
 };
 
@@ -74,6 +86,8 @@ struct F16 {
         const uint32_t u = __float_as_uint(a);                          // fp16-subnormal range
         return ((u & 0x1FFFu) - 0x0FFCu) < 8u || !(a == 0.0f || (a > 6.2e-5f && a < 6.0e4f));
     }
+    __device__ static __forceinline__ uint32_t boundary_key(float a) { return near_boundary(a) ? 0u : 0xFFFFFFFFu; }
+    static constexpr uint32_t KEY_LIMIT = 1u;
     static constexpr bool HAS_FAST_DIV = true;
     __device__ static __forceinline__ uint4 load_raw(const void* p, int64_t e) { return *(const uint4*)((const uint16_t*)p + e); }
     __device__ static __forceinline__ void unpack(const uint4 r, float v[8]) {
@@ -83,12 +97,15 @@ struct F16 {
         for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
     }
     __device__ static __forceinline__ void load(const void* p, int64_t e, float v[8]) { unpack(load_raw(p, e), v); }
-    __device__ static __forceinline__ void store(void* p, int64_t e, const float v[8]) {
+    __device__ static __forceinline__ uint4 pack(const float v[8]) {
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
         h8 a;
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = (_Float16)v[i];
-        *(h8*)((uint16_t*)p + e) = a;
+        return __builtin_bit_cast(uint4, a);
+    }
+    __device__ static __forceinline__ void store(void* p, int64_t e, const float v[8]) {
+        *(uint4*)((uint16_t*)p + e) = pack(v);
     }
 };
 
