@@ -392,6 +392,62 @@ def test_gemv_vs_oracle(dev, M, N, K):
     _check_gemm(y, O.linear_ref(x.numpy(), w16), f"gemv {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 16, 64), (4, 16, 64), (1, 48, 192), (3, 6144, 64), (2, 32, 1088), (4, 4096, 11008),
+                                   (1, 22016, 4096), (4, 12288, 4096)])
+@pytest.mark.parametrize("compact", [False, True])
+def test_gemv_pipeline_edge_shapes(dev, M, N, K, compact):
+    """Shapes that stress the GEMV's control structure rather than its arithmetic: one chunk (K = 64: every wave but the
+    first walks only out-of-range tiles), ragged tiles (K = 192: 3 chunks; K = 1088: 17), more staging steps than the
+    two that are hoisted (4 tokens x K = 11008 on 512 threads), every workgroup size (N = 16 .. 22016), both metadata
+    modes.  Reference: fp32 product on the kernel-dequantised weight (bit-exact vs the oracle in other tests)."""
+    from mxq_amd import packing
+    g = torch.Generator(device=dev).manual_seed(M * 5 + N + K)
+    p = packing.quantize_pack((torch.randn(N, K, generator=g, device=dev) * 0.02).half(), compact_meta=compact)
+    wd = packing.dequant(p).float()
+    x = torch.randn(M, K, generator=g, device=dev).half()
+    y = packing.linear(x, p, path="gemv").float()
+    ref = x.float() @ wd.t()
+    assert ((y - ref).abs().max() / ref.abs().max()).item() <= REL_TOL
+    x[M - 1, K - 1] = float("nan")          # a NaN stays in its own token's row
+    y2 = packing.linear(x, p, path="gemv").float()
+    assert torch.isnan(y2[M - 1]).all() and (M == 1 or torch.equal(y2[: M - 1], y[: M - 1]))
+
+
+@pytest.mark.parametrize("pos", [0, 1, 15, 16, 63, 64, 65, 130, 255])
+def test_attn_decode_kernel_across_the_prefetched_rows(dev, pos):
+    """csrc/decode_ops.hip loads the first 64 K / V rows of the cache speculatively together with the position and
+    walks the rest with ordinary loads; the new key / value take part from LDS.  Positions on both sides of every
+    boundary (0, 16-row V groups, 64, deep contexts, the cache's last row) against a torch restatement."""
+    from mxq_amd import _lib
+    heads, hd, ctx = 4, 128, 256
+    g = torch.Generator(device=dev).manual_seed(pos)
+    qkv = torch.randn(3 * heads * hd, generator=g, device=dev).half()
+    kc = torch.randn(heads, ctx, hd, generator=g, device=dev).half()
+    vc = torch.randn(heads, ctx, hd, generator=g, device=dev).half()
+    kc0, vc0 = kc.clone(), vc.clone()
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    ang = torch.arange(ctx, device=dev).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    posd = torch.tensor([pos], dtype=torch.int64, device=dev)
+    out = torch.empty(heads * hd, dtype=torch.float16, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.mxq_attn_decode_f16(qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), posd.data_ptr(), cos.data_ptr(),
+                                       sin.data_ptr(), out.data_ptr(), heads, hd, ctx,
+                                       torch.cuda.current_stream().cuda_stream), "mxq_attn_decode_f16")
+    q, k, v = (qkv[j * heads * hd:(j + 1) * heads * hd].view(heads, hd).float() for j in range(3))
+
+    def rope(t):
+        t1, t2 = t[:, : hd // 2], t[:, hd // 2:]
+        return torch.cat([t1 * cos[pos] - t2 * sin[pos], t2 * cos[pos] + t1 * sin[pos]], -1)
+    qr, kr = rope(q).half().float(), rope(k).half()
+    kref, vref = kc0.clone(), vc0.clone()
+    kref[:, pos], vref[:, pos] = kr, v.half()
+    assert torch.equal(kc, kref) and torch.equal(vc, vref)            # exactly one row appended, nothing else touched
+    att = (qr[:, None, :] @ kref[:, : pos + 1].float().transpose(1, 2) / hd ** 0.5).half().float().softmax(-1)
+    want = (att.half().float() @ vref[:, : pos + 1].float()).reshape(-1)
+    assert ((out.float() - want).abs().max() / want.abs().max()).item() < 4e-3
+
+
 @pytest.mark.parametrize("M", [1, 5, 8, 16, 17, 32])
 @pytest.mark.parametrize("N,K", [(64, 256), (256, 704), (4096, 4096), (11008, 4096), (4096, 11008)])
 @pytest.mark.parametrize("compact", [False, True])
