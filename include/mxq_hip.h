@@ -182,6 +182,14 @@ int mxq_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, 
 int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                         const void* sin_t, void* out, int heads, int head_dim, int max_ctx, void* stream);
 
+/* Decode-harness glue (BASELINE config 3), not part of the reference's hot path: final RMSNorm + the fp16 lm_head
+ * Linear + greedy argmax of ONE token.  h fp16[K], norm_w fp16[K], w fp16[V, K] (row-major nn.Linear weight), K = 4096;
+ * the normalised row is fp16(h * rsqrt(mean h^2 + eps)) * norm_w, a logit the fp32 dot rounded to fp16, the result
+ * the lowest index of the largest logit (NaN logits never win), written to *token (int64, device).  part: scratch of
+ * part_slots * 8 bytes (>= 256 slots recommended; fewer slots = fewer workgroups). */
+int mxq_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
+                          int part_slots, void* token, void* stream);
+
 /* Decode-harness glue, no reference counterpart: a loads-only pass over [p, p + bytes) (p 16-byte aligned; the tail
  * bytes % 16 is skipped) that pulls the range through the memory-side Infinity Cache.  Launched on a side stream
  * under the current GEMV, it keeps the HBM streaming while that GEMV is in its arithmetic phase, and the NEXT GEMV

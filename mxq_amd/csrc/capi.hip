@@ -142,6 +142,14 @@ int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const voi
                                       (hipStream_t)stream);
 }
 
+int mxq_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
+                          int part_slots, void* token, void* stream) {
+    if (!h || !norm_w || !w || !part || !token) return MXQ_E_NULL;
+    if (V <= 0 || K != 4096 || part_slots < 1) return MXQ_E_SHAPE;
+    if (!aligned16(h) || !aligned16(norm_w) || !aligned16(w)) return MXQ_E_ALIGN;
+    return mxq_launch_lmhead_argmax_f16(h, norm_w, eps, w, V, K, part, part_slots, token, (hipStream_t)stream);
+}
+
 int mxq_prefetch(const void* p, size_t bytes, int workgroups, void* sink, void* stream) {
     if (!p) return MXQ_E_NULL;
     if (((uintptr_t)p & 15) != 0) return MXQ_E_ALIGN;

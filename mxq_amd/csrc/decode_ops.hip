@@ -179,6 +179,89 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
     }
 }
 
+// Final RMSNorm + lm_head (a plain fp16 Linear in the reference: MXQ quantises the decoder Linears only) + greedy
+// argmax for ONE token, as two launches: (1) every workgroup normalises the hidden state like the torch path does
+// (fp16(x * rsqrt(mean x^2 + eps)) * norm_w, one fp16 multiply), keeps it in registers -- a lane owns the same 64
+// of the K = 4096 columns for every row -- and streams its share of the [V, K] fp16 weight, one wave per row, 8 KiB
+// of loads in flight per wave; a logit is the fp32 dot rounded to fp16 (what F.linear returns); the running best
+// (value, lowest index) per wave, then per workgroup, goes to a small partial buffer; (2) one wave reduces the
+// partials and writes the token id.  Replaces ~12 small torch launches (124 us of a 1.53 ms token).
+constexpr int LMH_THREADS = 256, LMH_K = 4096;
+__global__ __launch_bounds__(LMH_THREADS) void lmhead_argmax_kernel(const uint16_t* __restrict__ h,
+                                                                    const uint16_t* __restrict__ norm_w, float eps,
+                                                                    const uint16_t* __restrict__ w, int V,
+                                                                    float* __restrict__ part_val,
+                                                                    int* __restrict__ part_idx) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    __shared__ float bval[4];
+    __shared__ int bidx[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the lane's 64 columns: 8 chunks of 8 at k = 512 i + 8 lane
+    h8 x[8], g[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        x[i] = *(const h8*)(h + i * 512 + lane * 8);
+        g[i] = *(const h8*)(norm_w + i * 512 + lane * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += (float)x[i][j] * (float)x[i][j];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = rsqrtf(ss / (float)LMH_K + eps);      // every wave holds the whole row: no cross-wave step
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[i][j] = (_Float16)((float)x[i][j] * inv) * g[i][j];
+
+    float best = -INFINITY;
+    int besti = 0x7FFFFFFF;
+    const int stride = gridDim.x * 4;
+    for (int row = blockIdx.x * 4 + wave; row < V; row += stride) {
+        const uint16_t* wr = w + (int64_t)row * LMH_K + lane * 8;
+        h8 wv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wv[i] = *(const h8*)(wr + i * 512);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc = __builtin_amdgcn_fdot2((h2){wv[i][2 * j], wv[i][2 * j + 1]}, (h2){x[i][2 * j], x[i][2 * j + 1]}, acc, false);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        const float logit = (float)(_Float16)acc;           // F.linear's fp16 output
+        if (logit > best || (logit == best && row < besti)) { best = logit; besti = row; }   // (a NaN logit never wins)
+    }
+    if (lane == 0) { bval[wave] = best; bidx[wave] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (bval[k] > best || (bval[k] == best && bidx[k] < besti)) { best = bval[k]; besti = bidx[k]; }
+        part_val[blockIdx.x] = best;
+        part_idx[blockIdx.x] = besti;
+    }
+}
+__global__ __launch_bounds__(64) void lmhead_final_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
+                                                          int n, int64_t* __restrict__ token) {
+    const int lane = threadIdx.x;
+    float best = -INFINITY;
+    int besti = 0x7FFFFFFF;
+    for (int i = lane; i < n; i += 64) {
+        const float v = part_val[i];
+        const int ix = part_idx[i];
+        if (v > best || (v == best && ix < besti)) { best = v; besti = ix; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float v = __shfl_xor(best, o, 64);
+        const int ix = __shfl_xor(besti, o, 64);
+        if (v > best || (v == best && ix < besti)) { best = v; besti = ix; }
+    }
+    if (lane == 0) *token = besti == 0x7FFFFFFF ? 0 : besti;
+}
+
 // Infinity-Cache prefetch: a loads-only pass over a byte range.  The decode GEMVs are a chain of dependent launches
 // that each spend part of their time in arithmetic with the HBM idle; a prefetch of the NEXT launches' weights, running
 // on a side stream under the current one, keeps the HBM streaming and leaves the weights in the 256 MiB memory-side
@@ -196,6 +279,21 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__
 }
 
 }   // namespace
+
+int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
+                                 int part_slots, void* token, hipStream_t stream) {
+    if (K != LMH_K) return (int)hipErrorInvalidValue;
+    int wgs = (V + 3) / 4;
+    if (wgs > part_slots) wgs = part_slots;
+    if (wgs > 1024) wgs = 1024;        // 4 workgroups per CU: 16 waves x 8 KiB in flight
+    if (wgs < 1) return (int)hipErrorInvalidValue;
+    float* pv = (float*)part;
+    int* pi = (int*)(pv + part_slots);
+    lmhead_argmax_kernel<<<wgs, LMH_THREADS, 0, stream>>>((const uint16_t*)h, (const uint16_t*)norm_w, eps,
+                                                          (const uint16_t*)w, V, pv, pi);
+    lmhead_final_kernel<<<1, 64, 0, stream>>>(pv, pi, wgs, (int64_t*)token);
+    return (int)hipGetLastError();
+}
 
 int mxq_launch_prefetch(const void* p, size_t bytes, int workgroups, void* sink, hipStream_t stream) {
     if (bytes < 16) return 0;

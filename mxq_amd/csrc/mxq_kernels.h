@@ -47,6 +47,8 @@ int mxq_launch_uniform_expand(const void* qweight, const void* rowmeta, void* w1
 int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
                               int prologue, const void* norm_w, float eps, const void* residual, int compact,
                               hipStream_t stream);
+int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
+                                 int part_slots, void* token, hipStream_t stream);
 int mxq_launch_prefetch(const void* p, size_t bytes, int workgroups, void* sink, hipStream_t stream);
 int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                                const void* sin_t, void* out, int heads, int head_dim, int max_ctx,

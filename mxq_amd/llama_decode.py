@@ -88,6 +88,8 @@ class DecodeStage:
         if last:
             self.lm_head = (torch.randn(vocab, hidden, generator=g, device=dev) * 0.02).half()   # plain fp16 Linear
         self._graph = None
+        self._head_ws = None
+        self._head_tok = None
         self._h_in = torch.zeros(1, hidden, device=dev, dtype=torch.float16)
         self._h_out = torch.zeros(1, hidden, device=dev, dtype=torch.float16)
 
@@ -108,6 +110,19 @@ class DecodeStage:
         return self.embed.index_select(0, tok)
 
     def head(self, h):
+        """Final RMSNorm + lm_head + greedy argmax -> token id tensor [1] (int64).  Fused stages of Llama width run it
+        as one native launch pair (csrc/decode_ops.hip, mxq_lmhead_argmax_f16); otherwise plain torch ops."""
+        if self.fused and self.hidden == 4096 and h.shape[0] == 1:
+            if self._head_ws is None:
+                self._head_ws = torch.empty(2 * 1024, dtype=torch.float32, device=self.dev)
+                self._head_tok = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            hc = h.contiguous()
+            lib = _lib.load()
+            _lib.check(lib.mxq_lmhead_argmax_f16(hc.data_ptr(), self.norm_w.data_ptr(), 1e-5, self.lm_head.data_ptr(),
+                                                 self.lm_head.shape[0], self.hidden, self._head_ws.data_ptr(), 1024,
+                                                 self._head_tok.data_ptr(),
+                                                 torch.cuda.current_stream(self.dev).cuda_stream), "mxq_lmhead_argmax_f16")
+            return self._head_tok
         logits = torch.nn.functional.linear(self._rms(h), self.lm_head)
         return logits.argmax(dim=-1)
 

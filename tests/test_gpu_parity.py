@@ -413,6 +413,38 @@ def test_gemv_pipeline_edge_shapes(dev, M, N, K, compact):
     assert torch.isnan(y2[M - 1]).all() and (M == 1 or torch.equal(y2[: M - 1], y[: M - 1]))
 
 
+@pytest.mark.parametrize("V", [32000, 1000, 7])
+def test_lmhead_argmax_matches_the_torch_head(dev, V):
+    """csrc/decode_ops.hip: final RMSNorm + fp16 lm_head + greedy argmax in one launch pair against the torch ops it
+    replaces (same roundings: fp16(x * inv) * g, fp32 dot -> fp16 logit, lowest index on ties).  The two may only
+    differ where the top two fp16 logits are adjacent (another summation order): then either is accepted."""
+    from mxq_amd import _lib
+    K = 4096
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(V)
+    w = (torch.randn(V, K, generator=g, device=dev) * 0.02).half()
+    gw = (1.0 + 0.1 * torch.randn(K, generator=g, device=dev)).half()
+    part = torch.empty(2 * 1024, dtype=torch.float32, device=dev)
+    tok = torch.zeros(1, dtype=torch.int64, device=dev)
+    for it in range(6):
+        h = torch.randn(1, K, generator=g, device=dev).half() * (0.5 + it)
+        if it == 5:                                       # an exact tie: two identical rows -> the lower index
+            w[V - 1] = w[V // 2]
+        _lib.check(lib.mxq_lmhead_argmax_f16(h.data_ptr(), gw.data_ptr(), 1e-5, w.data_ptr(), V, K, part.data_ptr(), 1024,
+                                             tok.data_ptr(), torch.cuda.current_stream().cuda_stream), "mxq_lmhead_argmax_f16")
+        hf = h.float()
+        xn = (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-5)).half() * gw
+        logits = (xn.float() @ w.float().t()).half()[0]
+        want = int(logits.argmax())
+        got = int(tok.item())
+        assert 0 <= got < V
+        if got != want:
+            top = logits.float().topk(2).values
+            assert logits[got].float() >= top[1] and (top[0] - top[1]) <= top[0].abs() * 2 ** -9, (got, want)
+        if it == 5:
+            assert got != V - 1
+
+
 @pytest.mark.parametrize("pos", [0, 1, 15, 16, 63, 64, 65, 130, 255])
 def test_attn_decode_kernel_across_the_prefetched_rows(dev, pos):
     """csrc/decode_ops.hip loads the first 64 K / V rows of the cache speculatively together with the position and
