@@ -13,13 +13,15 @@
 //     range check) -- no VALU work in the loop at all.  (Round 1's kernel put the 2-bit dequant, ~48 VALU ops per
 //     K-step, INSIDE the MFMA waves' instruction streams: an in-order wave that carries VALU chains between its
 //     MFMAs stalls its MFMAs on them, and both MFMA waves of a SIMD do so in lockstep.)
-//   * waves 8-11 "dequant waves" (one per SIMD): the packed blocks' LDS-DMA (2 per wave and K-step) and the whole
-//     dequant of chunk t+1 (2-bit LUT / v_perm groups and the 4-bit arm) into the fp16 W16 tile, from packed words
-//     read out of the LDS copy one K-step earlier.  Their VALU ops fill the vector-issue slots the MFMAs leave
-//     free, in no fixed order relative to them; they run at raised issue priority (the dequant chain is the longer
-//     one of a K-step) and with scalar fp32 ops (no SLP packing: Makefile).
-//   * one raw s_barrier per K-step; x ring 3 slots (DMA two steps ahead, counted vmcnt), packed ring 4 slots, W16
-//     double buffer: 146 KiB of LDS.  D^T = W . x^T: a lane owns 4 consecutive channels of a token.
+//   * waves 8-11 "dequant waves" (one per SIMD): the whole dequant (2-bit LUT / v_perm groups and the 4-bit arm)
+//     into the fp16 W16 tile.  The packed words come straight from global memory into registers (6-7 dword loads
+//     per thread and chunk through the tile's buffer descriptor), a GROUP of 3 chunks at a time; a burst converts the
+//     whole group into result registers and issues the next group's loads, the 3 K-steps after it only write one
+//     chunk each into the W16 double buffer (deq_segment_h: why bursts).  Raised issue priority, scalar fp32 ops
+//     (no SLP packing: Makefile).
+//   * one raw s_barrier per K-step; x ring 3 slots (DMA two steps ahead, counted vmcnt), W16 double buffer
+//     (hoisted-dequant mode: a 3-slot ring of fp16 weight tiles instead): 144 KiB of LDS.  D^T = W . x^T: a lane
+//     owns 4 consecutive channels of a token.
 //   * the output leaves without an LDS round trip (store_tile_xpose), so a workgroup that runs several tiles issues
 //     the next tile's first DMAs behind the last barrier of this one and they fly under its epilogue.
 //
@@ -51,17 +53,13 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 256, BN = 128, BK = 64;
 constexpr int N_MMA = 8, N_DEQ = 4, THREADS = (N_MMA + N_DEQ) * 64;
 constexpr int A_STAGE = BM * BK * 2, A_SLOTS = 3;
-constexpr int BP_BLK = MXQ_BLK_BYTES;            // 576 B: stride of 144 dwords keeps blocks on distinct banks
-constexpr int BP_STAGE = (BN / 16) * BP_BLK, BP_SLOTS = 4;
 constexpr int W_STAGE = BN * BK * 2;
 constexpr int OFF_A = 0;
-constexpr int OFF_BP = OFF_A + A_SLOTS * A_STAGE;
-constexpr int OFF_W = (OFF_BP + BP_SLOTS * BP_STAGE + 255) / 256 * 256;
-constexpr int SMEM_BYTES = OFF_W + 2 * W_STAGE;
-static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
-// hoisted-dequant mode: the packed ring and the W16 double buffer make room for a 3-slot ring of fp16 weight tiles
-constexpr int OFF_WD = OFF_BP, WD_SLOTS = 3;
-static_assert(OFF_WD + WD_SLOTS * W_STAGE <= SMEM_BYTES, "dense weight ring fits the same LDS");
+constexpr int OFF_W = OFF_A + A_SLOTS * A_STAGE;
+// hoisted-dequant mode: a 3-slot ring of fp16 weight tiles in the place of the W16 double buffer
+constexpr int OFF_WD = OFF_W, WD_SLOTS = 3;
+constexpr int SMEM_BYTES = OFF_WD + WD_SLOTS * W_STAGE;
+static_assert(OFF_W + 2 * W_STAGE <= SMEM_BYTES && SMEM_BYTES <= 160 * 1024, "LDS budget");
 constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K] matrix (never part of the C ABI)
 
 // profiling-only switches (template parameter ABL; product build = 0)
@@ -430,106 +428,120 @@ __device__ __forceinline__ void sk_finish(const SkSeg& sk, int j, int NT_tile, i
 // ------------------------------------------------------------------------------------------------
 struct Deq {
     char* smem;
-    rsrc_t rsrc;          // this tile's 8 row-blocks of packed weights (range-checked at the N edge)
-    uint32_t voff[2];     // lane's 16-B piece inside row-block 2d + b of the tile (the range check is on this offset:
-                          // a row-block beyond the weight's last one reads as zeros, whatever the K offset)
+    rsrc_t rsrc;          // the WHOLE packed weight (one descriptor per launch: a per-tile one would have to be
+                          // selected between tiles, and a selected descriptor lives in VGPRs -- a waterfall loop around
+                          // every load).  Row-blocks are the outermost dimension, so a row-block beyond the weight's
+                          // last one lies beyond the buffer: zeros, whatever the K offset
+    uint32_t voff_blk;    // byte offset of the thread's row-block inside the packed weight; 0x80000000 = nothing to
+                          // load (the range check is on this offset; launcher: the weight is smaller than 2^31 bytes)
     uint32_t k0;          // byte offset of the segment's first K-step inside a row-block's run
     int d, lane, NT;
     int row, r, h;        // W row of this thread (0..127), its row inside the block, column half (wave-uniform)
-    int off_blk;          // byte offset of the row's block inside a packed slot
     float s4, z4;
     float4 rm;            // the row's 4-bit-arm parameters as loaded (rowmeta)
 };
-
-template <int LAYOUT>
-__device__ __forceinline__ void issue_bp(const Deq& c, int t) {
-    // dequant wave d copies packed blocks 2d, 2d+1 (rows 32d .. 32d+31), 36 lanes each (32 for W4ROW);
-    // the LDS stride stays 576 B for every layout (bank-conflict-free block spacing)
-    constexpr int BYTES = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : LAYOUT == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
-    char* dst = c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.d * 2 * BP_BLK;
-    if (c.lane < BYTES / 16) {
-        const uint32_t so = c.k0 + (uint32_t)t * BYTES;
-        bufdma16(c.rsrc, c.voff[0], so, dst);
-        bufdma16(c.rsrc, c.voff[1], so, dst + BP_BLK);
-    }
-}
 
 __device__ __forceinline__ void put8(char* wt, int row, int slot, const uint32_t* o) {
     *(u32x4*)(wt + swz(row, slot)) = (u32x4){o[0], o[1], o[2], o[3]};
 }
 
-// The packed words one thread needs for one chunk, read from the LDS copy ONE K-step before they are used, so that
-// the dequant arithmetic never waits for an LDS read.  h = 0: 2-bit groups 0, 1 (columns 0..31); h = 1: group 2 and
-// the 4-bit quarter (columns 32..63).  W2G16: h = 0 groups 0, 1; h = 1 groups 2, 3.  W4ROW: 4 code words each.
+// The packed words one thread needs for one chunk.  h = 0: 2-bit groups 0, 1 (columns 0..31); h = 1: group 2 and the
+// 4-bit quarter (columns 32..63).  W2G16: h = 0 groups 0, 1; h = 1 groups 2, 3.  W4ROW: 4 code words each.
 struct Pk {
     uint32_t c[4];    // code words
-    uint32_t z[2];    // 2-bit zero-points (fp32 bits)
+    uint32_t z[2];    // 2-bit zero-points (fp32 bits; compact metadata: the fp16 halfword until widen_pk)
     uint32_t scw;     // the row's scale codes
     f32x2 qq[2];      // (qs, qz) of the thread's 2-bit groups
 };
-
+struct Pk4 {          // W4ROW: code words only (scale / zero come from rowmeta)
+    uint32_t c[4];
+};
 template <int LAYOUT>
-__device__ __forceinline__ void load_pk(const Deq& c, int t, Pk& k) {
-    const uint32_t* blk = (const uint32_t*)(c.smem + OFF_BP + (t % BP_SLOTS) * BP_STAGE + c.off_blk);
+struct PkOf { typedef Pk type; };
+template <>
+struct PkOf<MXQ_LAYOUT_W4ROW> { typedef Pk4 type; };
+
+// They come STRAIGHT from global memory into registers, three K-steps before they are used (6-7 dword loads per
+// thread and chunk through the tile's buffer descriptor; 16 lanes of a row-block read 64 consecutive bytes).  Round 2
+// first had them copied into a 4-slot LDS ring by LDS-DMA and read back from there: the two DMA pieces per wave and
+// step cost their issuer 100-185 cycles apiece next to MFMAs, on the one wave per SIMD whose ~90-op chain is the
+// critical path of a K-step (-2..4 % per launch without them; bit-identical results).
+template <int LAYOUT, int H>
+__device__ __forceinline__ void load_pk(const Deq& c, int t, typename PkOf<LAYOUT>::type& k) {
+    constexpr int BYTES = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : LAYOUT == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
+    // wave-uniform by construction; said explicitly, or a K offset selected between two tiles' descriptors counts as
+    // divergent and every load below gets a waterfall loop around it
+    const uint32_t so = __builtin_amdgcn_readfirstlane(c.k0 + (uint32_t)t * BYTES);
+    auto dw = [&](int idx) { return __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, c.voff_blk + (uint32_t)idx * 4u, so, 0); };
+    auto hw = [&](int idx) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(c.rsrc, c.voff_blk + (uint32_t)idx * 2u, so, 0); };
     if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) k.c[i] = blk[mxq_w4_c4(c.h * 2 + (i >> 1), i & 1, c.r)];
-        return;
-    }
+        for (int i = 0; i < 4; ++i) k.c[i] = dw(mxq_w4_c4(H * 2 + (i >> 1), i & 1, c.r));
+    } else {
     constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC, COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
-    k.scw = ((const uint16_t*)blk)[COMPACT ? mxqc_sc_u16(c.r) : mxq_sc_u16(c.r)];
-    const int g0 = c.h * 2;   // first 2-bit group of this thread
-    auto zero_of = [&](int g) -> uint32_t {   // fp32 bits of the group's zero-point (compact: widened from fp16 here)
-        if constexpr (COMPACT) {
-            const uint16_t zh = ((const uint16_t*)blk)[mxqc_z2_u16(0, c.r) + g * 16];
-            return __float_as_uint((float)__builtin_bit_cast(_Float16, zh));
-        } else {
-            return blk[(MIXED ? mxq_z2(0, c.r) : mxq_w2_z2(0, c.r)) + g * 16];
-        }
+    k.scw = hw(COMPACT ? mxqc_sc_u16(c.r) : mxq_sc_u16(c.r));
+    const int g0 = H * 2;   // first 2-bit group of this thread
+    auto zero_of = [&](int g) -> uint32_t {
+        if constexpr (COMPACT) return hw(mxqc_z2_u16(0, c.r) + g * 16);
+        else return dw((MIXED ? mxq_z2(0, c.r) : mxq_w2_z2(0, c.r)) + g * 16);
     };
     constexpr int QQ0 = COMPACT ? MXQC_OFF_QQ : MXQ_OFF_QQ;
-    k.c[0] = blk[(MIXED ? mxq_c2(0, c.r) : mxq_w2_c2(0, c.r)) + g0 * 16];
+    k.c[0] = dw((MIXED ? mxq_c2(0, c.r) : mxq_w2_c2(0, c.r)) + g0 * 16);
     k.z[0] = zero_of(g0);
-    k.qq[0] = *(const f32x2*)(blk + QQ0 + g0 * 2);
-    if (LAYOUT == MXQ_LAYOUT_W2G16 || c.h == 0) {
-        k.c[1] = blk[(MIXED ? mxq_c2(1, c.r) : mxq_w2_c2(1, c.r)) + g0 * 16];
+    k.qq[0] = (f32x2){__uint_as_float(dw(QQ0 + g0 * 2)), __uint_as_float(dw(QQ0 + g0 * 2 + 1))};
+    if (LAYOUT == MXQ_LAYOUT_W2G16 || H == 0) {
+        k.c[1] = dw((MIXED ? mxq_c2(1, c.r) : mxq_w2_c2(1, c.r)) + g0 * 16);
         k.z[1] = zero_of(g0 + 1);
-        k.qq[1] = *(const f32x2*)(blk + QQ0 + g0 * 2 + 2);
+        k.qq[1] = (f32x2){__uint_as_float(dw(QQ0 + g0 * 2 + 2)), __uint_as_float(dw(QQ0 + g0 * 2 + 3))};
     } else {
-        k.c[2] = blk[mxq_c4(0, c.r)];
-        k.c[3] = blk[mxq_c4(1, c.r)];
+        k.c[2] = dw(mxq_c4(0, c.r));
+        k.c[3] = dw(mxq_c4(1, c.r));
+    }
+    }
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void widen_pk(typename PkOf<LAYOUT>::type& k) {   // compact zero-points arrive as fp16 halfwords
+    if constexpr (LAYOUT == MXQ_LAYOUT_MIXEDC) {
+        k.z[0] = __float_as_uint((float)__builtin_bit_cast(_Float16, (uint16_t)k.z[0]));
+        k.z[1] = __float_as_uint((float)__builtin_bit_cast(_Float16, (uint16_t)k.z[1]));
     }
 }
 
 // chunk t: preloaded packed words -> fp16 W16[t & 1]
-template <int LAYOUT>
-__device__ __forceinline__ void dequant_pk(const Deq& c, int t, const Pk& k) {
-    char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
+// chunk's packed words -> the thread's 32 fp16 weights (4 x 16 bytes: W16 slots s0 .. s0+3 of its row)
+template <int LAYOUT, int H>
+__device__ __forceinline__ void convert_pk(const Deq& c, const typename PkOf<LAYOUT>::type& k, u32x4 (&res)[4]) {
     uint32_t o[8];
     if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             mxq_deq4x8(k.c[2 * q], c.s4, c.z4, o);
             mxq_deq4x8(k.c[2 * q + 1], c.s4, c.z4, o + 4);
-            put8(wt, c.row, (c.h * 2 + q) * 2, o);
-            put8(wt, c.row, (c.h * 2 + q) * 2 + 1, o + 4);
+            res[2 * q] = (u32x4){o[0], o[1], o[2], o[3]};
+            res[2 * q + 1] = (u32x4){o[4], o[5], o[6], o[7]};
         }
-        return;
-    }
-    const int g0 = c.h * 2;
-    mxq_deq2x16(k.c[0], mxq_scale(k.qq[0][0], k.qq[0][1], (k.scw >> (4 * g0)) & 15u), __uint_as_float(k.z[0]), o);
-    put8(wt, c.row, g0 * 2, o);
-    put8(wt, c.row, g0 * 2 + 1, o + 4);
-    if (LAYOUT == MXQ_LAYOUT_W2G16 || c.h == 0) {
-        mxq_deq2x16(k.c[1], mxq_scale(k.qq[1][0], k.qq[1][1], (k.scw >> (4 * g0 + 4)) & 15u), __uint_as_float(k.z[1]), o);
-        put8(wt, c.row, g0 * 2 + 2, o);
-        put8(wt, c.row, g0 * 2 + 3, o + 4);
     } else {
-        mxq_deq4x8(k.c[2], c.s4, c.z4, o);
-        mxq_deq4x8(k.c[3], c.s4, c.z4, o + 4);
-        put8(wt, c.row, 6, o);
-        put8(wt, c.row, 7, o + 4);
+        const int g0 = H * 2;
+        mxq_deq2x16(k.c[0], mxq_scale(k.qq[0][0], k.qq[0][1], (k.scw >> (4 * g0)) & 15u), __uint_as_float(k.z[0]), o);
+        res[0] = (u32x4){o[0], o[1], o[2], o[3]};
+        res[1] = (u32x4){o[4], o[5], o[6], o[7]};
+        if (LAYOUT == MXQ_LAYOUT_W2G16 || H == 0) {
+            mxq_deq2x16(k.c[1], mxq_scale(k.qq[1][0], k.qq[1][1], (k.scw >> (4 * g0 + 4)) & 15u), __uint_as_float(k.z[1]), o);
+        } else {
+            mxq_deq4x8(k.c[2], c.s4, c.z4, o);
+            mxq_deq4x8(k.c[3], c.s4, c.z4, o + 4);
+        }
+        res[2] = (u32x4){o[0], o[1], o[2], o[3]};
+        res[3] = (u32x4){o[4], o[5], o[6], o[7]};
     }
+}
+// ... into W16[t & 1]: the thread's column half H = slots 4 H .. 4 H + 3
+template <int H>
+__device__ __forceinline__ void store_pk(const Deq& c, int t, const u32x4 (&res)[4]) {
+    char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(wt + swz(c.row, H * 4 + i)) = res[i];
 }
 
 template <int LAYOUT>
@@ -541,82 +553,89 @@ __device__ __forceinline__ void deq_setup(Deq& c, char* smem, int wave, int lane
     c.d = wave - N_MMA;
     c.lane = lane;
     c.NT = nsteps;
-    const int rb0 = n0 >> 4, rbs = (N >> 4) - rb0 < BN / 16 ? (N >> 4) - rb0 : BN / 16;   // live row-blocks
     const uint32_t blk_stride = (uint32_t)NT_tile * BLK_B;   // bytes between consecutive row-blocks
-    c.rsrc = make_rsrc((const char*)qweight + (int64_t)rb0 * NT_tile * BLK_B, (uint32_t)rbs * blk_stride);
-    c.voff[0] = (uint32_t)lane * 16u + (uint32_t)(c.d * 2) * blk_stride;
-    c.voff[1] = c.voff[0] + blk_stride;
+    c.rsrc = make_rsrc(qweight, (uint32_t)(N >> 4) * blk_stride);
     c.k0 = (uint32_t)kt0 * BLK_B;
     const int dt = c.d * 64 + lane;   // 0..255
     c.row = dt & 127;
     c.h = __builtin_amdgcn_readfirstlane(dt >> 7);   // wave-uniform: dequant waves 0,1 -> 0; 2,3 -> 1
     c.r = c.row & 15;
-    c.off_blk = (c.row >> 4) * BP_BLK;
+    c.voff_blk = (uint32_t)((n0 >> 4) + (c.row >> 4)) * blk_stride;
 }
-// a segment's prologue DMAs (packed blocks of its first BP_SLOTS K-steps: needs the whole packed ring idle) and
-// the row's 4-bit-arm parameters; the values are first used behind prologue barrier 1
-template <int LAYOUT>
-__device__ __forceinline__ void deq_prologue_issue(Deq& c, const float4* __restrict__ rowmeta, int N, int n0) {
-    for (int t = 0; t < BP_SLOTS && t < c.NT; ++t) issue_bp<LAYOUT>(c, t);
+__device__ __forceinline__ void deq_none(Deq& c, const Deq& like) {   // a descriptor whose every load is out of range
+    c = like;
+    c.voff_blk = 0x80000000u;
+    c.k0 = 0;
+}
+
+// One segment on the dequant waves, R chunks at a time ("group").  A BURST waits for the group's R register sets
+// (loaded during the previous group's steps), converts all of them into result registers, and at once issues the loads
+// of the next group -- of this segment, or, after its last group, group 0 of `nxt` (the next tile of the persistent
+// loop, or nothing).  The following R K-steps only write one chunk's results into the W16 double buffer and meet the
+// barrier.  Why bursts instead of ~90 VALU ops in every step: next to MFMAs a VALU op of this wave issues at ~8-10
+// cycles, and the same ops interleaved into the MFMA waves' issue slots slow those down; in a burst step the MFMA
+// waves finish their step and wait at the barrier while the rest of the burst runs at full rate, and the R-1 steps
+// after it carry no VALU work at all (measured +3 % over the same work spread evenly, R = 3).
+// pre: the sets already hold / are loading chunks 0 .. R-1 (issued by the previous tile's last burst).
+template <int ABL, int LAYOUT, int H, int R>
+__device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const float4* __restrict__ rowmeta, int N, int n0,
+                                              bool pre, typename PkOf<LAYOUT>::type (&S)[R]) {
+    const int NT = c.NT;
+    u32x4 res[R][4];
+    auto load_group = [&](int base) {          // chunks base .. base+R-1 of this segment, or group 0 of nxt past its end
+        if constexpr (ABL & ABL_NO_DEQ) return;
+        const bool over = base >= NT;
+        Deq d = c;
+        d.voff_blk = over ? nxt.voff_blk : c.voff_blk;
+        d.k0 = over ? nxt.k0 : c.k0;
+        const int b0 = over ? 0 : base;
+#pragma unroll
+        for (int i = 0; i < R; ++i) load_pk<LAYOUT, H>(d, b0 + i, S[i]);
+    };
+    auto burst = [&](int base) {               // convert the loaded group, then fetch the one after it
+        if constexpr (!(ABL & ABL_NO_DEQ)) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                widen_pk<LAYOUT>(S[i]);
+                convert_pk<LAYOUT, H>(c, S[i], res[i]);
+            }
+        }
+        load_group(base + R);
+    };
+    auto put = [&](int q, const u32x4 (&r4)[4]) {   // chunk q -> W16[q & 1], then the step's barrier
+        if constexpr (!(ABL & ABL_NO_DEQ)) store_pk<H>(c, q, r4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    if (!pre) load_group(0);
     int gn = n0 + c.row;
     gn = gn < N ? gn : N - 1;
     c.rm = rowmeta[gn];
-}
-
-// One segment on the dequant waves; pre / next as in mma_segment.
-template <int ABL, int LAYOUT, class Next>
-__device__ __forceinline__ void deq_segment(Deq& c, int wave, int lane, const float4* __restrict__ rowmeta, int N,
-                                            int n0, bool pre, u64t* dbg, Next&& next) {
-    if (!pre) deq_prologue_issue<LAYOUT>(c, rowmeta, N, n0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();              // prologue barrier 1 (the MFMA waves' x tile 0 has landed)
     c.s4 = mxq_scale(c.rm.z, c.rm.w, (uint32_t)c.rm.y);
     c.z4 = c.rm.x;
-    Pk cur = {}, nxt = {};
-    if constexpr (!(ABL & ABL_NO_DEQ)) {
-        load_pk<LAYOUT>(c, 0, cur);
-        dequant_pk<LAYOUT>(c, 0, cur);
-        if (c.NT > 1) load_pk<LAYOUT>(c, 1, cur);
+    burst(0);
+    put(0, res[0]);                            // prologue barrier 2: W16(0) written
+    // step t = q - 1 writes chunk q; the segment's last step (t = NT - 1) writes nothing
+    for (int base = 0; base < NT; base += R) {
+#pragma unroll
+        for (int i = 1; i < R; ++i)
+            if (base + i < NT) put(base + i, res[i]);
+        if (base + R < NT) {
+            burst(base + R);
+            put(base + R, res[0]);
+        }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();              // step NT - 1
+}
 
-    // K-step t: read the packed words of chunk t+2 (landed one step ago), issue the DMA of chunk t+4 (its slot held
-    // chunk t, read into registers two steps ago), dequantise chunk t+1 from registers into W16[(t+1) & 1]
-    int t = 0;
-    Stamps st = {0, 0, 0, 0};
-    for (; t + 4 < c.NT; ++t) {   // steady state: everything unconditional
-        u64t t0 = 0, t1 = 0, t2 = 0;
-        if constexpr ((ABL & EXP_STAMPS) != 0) t0 = stamp();
-        if constexpr (!(ABL & ABL_NO_DEQ)) load_pk<LAYOUT>(c, t + 2, nxt);
-        issue_bp<LAYOUT>(c, t + 4);
-        if constexpr (!(ABL & ABL_NO_DEQ)) dequant_pk<LAYOUT>(c, t + 1, cur);
-        if constexpr ((ABL & EXP_STAMPS) != 0) t1 = stamp();
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // this step's 2 DMAs stay in flight
-        cur = nxt;
-        if constexpr ((ABL & EXP_STAMPS) != 0) t2 = stamp();
-        __builtin_amdgcn_s_barrier();
-        if constexpr ((ABL & EXP_STAMPS) != 0) {
-            const u64t t3 = stamp();
-            st.work += t1 - t0; st.wait += t2 - t1; st.bar += t3 - t2; st.n += 1;
-        }
-    }
-    if constexpr ((ABL & EXP_STAMPS) != 0) {
-        if (lane == 0 && dbg) {
-            u64t* d = dbg + ((int64_t)blockIdx.x * (N_MMA + N_DEQ) + wave) * 4;
-            d[0] = st.work; d[1] = st.wait; d[2] = st.bar; d[3] = st.n;
-        }
-    }
-    for (; t < c.NT; ++t) {
-        if constexpr (!(ABL & ABL_NO_DEQ)) {
-            if (t + 2 < c.NT) load_pk<LAYOUT>(c, t + 2, nxt);
-            if (t + 1 < c.NT) dequant_pk<LAYOUT>(c, t + 1, cur);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        cur = nxt;
-        __builtin_amdgcn_s_barrier();
-    }
-    next();   // the rings are idle from here on
+// the column half a dequant wave works on is wave-uniform but not a constant: dispatch once, outside the loops
+constexpr int DEQ_R = 3;    // measured: R = 2 -5 %, 3 and 4 +2 % over per-step dequant; R = 4 spills at the 168-VGPR cap
+template <int ABL, int LAYOUT>
+__device__ __forceinline__ void deq_segment(Deq& c, const Deq& nxt, int wave, int lane, const float4* __restrict__ rowmeta,
+                                            int N, int n0, bool pre, typename PkOf<LAYOUT>::type (&S)[DEQ_R]) {
+    if (c.h == 0) deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+    else deq_segment_h<ABL, LAYOUT, 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -755,19 +774,21 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             int ln;
             MXQ_LANE_ID(ln);
             Deq cur, nxt;
+            typename PkOf<LAYOUT>::type S[DEQ_R] = {};
             deq_setup<LAYOUT>(cur, smem, wave, ln, qweight, N, K, tn * BN, 0, NT);
-            deq_prologue_issue<LAYOUT>(cur, rowmeta, N, tn * BN);
+            bool pre = false;                  // a tile's last burst loads the next tile's first group
             for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
                 MXQ_LANE_ID(ln);
                 const int n0 = tn * BN;
                 const bool more = tile + dp_grid < dp_tiles;
-                if (more) tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
-                deq_segment<ABL, LAYOUT>(cur, wave, ln, rowmeta, N, n0, true, (u64t*)ws, [&] {
-                    if (more) {
-                        deq_setup<LAYOUT>(nxt, smem, wave, ln, qweight, N, K, tn * BN, 0, NT);
-                        deq_prologue_issue<LAYOUT>(nxt, rowmeta, N, tn * BN);
-                    }
-                });
+                if (more) {
+                    tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
+                    deq_setup<LAYOUT>(nxt, smem, wave, ln, qweight, N, K, tn * BN, 0, NT);
+                } else {
+                    deq_none(nxt, cur);
+                }
+                deq_segment<ABL, LAYOUT>(cur, nxt, wave, ln, rowmeta, N, n0, pre, S);
+                pre = true;
                 cur = nxt;
             }
         }
@@ -839,9 +860,11 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
                 wdma_setup(w, (const uint16_t*)qweight, N, K, tn * BN, pos - j * NT, end - pos, wave, ln);
                 wdma_segment(w, smem, false, nothing);
             } else {
-                Deq c;
+                Deq c, none;
+                typename PkOf<LAYOUT>::type S[DEQ_R] = {};
                 deq_setup<LAYOUT>(c, smem, wave, ln, qweight, N, K, tn * BN, pos - j * NT, end - pos);
-                deq_segment<ABL, LAYOUT>(c, wave, ln, rowmeta, N, tn * BN, false, (u64t*)ws, nothing);
+                deq_none(none, c);
+                deq_segment<ABL, LAYOUT>(c, none, wave, ln, rowmeta, N, tn * BN, false, S);
             }
             pos = end;
         }
@@ -867,7 +890,8 @@ template <int ABL, int LAYOUT = MXQ_LAYOUT_MIXED>
 static int launch8(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* workspace, size_t ws_bytes, bool force, hipStream_t stream) {
     // the DMA descriptors address one tile's rows with 32-bit offsets: 256 rows of x, 8 row-blocks of packed weights
-    if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(BN / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 32))
+    // 32-bit offsets: 256 rows of x per DMA descriptor; the whole packed weight behind one (offsets < 2^31)
+    if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(N / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 31))
         return -1;   // MXQ_E_SHAPE
     hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm8_f16_kernel<ABL, LAYOUT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);

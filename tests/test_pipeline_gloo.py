@@ -57,7 +57,8 @@ def _worker(rank, world, port, q):
         assert pipe.run_microbatches(lambda h: ybuf.copy_(h * 2), xs * 3, torch.empty(4, HID), collect=False) == []
         gen = pipe.decode(3, 6, lambda t: emb.index_select(0, t), fn, lambda h: (h @ head.t()).argmax(-1),
                           torch.empty(1, HID), torch.zeros(1, dtype=torch.int64))
-        q.put((rank, [o.clone() for o in outs], gen))
+        # by value (numpy), not as shared-memory tensors: a shared tensor must be rebuilt while its producer still runs
+        q.put((rank, [o.numpy().copy() for o in outs], gen))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -80,7 +81,7 @@ def test_pipeline_matches_single_process(world):
         assert p.exitcode == 0
     ref_outs, ref_gen = _reference(6, 3)
     outs, gen = res[world - 1]
-    assert len(outs) == 5 and all(torch.equal(a, b) for a, b in zip(outs, ref_outs))
+    assert len(outs) == 5 and all(torch.equal(torch.from_numpy(a), b) for a, b in zip(outs, ref_outs))
     assert res[0][1] == ref_gen and res[world - 1][1] == ref_gen      # first and last stage track the tokens
     assert all(res[r][1] == [] for r in range(1, world - 1))          # the stages in between never see them
     assert all(len(res[r][0]) == 0 for r in range(world - 1))
@@ -102,7 +103,7 @@ def _worker_subgroup(rank, world, port, q):
             outs = pipe.run_microbatches(fn, xs, torch.empty(4, HID))
             gen = pipe.decode(3, 6, lambda t: emb.index_select(0, t), fn, lambda h: (h @ head.t()).argmax(-1),
                               torch.empty(1, HID), torch.zeros(1, dtype=torch.int64))
-            out = ([o.clone() for o in outs], gen)
+            out = ([o.numpy().copy() for o in outs], gen)
         q.put((rank, out))
         dist.barrier()
     finally:
@@ -123,7 +124,7 @@ def test_pipeline_in_a_subgroup_addresses_its_own_members():
     ref_outs, ref_gen = _reference(6, 3)
     assert res[0] is None
     outs, gen = res[2]
-    assert len(outs) == 5 and all(torch.equal(a, b) for a, b in zip(outs, ref_outs))
+    assert len(outs) == 5 and all(torch.equal(torch.from_numpy(a), b) for a, b in zip(outs, ref_outs))
     assert gen == ref_gen and res[1][1] == ref_gen and res[1][0] == []
 
 
