@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Where a K-step of the gemm8 prefill kernel spends its cycles, per wave role (diagnostic build with s_memtime
-stamps in libmxq_hip_prof.so; the stamps perturb the run: read the SHARES, not the length).
+"""Where a K-step of the gemm8 prefill kernel spends its cycles on the MFMA waves (diagnostic build with s_memtime
+stamps in libmxq_hip_prof.so; the stamps perturb the run: read the SHARES, not the length).  The dequant waves'
+stamps went away with their per-step structure (they now work in bursts of three chunks); their rows in
+profiles/r02_*stamps* are from the per-step kernel earlier in round 2.
     python tools/gemm_stamps.py [--m 2048] [--n 4096] [--k 4096] [--abl 0,2048,4,2]"""
 import argparse
 import ctypes
@@ -43,8 +45,7 @@ def main():
         d = dbg.view(grid, 12, 4).double().cpu()
         steps = d[:, :, 3].clamp(min=1)
         per = d[:, :, :3] / steps[:, :, None]            # cycles per K-step
-        for name, sl in (("MFMA waves 0-7", slice(0, 8)), ("dequant waves h=0 (8,9)", slice(8, 10)),
-                         ("dequant waves h=1 (10,11)", slice(10, 12))):
+        for name, sl in (("MFMA waves 0-7", slice(0, 8)),):
             w = per[:, sl, :].mean(dim=(0, 1))
             print(f"abl {abl:5d} {name:28s} work {w[0]:7.0f}  wait {w[1]:6.0f}  barrier {w[2]:6.0f}  total {w.sum():7.0f} cycles/step",
                   flush=True)
