@@ -31,21 +31,49 @@ using namespace mxq_fq;
 __device__ __forceinline__ float nan_max(float a, float b) { return (b > a || b != b) ? b : a; }
 __device__ __forceinline__ float nan_min(float a, float b) { return (b < a || b != b) ? b : a; }
 
+// x[j] <- x[j] / d for the lane's VEC values, where the quotient is rounded to T right afterwards.  An IEEE fp32
+// division is ~10 VALU ops; x * v_rcp_f32(d) is two, and fl32(x * rcp(d)) rounds to the same T value as the correctly
+// rounded quotient unless it lies within a few fp32 ulps of one of T's rounding boundaries (mxq_fq_types.h,
+// boundary_key: the screen of the weight fake-quant kernel).  Any lane of the wave near a boundary (or outside the
+// normal range, or fp32 tensors, whose quotients are not re-rounded) sends the wave through the real division.
+template <typename T>
+__device__ __forceinline__ void div_vec(float (&x)[T::VEC], float d) {
+    if constexpr (T::HAS_FAST_DIV) {
+        const float r = __builtin_amdgcn_rcpf(d);
+        float q[T::VEC];
+        uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < T::VEC; ++j) {
+            q[j] = x[j] * r;
+            key = min(key, T::boundary_key(q[j]));
+        }
+        if (!__any(key < T::KEY_LIMIT)) {
+#pragma unroll
+            for (int j = 0; j < T::VEC; ++j) x[j] = q[j];
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < T::VEC; ++j) x[j] = x[j] / d;
+}
+template <typename T>
+__device__ __forceinline__ void rnd_vec(float (&x)[T::VEC]) {   // roundings go pairwise (T::rnd2: one v_cvt_pk per two values)
+#pragma unroll
+    for (int j = 0; j < T::VEC; j += 2) T::rnd2(x[j], x[j + 1]);
+}
+
 template <typename T>
 __device__ __forceinline__ void sym_apply(const float (&v)[T::VEC], float mx, float qmax, float (&o)[T::VEC]) {
     // `qmax / tensor` is Tensor.__rtruediv__ = tensor.reciprocal() * qmax: two roundings, not one division
     const float s = T::rnd(T::rnd(1.0f / T::rnd(mx + 1e-6f)) * qmax);
     const float s2 = T::rnd(s + 1e-6f);
 #pragma unroll
-    for (int j = 0; j < T::VEC; j += 2) {   // roundings go pairwise (T::rnd2: one v_cvt_pk per two values)
-        float a = v[j] * s, b = v[j + 1] * s;
-        T::rnd2(a, b);
-        a = rintf(a) / s2;
-        b = rintf(b) / s2;
-        T::rnd2(a, b);
-        o[j] = a;
-        o[j + 1] = b;
-    }
+    for (int j = 0; j < T::VEC; ++j) o[j] = v[j] * s;
+    rnd_vec<T>(o);
+#pragma unroll
+    for (int j = 0; j < T::VEC; ++j) o[j] = rintf(o[j]);
+    div_vec<T>(o, s2);
+    rnd_vec<T>(o);
 }
 
 template <typename T>
@@ -53,23 +81,23 @@ __device__ __forceinline__ void asym_apply(const float (&v)[T::VEC], float mn, f
     const float alpha = T::rnd(mx - mn);
     const float e = T::rnd(alpha + 1e-8f);
 #pragma unroll
-    for (int j = 0; j < T::VEC; j += 2) {
-        float a = v[j] - mn, b = v[j + 1] - mn;
-        T::rnd2(a, b);
-        a /= e; b /= e;
-        T::rnd2(a, b);
-        a *= L; b *= L;
-        T::rnd2(a, b);
-        a = rintf(a) / L;
-        b = rintf(b) / L;
-        T::rnd2(a, b);
-        a *= e; b *= e;
-        T::rnd2(a, b);
-        a += mn; b += mn;
-        T::rnd2(a, b);
-        o[j] = a;
-        o[j + 1] = b;
-    }
+    for (int j = 0; j < T::VEC; ++j) o[j] = v[j] - mn;
+    rnd_vec<T>(o);
+    div_vec<T>(o, e);
+    rnd_vec<T>(o);
+#pragma unroll
+    for (int j = 0; j < T::VEC; ++j) o[j] *= L;
+    rnd_vec<T>(o);
+#pragma unroll
+    for (int j = 0; j < T::VEC; ++j) o[j] = rintf(o[j]);
+    div_vec<T>(o, L);
+    rnd_vec<T>(o);
+#pragma unroll
+    for (int j = 0; j < T::VEC; ++j) o[j] *= e;
+    rnd_vec<T>(o);
+#pragma unroll
+    for (int j = 0; j < T::VEC; ++j) o[j] += mn;
+    rnd_vec<T>(o);
 }
 
 // ------------------------------------------------------------------------------------------------

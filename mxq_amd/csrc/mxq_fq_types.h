@@ -83,8 +83,9 @@ struct F16 {
         b = (float)(_Float16)b;
     }
     __device__ static __forceinline__ bool near_boundary(float a) {   // 11 significant bits; no shortcut in the
-        const uint32_t u = __float_as_uint(a);                          // fp16-subnormal range
-        return ((u & 0x1FFFu) - 0x0FFCu) < 8u || !(a == 0.0f || (a > 6.2e-5f && a < 6.0e4f));
+        const uint32_t u = __float_as_uint(a);                          // fp16-subnormal range; either sign
+        const float m = fabsf(a);
+        return ((u & 0x1FFFu) - 0x0FFCu) < 8u || !(m == 0.0f || (m > 6.2e-5f && m < 6.0e4f));
     }
     __device__ static __forceinline__ uint32_t boundary_key(float a) { return near_boundary(a) ? 0u : 0xFFFFFFFFu; }
     static constexpr uint32_t KEY_LIMIT = 1u;
