@@ -37,11 +37,13 @@ def main():
     b = last_json(run(["bench.py", "--gpus", "1", "--steps", "10", "--warmup", "3"]))
     rep["config1_cpu_dequant_linear"] = b["cpu_baseline"]
     rep["config2_prefill_all_linears"] = {k: b[k] for k in ("value", "unit", "ms_per_step", "tokens_per_s", "roofline")}
-    d = last_json(run(["tools/decode_bench.py", "--tokens", "64"]))
-    rep["config3_decode_1gpu"] = {"tokens_per_s": d["tokens_per_s"], "ms_per_token": d["ms_per_token"],
-                                  "packed_weight_GBps": d["weight_stream_GBps"],
-                                  "hbm_frac_of_8TBps": round(d["weight_stream_GBps"] / 8000.0, 3),
-                                  "floor_ms_per_token_at_6.3TBps": round(d["packed_weight_GB_per_token"] / 6.3, 3)}
+    rep["config3_decode_1gpu"] = {}
+    for mode, extra in (("exact_metadata", []), ("compact_metadata", ["--compact"])):     # state the mode
+        d = last_json(run(["tools/decode_bench.py", "--tokens", "64"] + extra))
+        rep["config3_decode_1gpu"][mode] = {"tokens_per_s": d["tokens_per_s"], "ms_per_token": d["ms_per_token"],
+                                            "packed_weight_GBps": d["weight_stream_GBps"],
+                                            "hbm_frac_of_8TBps": round(d["weight_stream_GBps"] / 8000.0, 3),
+                                            "floor_ms_per_token_at_6.3TBps": round(d["packed_weight_GB_per_token"] / 6.3, 3)}
     kb = run(["tools/kernels_bench.py"])
     blk = [l for l in kb.splitlines() if "one decoder block" in l]
     rep["config4_fakequant_block_bf16"] = {"line": blk[0].strip() if blk else None}
