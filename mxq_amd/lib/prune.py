@@ -95,12 +95,16 @@ class _StopForward(Exception):
     """Raised by the input recorder to abandon the rest of the model's forward."""
 
 
-def prepare_calibration_input(model: nn.Module, dataloader, device, nsamples: int = 128):
+def prepare_calibration_input(model: nn.Module, dataloader, device, nsamples: int = 128, return_kwargs: bool = False):
     """Record what reaches the first decoder layer for every calibration batch (the reference's Catcher,
     prune.py:64-102): returns ``(inps [nsamples, seqlen, hidden], outs, attention_mask, position_ids)`` --
     the arguments ``quantize_sequential`` / ``nas_quant``'s layer loop start from.  ``model`` is HF-shaped
     (``model.model.layers``, ``model.config.hidden_size / use_cache``, ``model.seqlen``); ``dataloader``
-    yields ``(input_ids, ...)`` tuples as ``lib/data.py``'s loaders do."""
+    yields ``(input_ids, ...)`` tuples as ``lib/data.py``'s loaders do.
+
+    ``return_kwargs=True`` appends a fifth item: every keyword argument the model passed to its first layer
+    (newer ``transformers`` hand the rotary ``position_embeddings`` to the layers; the reference's pinned
+    version needed only the two it names), ready to be given to ``quantize_sequential`` as ``layer_kwargs``."""
     use_cache = getattr(model.config, "use_cache", None)
     model.config.use_cache = False
     layers = model.model.layers
@@ -120,6 +124,7 @@ def prepare_calibration_input(model: nn.Module, dataloader, device, nsamples: in
             seen["n"] += 1
             seen["attention_mask"] = kwargs.get("attention_mask")
             seen["position_ids"] = kwargs.get("position_ids")
+            seen["kwargs"] = dict(kwargs)
             raise _StopForward
 
     first = layers[0]
@@ -133,6 +138,8 @@ def prepare_calibration_input(model: nn.Module, dataloader, device, nsamples: in
     finally:
         layers[0] = first
         model.config.use_cache = use_cache
+    if return_kwargs:
+        return inps, torch.zeros_like(inps), seen["attention_mask"], seen["position_ids"], seen.get("kwargs", {})
     return inps, torch.zeros_like(inps), seen["attention_mask"], seen["position_ids"]
 
 

@@ -1017,6 +1017,57 @@ def test_activation_quantizer_backward_and_errors(dev):
 
 
 # ----------------------------------------------------------------------------------------
+# the reference's PTQ flow on a real HF module tree (mxq_quant/main.py --prune_method mxq, lib/prune.py:338-420)
+# ----------------------------------------------------------------------------------------
+def test_hf_llama_ptq_flow_fake_quant_vs_packed(dev, tmp_path):
+    """A tiny ``transformers`` LlamaForCausalLM (random init: no checkpoint offline) goes through the reference's
+    flow -- calibration inputs recorded at the first decoder layer, then layer-by-layer MXQGPT quantisation -- once
+    leaving fp16 fake-quant weights in ``nn.Linear`` (what the reference does) and once swapping in packed
+    ``QuantLinear`` modules; the two models must produce the same logits (the packed kernels compute on the very
+    weights the fake-quant model holds), and the packed checkpoint must reload into a fresh model bit for bit."""
+    transformers = pytest.importorskip("transformers")
+    from mxq_amd import checkpoint
+    from mxq_amd.lib.prune import find_layers, prepare_calibration_input, quantize_sequential
+    from mxq_amd.quant_linear import QuantLinear
+    cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=704, num_attention_heads=2, num_key_value_heads=2,
+                                   num_hidden_layers=2, vocab_size=128, max_position_embeddings=64)
+    cfg._attn_implementation = "eager"
+
+    def fresh():
+        torch.manual_seed(11)
+        m = transformers.LlamaForCausalLM(cfg).half().to(dev).eval()
+        m.seqlen = 32
+        return m
+    g = torch.Generator().manual_seed(5)
+    calib = [(torch.randint(0, 128, (1, 32), generator=g),) for _ in range(4)]
+    probe = torch.randint(0, 128, (2, 32), generator=g).to(dev)
+    models = []
+    for pack in (False, True):
+        m = fresh()
+        with torch.no_grad():
+            inps, _outs, _am, _pid, kw = prepare_calibration_input(m, calib, dev, nsamples=4, return_kwargs=True)
+            packed = quantize_sequential(m.model.layers, inps, kw, pack=pack)
+        assert len(packed) == 2 * 7
+        models.append(m)
+    fq, pk = models
+    assert all(isinstance(l, QuantLinear) for layer in pk.model.layers for l in find_layers(layer, layers=[QuantLinear]).values())
+    assert not find_layers(pk.model.layers[0]) and len(find_layers(fq.model.layers[0])) == 7
+    # the packed modules hold exactly the fake-quant weights of the first model's first layer
+    # (later layers see slightly different calibration activations: packed kernels vs fp16 matmul on the way)
+    for name, lin in find_layers(fq.model.layers[0]).items():
+        ql = find_layers(pk.model.layers[0], layers=[QuantLinear])[name]
+        assert torch.equal(ql.dequantize(), lin.weight.data), name
+    with torch.no_grad():
+        a = fq(probe).logits.float()
+        b = pk(probe).logits.float()
+    assert ((a - b).abs().max() / a.abs().max()).item() < 3e-2          # fp16 model end to end, two GEMM implementations
+    checkpoint.save_packed(pk, str(tmp_path))
+    again = checkpoint.load_packed(fresh(), str(tmp_path))
+    with torch.no_grad():
+        assert torch.equal(again(probe).logits, pk(probe).logits)
+
+
+# ----------------------------------------------------------------------------------------
 # decode stage (config 3 harness): fused q/k/v and gate/up GEMVs vs a dense fp32 restatement
 # ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("heads,fused", [(4, False), (2, True), (2, False), (32, True), (32, False)])
