@@ -1061,6 +1061,13 @@ def test_hf_llama_ptq_flow_fake_quant_vs_packed(dev, tmp_path):
         a = fq(probe).logits.float()
         b = pk(probe).logits.float()
     assert ((a - b).abs().max() / a.abs().max()).item() < 3e-2          # fp16 model end to end, two GEMM implementations
+    # one decoded token on top of a KV cache: the packed model's Linears now see 2 rows (batch 2 x 1 token: GEMV path)
+    with torch.no_grad():
+        pa = fq(probe[:, :16], use_cache=True)
+        pb = pk(probe[:, :16], use_cache=True)
+        a1 = fq(probe[:, 16:17], past_key_values=pa.past_key_values, use_cache=True).logits.float()
+        b1 = pk(probe[:, 16:17], past_key_values=pb.past_key_values, use_cache=True).logits.float()
+    assert ((a1 - b1).abs().max() / a1.abs().max()).item() < 3e-2
     checkpoint.save_packed(pk, str(tmp_path))
     again = checkpoint.load_packed(fresh(), str(tmp_path))
     with torch.no_grad():
