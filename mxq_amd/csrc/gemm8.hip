@@ -36,6 +36,7 @@
 // another workgroup.  Slots and counters cross XCDs (one L2 each): slot traffic is agent-scope relaxed atomics
 // (global_store / load ... sc1), ordered against the counter bump by s_waitcnt vmcnt(0).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "mxq_dequant.h"
 #include "mxq_format.h"
@@ -75,12 +76,18 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ void bufdma16(rsrc_t rsrc, uint32_t voff, uint32_t soff, void* l) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
 }
+// the same with sc1 (aux bit 4): served by L2, never by this CU's L1 -- for bytes another workgroup wrote in this launch
+__device__ __forceinline__ void bufdma16_sc1(rsrc_t rsrc, uint32_t voff, uint32_t soff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 16);
+}
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 
 // XCD-aware tile order (speed only): tiles are dealt to the 8 XCDs as compact 2-D blocks (4 x 2 regions)
-__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+// cls (coop mode, speed only): the production class of the workgroup on this tile -- the (up to) eight workgroups that
+// run one weight panel at the same time get eight different classes
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn, int& cls) {
     if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0) {
         const int e = bid & 7, l = bid >> 3;
         const int rm = tiles_m >> 2, rn = tiles_n >> 1;
@@ -91,6 +98,7 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
         const int pw = left < 16 ? left : 16;
         tm = (e & 3) * rm + j / pw;
         tn = (e >> 2) * rn + p * 16 + j % pw;
+        cls = (e & 3) * 2 + ((j / pw) & 1);
         return;
     }
     const int nwg = tiles_m * tiles_n;
@@ -98,6 +106,11 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     tm = lin % tiles_m;
     tn = lin / tiles_m;
+    cls = tm & 7;
+}
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    int cls;
+    tile_of_block(bid, tiles_m, tiles_n, tm, tn, cls);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -696,13 +709,329 @@ __device__ __forceinline__ void wdma_segment(const WDma& w, char* smem, bool pre
     next();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// cooperative-dequant mode ("coop"): the workgroups that share a weight panel dequantise it ONCE between them
+// ------------------------------------------------------------------------------------------------
+// The fused kernel dequantises every 128 x 64 weight tile once per 256 tokens; at 2048 tokens the eight workgroups
+// (tm = 0..7) of a 128-channel panel all convert the same packed words at the same time, and that conversion -- not
+// the MFMAs -- is the critical path of their K-steps (header of deq_segment_h).  Here every chunk tile of the panel
+// is converted by ONE of them into an fp16 scratch image in global memory (L2 / Infinity Cache resident), published
+// with a flag, and streamed into everybody's LDS ring by LDS-DMA exactly as the hoisted mode streams a dequantised
+// weight: the MFMA waves run the DENSE loop unchanged, the conversion work per workgroup drops to 1/8, and there is no
+// separate dequant pass (the scratch of chunk c is written while the K-steps c-20 .. c-13 run).
+//
+//   scratch image of chunk tile (tn, c): 16 KB at ((tn * NT + c) * 16 KB), 16-byte cell (row, slot) at
+//     (slot * 128 + row) * 16 -- a producer wave's store instruction writes eight whole 128-B lines, a consumer's
+//     DMA piece reads eight whole lines (slots XOR-swizzled on the way into LDS like the x tile).
+//   flags[(tn * NT + c) * 4 + d] = epoch + 1 once rows 32d .. 32d+31 of that tile are in the scratch; `epoch` is a
+//     word of the workspace that the last workgroup to finish a launch increments (hipGraph-replay safe, no memset
+//     between launches; the flags of earlier launches never match).
+//   W wave d (waves 8 + d) of EVERY workgroup consumes slice d of every chunk: it loads the flag of chunk s+4 in
+//     K-step s, checks the flag of chunk s+2 (loaded two steps earlier) and issues that chunk's four DMA pieces.
+//     A flag that is not up yet is polled for a bounded time; after that the wave converts the slice ITSELF, stores
+//     it, and goes on -- nobody ever depends on another workgroup making progress (a duplicate conversion writes the
+//     same bytes).  Producer and consumer of a slice are the same wave index, so that fallback needs no barrier.
+//   production: workgroup class m (tile_of_block: the eight classes of a panel run concurrently) converts chunk
+//     8j + COOP_LEAD + m during K-steps 8j .. 8j+7 (loads in step 8j, conversion in steps 8j+3 / 8j+4, sc1 stores in
+//     step 8j+4, the flag in step 8j+7, after the counted wait that covers the stores), and the chunks below
+//     COOP_LEAD in the tile's prologue.  The K loop is unrolled by 8 ("octet") so that every step's number of
+//     vector-memory operations is a constant and the waits can be counted: the wave's queue carries, in issue
+//     order, [flag load] [4 DMA pieces] [production ops of the step]; loads that return registers are inline asm
+//     (the compiler would wait for them with a drain).  All cross-workgroup traffic is sc1 (write-through stores,
+//     L1-bypassing loads and DMAs): the hand-off forms of MI355X_MICROARCH.md "Hand-offs measured with sc1 loads".
+constexpr int COOP_LEAD = 13;
+constexpr int COOP_CTL_INTS = 1024;            // control words in front of the flags: [0] epoch, [1] finished workgroups
+constexpr uint32_t COOP_OFF = 0x80000000u;     // an soffset that puts any access beyond its buffer: loads 0, stores dropped
+
+struct CoopRegs { uint32_t a, b, c, z0, z1, sc, q0x, q0y, q1x, q1y; };
+
+template <int LAYOUT>
+struct CoopW {
+    static constexpr bool COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
+    static constexpr int BYTES = COMPACT ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
+    const char* qw;          // packed weight
+    const uint32_t* flags;   // flag words
+    rsrc_t srs, frs;         // scratch / flags as buffers (stores, DMA)
+    uint32_t e1;             // what a ready flag holds in this launch
+    int d, NT;
+    int dbg;
+    // per tile
+    uint32_t ct0;            // chunk-tile index of the panel's chunk 0
+    int cls;                 // production class of this workgroup on this tile
+    uint32_t dv[4];          // DMA source offsets inside a chunk tile (per lane)
+    uint32_t pv[7];          // production load offsets inside the packed weight at chunk 0 (per lane): A B C Z0 Z1 SC QQ
+    uint32_t sv;             // production store offset inside a chunk tile (res[0]; res[i] at + i * 2 KB)
+    int row, H;              // tile row of the lane's production slice (32 d + lane % 32), its column half
+    float s4, z4;
+};
+
+// (s_nop 4: the base may have been written by a VALU instruction just before -- an SGPR spill reload is a v_readlane --
+// and a vector-memory instruction that reads an SGPR needs 5 wait states behind such a write; the compiler pads its
+// own instructions, never the inside of an asm statement)
+#define COOP_LD(op, dst, voff, base, extra) \
+    asm volatile("s_nop 4\n\t" op " %0, %1, %2" extra : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#define COOP_WAIT1(n, r0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "n"(n) : "memory")
+
+template <int LAYOUT>
+__device__ __forceinline__ void coop_tile_setup(CoopW<LAYOUT>& k, int lane, int N, int K, int tn, int cls,
+                                                const float4* __restrict__ rowmeta) {
+    constexpr bool COMPACT = CoopW<LAYOUT>::COMPACT;
+    const int NT = k.NT;
+    k.ct0 = (uint32_t)tn * (uint32_t)NT;
+    k.cls = cls;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = k.d * 32 + i * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ (row & 7);
+        k.dv[i] = (uint32_t)(slot * 128 + row) * 16u;
+    }
+    k.row = k.d * 32 + (lane & 31);
+    k.H = lane >> 5;
+    const int H = k.H, r = k.row & 15;
+    int rb = (tn * BN + k.row) >> 4;                  // row-block; beyond the weight: any valid one (its rows are never stored)
+    rb = rb < (N >> 4) ? rb : (N >> 4) - 1;
+    const uint32_t blk = (uint32_t)rb * (uint32_t)NT * (uint32_t)CoopW<LAYOUT>::BYTES;
+    k.pv[0] = blk + (uint32_t)((2 * H * 16 + r) * 4);                          // A: codes of 2-bit group 2H
+    k.pv[1] = blk + (uint32_t)(((H ? 48 : 16) + r) * 4);                       // B: group 1 | 4-bit half 0
+    k.pv[2] = blk + (uint32_t)(((H ? 64 : 16) + r) * 4);                       // C: (unused) | 4-bit half 1
+    if constexpr (COMPACT) {
+        k.pv[3] = blk + (uint32_t)((MXQC_OFF_Z2H * 2 + 2 * H * 16 + r) * 2);   // Z0 (fp16)
+        k.pv[4] = blk + (uint32_t)((MXQC_OFF_Z2H * 2 + 16 + r) * 2);           // Z1 (fp16)
+        k.pv[5] = blk + (uint32_t)((MXQC_OFF_SC * 2 + r) * 2);
+        k.pv[6] = blk + (uint32_t)((MXQC_OFF_QQ + 4 * H) * 4);
+    } else {
+        k.pv[3] = blk + (uint32_t)((MXQ_OFF_Z2 + 2 * H * 16 + r) * 4);
+        k.pv[4] = blk + (uint32_t)((MXQ_OFF_Z2 + 16 + r) * 4);
+        k.pv[5] = blk + (uint32_t)((MXQ_OFF_SC * 2 + r) * 2);
+        k.pv[6] = blk + (uint32_t)((MXQ_OFF_QQ + 4 * H) * 4);
+    }
+    k.sv = (uint32_t)((4 * H) * 128 + k.row) * 16u;
+    int gn = tn * BN + k.row;
+    gn = gn < N ? gn : N - 1;
+    const float4 rm = rowmeta[gn];
+    k.s4 = mxq_scale(rm.z, rm.w, (uint32_t)rm.y);
+    k.z4 = rm.x;
+}
+
+// production, part 0: the ten loads of the lane's 32 weights of chunk cp (cp < NT)
+template <int LAYOUT>
+__device__ __forceinline__ void coop_prod_load(const CoopW<LAYOUT>& k, int cp, CoopRegs& p) {
+    const char* sb = k.qw + (size_t)cp * CoopW<LAYOUT>::BYTES;
+    COOP_LD("global_load_dword", p.a, k.pv[0], sb, "");
+    COOP_LD("global_load_dword", p.b, k.pv[1], sb, "");
+    COOP_LD("global_load_dword", p.c, k.pv[2], sb, "");
+    if constexpr (CoopW<LAYOUT>::COMPACT) {
+        COOP_LD("global_load_ushort", p.z0, k.pv[3], sb, "");
+        COOP_LD("global_load_ushort", p.z1, k.pv[4], sb, "");
+    } else {
+        COOP_LD("global_load_dword", p.z0, k.pv[3], sb, "");
+        COOP_LD("global_load_dword", p.z1, k.pv[4], sb, "");
+    }
+    COOP_LD("global_load_ushort", p.sc, k.pv[5], sb, "");
+    COOP_LD("global_load_dword", p.q0x, k.pv[6], sb, "");
+    COOP_LD("global_load_dword", p.q0y, k.pv[6], sb, " offset:4");
+    COOP_LD("global_load_dword", p.q1x, k.pv[6], sb, " offset:8");
+    COOP_LD("global_load_dword", p.q1y, k.pv[6], sb, " offset:12");
+}
+// "every production register has arrived once at most `n` younger vector-memory operations are outstanding"
+template <int NWAIT>
+__device__ __forceinline__ void coop_prod_wait(CoopRegs& p) {
+    asm volatile("s_waitcnt vmcnt(%10)"
+                 : "+v"(p.a), "+v"(p.b), "+v"(p.c), "+v"(p.z0), "+v"(p.z1), "+v"(p.sc), "+v"(p.q0x), "+v"(p.q0y),
+                   "+v"(p.q1x), "+v"(p.q1y)
+                 : "n"(NWAIT)
+                 : "memory");
+}
+// part 1: 2-bit group 2H -> slots 4H, 4H+1 (the same arithmetic as convert_pk)
+template <int LAYOUT>
+__device__ __forceinline__ void coop_convert0(const CoopW<LAYOUT>& k, const CoopRegs& p, u32x4 (&res)[4]) {
+    uint32_t o[8];
+    float z0;
+    if constexpr (CoopW<LAYOUT>::COMPACT) z0 = (float)__builtin_bit_cast(_Float16, (uint16_t)p.z0);
+    else z0 = __uint_as_float(p.z0);
+    mxq_deq2x16(p.a, mxq_scale(__uint_as_float(p.q0x), __uint_as_float(p.q0y), (p.sc >> (8 * k.H)) & 15u), z0, o);
+    res[0] = (u32x4){o[0], o[1], o[2], o[3]};
+    res[1] = (u32x4){o[4], o[5], o[6], o[7]};
+}
+// part 2: H = 0: 2-bit group 1; H = 1: the 4-bit quarter -> slots 4H+2, 4H+3
+template <int LAYOUT>
+__device__ __forceinline__ void coop_convert1(const CoopW<LAYOUT>& k, const CoopRegs& p, u32x4 (&res)[4]) {
+    uint32_t o[8];
+    if (k.H == 0) {
+        float z1;
+        if constexpr (CoopW<LAYOUT>::COMPACT) z1 = (float)__builtin_bit_cast(_Float16, (uint16_t)p.z1);
+        else z1 = __uint_as_float(p.z1);
+        mxq_deq2x16(p.b, mxq_scale(__uint_as_float(p.q1x), __uint_as_float(p.q1y), (p.sc >> 4) & 15u), z1, o);
+    } else {
+        mxq_deq4x8(p.b, k.s4, k.z4, o);
+        mxq_deq4x8(p.c, k.s4, k.z4, o + 4);
+    }
+    res[2] = (u32x4){o[0], o[1], o[2], o[3]};
+    res[3] = (u32x4){o[4], o[5], o[6], o[7]};
+}
+// the lane's 4 x 16 bytes -> the scratch image of chunk tile cp (dropped when !en)
+template <int LAYOUT>
+__device__ __forceinline__ void coop_store(const CoopW<LAYOUT>& k, int cp, bool en, const u32x4 (&res)[4]) {
+    const uint32_t so = en ? (k.ct0 + (uint32_t)cp) * (uint32_t)W_STAGE : COOP_OFF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(res[i], k.srs, k.sv + (uint32_t)i * 2048u, so, 16);
+}
+template <int LAYOUT>
+__device__ __forceinline__ void coop_flag_store(const CoopW<LAYOUT>& k, int cp, bool en) {
+    const uint32_t so = en ? ((k.ct0 + (uint32_t)cp) * 4u + (uint32_t)k.d) * 4u : COOP_OFF;
+    __builtin_amdgcn_raw_buffer_store_b32(k.e1, k.frs, 0u, so, 16);
+}
+// flag of slice (c, d) into a register (asynchronous: pair with a counted wait); c beyond the panel: any valid flag
+template <int LAYOUT>
+__device__ __forceinline__ void coop_flag_load(const CoopW<LAYOUT>& k, int c, uint32_t& f) {
+    const int cc = c < k.NT ? c : k.NT - 1;
+    const uint32_t* fp = k.flags + ((size_t)(k.ct0 + (uint32_t)cc) * 4u + (uint32_t)k.d);
+    const uint32_t zero = 0;
+    COOP_LD("global_load_dword", f, zero, fp, " sc1");
+}
+// the four DMA pieces of slice (c, d) into ring slot c % 3 (c beyond the panel: zeros, no traffic)
+template <int LAYOUT>
+__device__ __forceinline__ void coop_issue_w(const CoopW<LAYOUT>& k, char* smem, int c) {
+    char* dst = smem + OFF_WD + (c % WD_SLOTS) * W_STAGE + k.d * 4096;
+    const uint32_t so = c < k.NT ? (k.ct0 + (uint32_t)c) * (uint32_t)W_STAGE : COOP_OFF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bufdma16_sc1(k.srs, k.dv[i], so, dst + i * 1024);
+}
+// slice (c, d) produced here and now, synchronously (prologue chunks; fallback of a consumer whose flag stays down)
+template <int LAYOUT>
+__device__ __forceinline__ void coop_produce_now(const CoopW<LAYOUT>& k, int c) {
+    CoopRegs p = {};
+    u32x4 res[4];
+    if (!(k.dbg & 2)) coop_prod_load(k, c, p);
+    coop_prod_wait<0>(p);
+    coop_convert0(k, p, res);
+    coop_convert1(k, p, res);
+    coop_store(k, c, !(k.dbg & 1), res);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    coop_flag_store(k, c, true);
+}
+// make sure slice (c, d) is in the scratch: bounded poll (~COOP_POLLS round trips), then do it ourselves
+constexpr int COOP_POLLS = 6;
+template <int LAYOUT>
+__device__ __forceinline__ void coop_ensure_slow(const CoopW<LAYOUT>& k, int c) {
+    if (k.dbg & 16) return;
+    for (int i = 0; i < COOP_POLLS && !(k.dbg & 4); ++i) {
+        uint32_t f;
+        coop_flag_load(k, c, f);
+        COOP_WAIT1(0, f);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane(f) == k.e1) return;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    if (k.dbg & 8) return;
+    coop_produce_now(k, c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// One K-step s = s0 + O of the W wave (O = position in the octet; FIRST: the tile's first octet, whose predecessors are
+// the prologue's [F(2)] [D(0)] [F(3)] [D(1)]).  cp / en: the chunk this octet produces, and whether it exists.
+template <int LAYOUT, int O, bool FIRST>
+__device__ __forceinline__ bool coop_step(const CoopW<LAYOUT>& k, char* smem, int s, uint32_t (&f)[4], CoopRegs& pr,
+                                          u32x4 (&res)[4], int cp, bool en) {
+    constexpr int P[8] = {10, 0, 0, 0, 4, 0, 0, 1};      // production vector-memory operations per octet position
+    constexpr int Pm1 = (FIRST && O < 1) ? 0 : P[(O + 7) & 7];
+    constexpr int Pm2 = (FIRST && O < 2) ? 0 : P[(O + 6) & 7];
+    if (s >= k.NT) return false;
+    __builtin_amdgcn_sched_barrier(0);
+    // the flag of chunk s+2 (loaded in step s-2): younger in the queue are D x 4, P(s-2), F, D x 4, P(s-1)
+    if constexpr (O == 3) coop_prod_wait<9 + Pm2 + Pm1>(pr);     // ... and the production loads of step s-3
+    COOP_WAIT1(9 + Pm2 + Pm1, f[(O + 2) & 3]);
+    if (__builtin_expect(s + 2 < k.NT && (uint32_t)__builtin_amdgcn_readfirstlane(f[(O + 2) & 3]) != k.e1, 0)) coop_ensure_slow(k, s + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    coop_flag_load(k, s + 4, f[O & 3]);
+    coop_issue_w(k, smem, s + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (O == 0) coop_prod_load(k, cp < k.NT ? cp : k.NT - 1, pr);
+    if constexpr (O == 3) coop_convert0(k, pr, res);
+    if constexpr (O == 4) {
+        coop_convert1(k, pr, res);
+        coop_store(k, cp, en, res);
+    }
+    if constexpr (O == 7) coop_flag_store(k, cp, en);    // the stores of step s-3 are behind this step's first wait
+    __builtin_amdgcn_sched_barrier(0);
+    // chunk s+1's pieces (issued in step s-1) have landed: younger are P(s-1), F, D x 4, P(s)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + Pm1 + P[O]) : "memory");
+    __builtin_amdgcn_s_barrier();
+    return true;
+}
+template <int LAYOUT, bool FIRST>
+__device__ __forceinline__ void coop_octet(const CoopW<LAYOUT>& k, char* smem, int s0, uint32_t (&f)[4]) {
+    CoopRegs pr = {};
+    u32x4 res[4] = {};
+    const int cp = s0 + COOP_LEAD + k.cls;
+    const bool en = cp < k.NT;
+    // (a tile that ends inside the octet before step 3 has consumed the production loads of step 0: they are asm loads,
+    // so their registers must not die while the loads are in flight)
+    if (!coop_step<LAYOUT, 0, FIRST>(k, smem, s0 + 0, f, pr, res, cp, en)) return;
+    if (!coop_step<LAYOUT, 1, FIRST>(k, smem, s0 + 1, f, pr, res, cp, en)) { coop_prod_wait<0>(pr); return; }
+    if (!coop_step<LAYOUT, 2, FIRST>(k, smem, s0 + 2, f, pr, res, cp, en)) { coop_prod_wait<0>(pr); return; }
+    if (!coop_step<LAYOUT, 3, FIRST>(k, smem, s0 + 3, f, pr, res, cp, en)) { coop_prod_wait<0>(pr); return; }
+    if (!coop_step<LAYOUT, 4, FIRST>(k, smem, s0 + 4, f, pr, res, cp, en)) return;
+    if (!coop_step<LAYOUT, 5, FIRST>(k, smem, s0 + 5, f, pr, res, cp, en)) return;
+    if (!coop_step<LAYOUT, 6, FIRST>(k, smem, s0 + 6, f, pr, res, cp, en)) return;
+    coop_step<LAYOUT, 7, FIRST>(k, smem, s0 + 7, f, pr, res, cp, en);
+}
+
+// One whole tile on W wave d: prologue production, the first two chunks' DMAs, then the octets.  Barrier for barrier the
+// twin of wdma_segment / deq_segment (two prologue barriers, one per K-step).
+template <int LAYOUT>
+__device__ __forceinline__ void coop_tile(const CoopW<LAYOUT>& k, char* smem) {
+    const int NT = k.NT;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the previous tile's trailing (zero) DMAs
+    // the chunks below COOP_LEAD of this workgroup's class (class m: chunks m and m + 8)
+    {
+        CoopRegs p0, p1;
+        u32x4 r0[4], r1[4];
+        const int c0 = k.cls, c1 = k.cls + 8;
+        const bool en1 = c1 < COOP_LEAD && c1 < NT;
+        coop_prod_load(k, c0, p0);
+        coop_prod_load(k, en1 ? c1 : c0, p1);
+        coop_prod_wait<0>(p0);
+        coop_prod_wait<0>(p1);
+        coop_convert0(k, p0, r0);
+        coop_convert1(k, p0, r0);
+        coop_store(k, c0, true, r0);
+        coop_convert0(k, p1, r1);
+        coop_convert1(k, p1, r1);
+        coop_store(k, c1, en1, r1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        coop_flag_store(k, c0, true);
+        coop_flag_store(k, c1, en1);
+    }
+    uint32_t f[4] = {0, 0, 0, 0};
+    coop_flag_load(k, 0, f[0]);
+    coop_flag_load(k, 1, f[1]);
+    COOP_WAIT1(0, f[0]);
+    COOP_WAIT1(0, f[1]);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane(f[0]) != k.e1) coop_ensure_slow(k, 0);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane(f[1]) != k.e1) coop_ensure_slow(k, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    coop_flag_load(k, 2, f[2]);
+    coop_issue_w(k, smem, 0);
+    coop_flag_load(k, 3, f[3]);
+    coop_issue_w(k, smem, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");        // chunk 0 has landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    coop_octet<LAYOUT, true>(k, smem, 0, f);
+    for (int s0 = 8; s0 < NT; s0 += 8) coop_octet<LAYOUT, false>(k, smem, s0, f);
+    // the last steps' flag loads are still in flight: their registers stay live until they have landed
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+}
+
 #define MXQ_LANE_ID(ln) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln))
 
 // grid = dp_grid persistent workgroups, which deal the first dp_tiles tiles round-robin (tile = block + k * dp_grid:
 // blocks b and b + 8 share an XCD and dp_grid is a multiple of 8 or the tile count itself, so a workgroup's tiles
 // keep its XCD's label) and overlap one tile's output with the next one's first DMAs, + 8 * units stream-K
 // workgroups for the `tail` tiles beyond them.
-template <int ABL, int LAYOUT>
+template <int ABL, int LAYOUT, bool COOP = false>
 __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* __restrict__ x,
                                                                const uint32_t* __restrict__ qweight,
                                                                const float4* __restrict__ rowmeta,
@@ -744,13 +1073,52 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
                 const int m0 = tm * BM, n0 = tn * BN;
                 const bool more = tile + dp_grid < dp_tiles;
                 if (more) tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
-                mma_segment<ABL, LAYOUT == LAYOUT_DENSE16>(smem, wave, ln, NT, cur, true, y, M, N, m0, n0, NT, sk, [&] {
+                mma_segment<ABL, LAYOUT == LAYOUT_DENSE16 || COOP>(smem, wave, ln, NT, cur, true, y, M, N, m0, n0, NT, sk, [&] {
                     if (more) {
                         xdma_setup(nxt, x, M, K, tm * BM, 0, wave, ln);
                         mma_prologue_issue<ABL>(nxt, smem, wave, NT);
                     }
                 });
                 cur = nxt;
+            }
+        } else if constexpr (COOP) {
+            // cooperative-dequant mode: ws = the fp16 scratch image, cnt = control words + flags (launch8)
+            int ln;
+            MXQ_LANE_ID(ln);
+            CoopW<LAYOUT> k;
+            k.qw = (const char*)qweight;
+            k.flags = (const uint32_t*)cnt + COOP_CTL_INTS;
+            k.srs = make_rsrc(ws, (uint32_t)tiles_n * (uint32_t)NT * (uint32_t)W_STAGE);
+            k.frs = make_rsrc(k.flags, (uint32_t)tiles_n * (uint32_t)NT * 16u);
+            k.d = wave - N_MMA;
+            k.NT = NT;
+            k.dbg = units;
+            {
+                uint32_t e;
+                const uint32_t zero = 0;
+                COOP_LD("global_load_dword", e, zero, cnt, " sc1");
+                COOP_WAIT1(0, e);
+                k.e1 = (uint32_t)__builtin_amdgcn_readfirstlane(e) + 1u;
+            }
+            int cls;
+            tile_of_block(bid, tiles_m, tiles_n, tm, tn, cls);
+            for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
+                MXQ_LANE_ID(ln);
+                coop_tile_setup(k, ln, N, K, tn, cls, rowmeta);
+                if (tile + dp_grid < dp_tiles) tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn, cls);
+                coop_tile(k, smem);
+            }
+            // the launch is over for this workgroup's scratch traffic; the LAST workgroup to say so moves the epoch on
+            // (every flag of this launch stops matching) and re-arms the count
+            if (k.d == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int old = 0;
+                if (ln == 0) old = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if (old == (int)gridDim.x - 1 && ln == 0) {
+                    __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cnt, (int)k.e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         } else if constexpr (LAYOUT == LAYOUT_DENSE16) {
             int ln;
@@ -885,10 +1253,23 @@ int cu_count() {
 }
 
 constexpr size_t CNT_BYTES = 64 * 1024;   // K-step counters at the head of the workspace (>= 8*units*N_MMA ints)
+// workspace = [stream-K counters 64 KB][coop control words + flags 512 KB][stream-K slots | coop scratch image]; the
+// first HEAD_BYTES must be zero when the buffer is first used (the kernels keep them consistent afterwards)
+constexpr size_t COOP_HEAD_BYTES = 512 * 1024;
+constexpr size_t HEAD_BYTES = CNT_BYTES + COOP_HEAD_BYTES;
+constexpr int COOP_MIN_TILES_M = 8, COOP_MIN_NT = 24;
 
+size_t coop_scratch_bytes(int N, int K) { return (size_t)((N + BN - 1) / BN) * (size_t)(K / BK) * W_STAGE; }
+bool coop_shape_ok(int N, int K) {
+    const size_t ct = (size_t)((N + BN - 1) / BN) * (size_t)(K / BK);
+    return K / BK >= COOP_MIN_NT && COOP_CTL_INTS * 4 + ct * 16 <= COOP_HEAD_BYTES && ct * W_STAGE < ((size_t)1 << 31);
+}
+
+// mode: 0 = automatic, 1 = stream-K split of the tail forced (tests), 2 = never the cooperative-dequant mode
 template <int ABL, int LAYOUT = MXQ_LAYOUT_MIXED>
 static int launch8(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                   void* workspace, size_t ws_bytes, bool force, hipStream_t stream) {
+                   void* workspace, size_t ws_bytes, int mode, hipStream_t stream) {
+    const bool force = mode == 1;
     // the DMA descriptors address one tile's rows with 32-bit offsets: 256 rows of x, 8 row-blocks of packed weights
     // 32-bit offsets: 256 rows of x per DMA descriptor; the whole packed weight behind one (offsets < 2^31)
     if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(N / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 31))
@@ -901,7 +1282,7 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     const int cus = cu_count() / 8 * 8, units = cus / 8;
     int dp_tiles = tiles, tail = 0;
     if (workspace && tiles % cus != 0 && units * 8 * N_MMA * sizeof(int) <= CNT_BYTES &&
-        ws_bytes >= CNT_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
+        ws_bytes >= HEAD_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
         const int t8 = (tiles % cus) / 8;   // tail tiles per XCD (the first tail % 8 XCDs hold one more)
         // Splitting the tail costs ~20 us (every unit parks 128 KB of fp32 partials, the finishers read them back)
         // and saves the idle share of one tile time, (1 - tail/CUs) * NT K-steps of ~1 us: worth it from ~24 idle
@@ -913,36 +1294,59 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
         }
     }
     const int dp_grid = dp_tiles < cus ? dp_tiles : cus;   // persistent: at most one data-parallel workgroup per CU
+    if constexpr (ABL == 0 && (LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC)) {
+        // cooperative-dequant mode: from 8 token tiles on (a panel's chunk is converted once per 8 workgroups), whole
+        // tiles only, and only with a workspace that holds the fp16 image of this weight
+        if (mode != 2 && workspace && tail == 0 && tiles_m >= COOP_MIN_TILES_M && coop_shape_ok(N, K) &&
+            ws_bytes >= HEAD_BYTES + coop_scratch_bytes(N, K)) {
+            e = hipFuncSetAttribute((const void*)mxq_gemm8_f16_kernel<ABL, LAYOUT, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+            if (e != hipSuccess) return (int)e;
+            mxq_gemm8_f16_kernel<ABL, LAYOUT, true><<<dp_grid, THREADS, SMEM_BYTES, stream>>>(
+                (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m,
+                tiles_n, dp_tiles, dp_grid, 0, getenv("MXQ_COOP_DBG") ? atoi(getenv("MXQ_COOP_DBG")) : 0,
+                (float*)((char*)workspace + HEAD_BYTES), (int*)((char*)workspace + CNT_BYTES));
+            return (int)hipGetLastError();
+        }
+    }
     const int grid = dp_grid + (tail ? cus : 0);
     mxq_gemm8_f16_kernel<ABL, LAYOUT><<<grid, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
-        dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace);
+        dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + HEAD_BYTES), (int*)workspace);
     return (int)hipGetLastError();
 }
 
 }   // namespace
 
-size_t mxq_gemm8_workspace_bytes() { return CNT_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
+size_t mxq_gemm8_workspace_bytes() { return HEAD_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
+size_t mxq_gemm8_workspace_head_bytes() { return HEAD_BYTES; }
+// ... that also holds the cooperative-dequant mode's fp16 image of an [N, K] weight
+size_t mxq_gemm8_workspace_bytes_for(int N, int K) {
+    const size_t base = mxq_gemm8_workspace_bytes();
+    if (N <= 0 || K <= 0 || !coop_shape_ok(N, K)) return base;
+    const size_t coop = HEAD_BYTES + coop_scratch_bytes(N, K);
+    return coop > base ? coop : base;
+}
 
 int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         void* workspace, size_t ws_bytes, int force, hipStream_t stream) {
-    return launch8<0>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, force != 0, stream);
+                         void* workspace, size_t ws_bytes, int mode, hipStream_t stream) {
+    return launch8<0>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, mode, stream);
 }
 
 int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream) {
     switch (layout) {
-        case MXQ_LAYOUT_MIXED: return launch8<0, MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
-        case MXQ_LAYOUT_W2G16: return launch8<0, MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
-        case MXQ_LAYOUT_W4ROW: return launch8<0, MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
-        case MXQ_LAYOUT_MIXEDC: return launch8<0, MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
+        case MXQ_LAYOUT_MIXED: return launch8<0, MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
+        case MXQ_LAYOUT_W2G16: return launch8<0, MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
+        case MXQ_LAYOUT_W4ROW: return launch8<0, MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
+        case MXQ_LAYOUT_MIXEDC: return launch8<0, MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
     }
     return -1;
 }
 
 // hoisted-dequant mode: w16 = dense fp16 [N, K] weight (the dequant kernel's output); same tiles, no stream-K tail
 int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, hipStream_t stream) {
-    return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, false, stream);
+    return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, 0, stream);
 }
 
 #ifdef MXQ_PROFILING
@@ -953,19 +1357,24 @@ extern "C" int mxq_prof_gemm8_ablate_f16(const void* x, const void* qweight, con
                                          int K, int abl, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     switch (abl) {
-        case 0: return launch8<0>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 1: return launch8<1>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 2: return launch8<2>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 4: return launch8<4>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 5: return launch8<5>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 6: return launch8<6>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 256: return launch8<256>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 260: return launch8<260>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 1024: return launch8<1024>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // correct results
-        case 2048: return launch8<2048>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // correct results
-        case 2050: return launch8<2050>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 0: return launch8<0>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 1: return launch8<1>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 2: return launch8<2>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 4: return launch8<4>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 5: return launch8<5>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 6: return launch8<6>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 256: return launch8<256>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 260: return launch8<260>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 1024: return launch8<1024>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);   // correct results
+        case 2048: return launch8<2048>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);   // correct results
+        case 2050: return launch8<2050>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
     }
     return -1;   // MXQ_E_SHAPE: not an ablation this build carries
+}
+
+// the hoisted mode's MFMA kernel alone on an already dequantised fp16 weight
+extern "C" int mxq_prof_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, void* stream_) {
+    return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, 0, (hipStream_t)stream_);
 }
 
 // Diagnostic build with cycle stamps (cdna guide section 7, "In-kernel stamps"): dbg receives, per workgroup and wave,

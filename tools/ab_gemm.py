@@ -47,6 +47,17 @@ def make_call(v, x, p, wd, out):
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (v, rc)
         return call
+    if v == "dense":           # the hoisted mode's MFMA kernel alone, on the dequantised weight
+        fn = prof_lib().mxq_prof_gemm8_dense_f16
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+        M = x.shape[0]
+
+        def call():
+            rc = fn(x.data_ptr(), wd.data_ptr(), out.data_ptr(), M, p.N, p.K,
+                    torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, (v, rc)
+        return call
     if v == "hoist":
         return lambda: packing.linear_hoisted(x, p, out=out)
     if v == "fused":
