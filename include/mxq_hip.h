@@ -100,27 +100,18 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * whose tile count is not a multiple of the CU count (stream-K tail, csrc/gemm8.hip): e.g. 512 tokens
  * x 4096^2 is 64 tiles, a quarter of the 256 CUs, unless every CU takes a quarter of a tile's K range.
  * `workspace` is device memory of at least mxq_gemm_workspace_bytes() bytes, 16-byte aligned, whose
- * first mxq_gemm_workspace_head_bytes() bytes the caller zeroes ONCE (hipMemset) before first use; the
- * kernels keep that head consistent, so the buffer can be reused by every later launch on the SAME stream
- * (launches on different streams need different workspaces).  workspace == NULL selects the
- * workspace-free schedule of mxq_linear_f16.
- * Cooperative-dequant mode (csrc/gemm8.hip): from 2048 tokens on (8 token tiles), when the tile count
- * needs no stream-K split and the workspace holds at least mxq_gemm_workspace_bytes_for(N, K) bytes, the
- * workgroups that share a 128-channel weight panel convert each of its 128 x 64 tiles ONCE between them
- * into an fp16 image inside the workspace and all stream it from there (flags + a launch epoch in the
- * head; no workgroup ever waits unboundedly on another: a tile that is not there in time is converted
- * locally).  Same products, same summation order: results are bit-identical to the fused mode.
+ * first 64 KiB the caller zeroes ONCE (hipMemset) before first use; the kernels leave it zeroed, so
+ * it can be reused by every later launch on the SAME stream (launches on different streams need
+ * different workspaces).  workspace == NULL selects the workspace-free schedule of mxq_linear_f16.
  * The tail is only split where that pays (about 24 idle K-steps per CU; it does for 128 < M <= 1024 on
  * the Llama shapes, not for gate/up at M = 2048).
  * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 8 = the
  * 256x128-tile kernel (MFMA waves stream x, dedicated waves dequantise, persistent over tiles, stream-K tail;
- * csrc/gemm8.hip) at any M, 9 = the same but splitting its tail whenever that is structurally possible (tests),
- * 10 = the same but never in cooperative-dequant mode; anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
+ * csrc/gemm8.hip) at any M, 9 = the same but splitting its tail whenever that is structurally possible (tests);
+ * anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
  * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
  * used by tools/ alone: they are not part of this ABI.) */
 size_t mxq_gemm_workspace_bytes(void);
-size_t mxq_gemm_workspace_head_bytes(void);
-size_t mxq_gemm_workspace_bytes_for(int N, int K);
 int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                       void* workspace, size_t workspace_bytes, void* stream);
 int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,

@@ -43,8 +43,6 @@ SIGNATURES = {
     "mxq_actquant_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int,
                                  c_void_p]),
     "mxq_gemm_workspace_bytes": (c_size_t, []),
-    "mxq_gemm_workspace_head_bytes": (c_size_t, []),
-    "mxq_gemm_workspace_bytes_for": (c_size_t, [c_int, c_int]),
     "mxq_hoist_scratch_bytes": (c_size_t, [c_int, c_int]),
     "mxq_linear_f16_hoisted": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "mxq_linear_f16_ws": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -231,8 +231,6 @@ int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void
 }
 
 size_t mxq_gemm_workspace_bytes(void) { return mxq_gemm8_workspace_bytes(); }
-size_t mxq_gemm_workspace_head_bytes(void) { return mxq_gemm8_workspace_head_bytes(); }
-size_t mxq_gemm_workspace_bytes_for(int N, int K) { return mxq_gemm8_workspace_bytes_for(N, K); }
 
 static int gemm_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* workspace, size_t ws_bytes, hipStream_t stream) {
@@ -258,8 +256,8 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
     if (variant == 0) return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
     if (variant == 1) return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-    if (variant == 8 || variant == 9 || variant == 10)
-        return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant - 8,
+    if (variant == 8 || variant == 9)
+        return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 9,
                                     (hipStream_t)stream);
     return MXQ_E_SHAPE;
 }

@@ -26,11 +26,9 @@ int mxq_launch_gemm_f16(const void* x, const void* qweight, const void* rowmeta,
 int mxq_launch_gemm1_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          hipStream_t stream);   // 128x128 tile, two LDS stages (gemm.hip)
 size_t mxq_gemm8_workspace_bytes();
-size_t mxq_gemm8_workspace_head_bytes();
-size_t mxq_gemm8_workspace_bytes_for(int N, int K);   // ... that also holds the cooperative-dequant mode's fp16 image
 int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         void* workspace, size_t ws_bytes, int mode,
-                         hipStream_t stream);   // 256x128 tile: MFMA waves stream x, dedicated waves dequantise; stream-K tail / cooperative-dequant mode with a workspace (gemm8.hip); mode: 0 automatic, 1 split the tail even when it does not pay, 2 never the cooperative mode
+                         void* workspace, size_t ws_bytes, int force,
+                         hipStream_t stream);   // 256x128 tile: MFMA waves stream x, dedicated waves dequantise; stream-K tail with a workspace (gemm8.hip); force: split even when it does not pay
 int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K,
                                hipStream_t stream);   // hoisted-dequant mode: w16 = dense fp16 [N, K] weight
 int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,

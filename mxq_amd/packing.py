@@ -30,19 +30,13 @@ def _stream(t: torch.Tensor) -> int:
 
 
 _WORKSPACES: Dict[tuple, torch.Tensor] = {}
+_WS_HEAD = 65536      # bytes of K-step counters at the head of a workspace (include/mxq_hip.h)
 
 
-def _ws_head() -> int:
-    """Bytes at the head of a workspace (stream-K counters, cooperative-dequant control words and flags:
-    include/mxq_hip.h) that must be zero when the buffer is first used."""
-    return _lib.load().mxq_gemm_workspace_head_bytes()
-
-
-def gemm_workspace(device: torch.device, N: int = 0, K: int = 0) -> torch.Tensor:
-    """Scratch buffer of the prefill GEMM (include/mxq_hip.h: mxq_linear_f16_ws: stream-K slots, and the fp16 image
-    of an [N, K] weight for the cooperative-dequant mode), one per (device, stream), grown on demand: launches on
-    one stream run in order and may share it, launches on different streams may not.  Its head must be zero when
-    the buffer is first used; the kernels keep it consistent.
+def gemm_workspace(device: torch.device) -> torch.Tensor:
+    """Scratch buffer of the stream-K prefill GEMM (include/mxq_hip.h: mxq_linear_f16_ws), one per
+    (device, stream): launches on one stream run in order and may share it, launches on different
+    streams may not.  Its counter head must be zero when a launch starts; the kernels leave it zeroed.
 
     Eager use: the head is zeroed once, when the buffer is created.  Under hipGraph capture the buffer handed out
     (new or cached -- torch's capture stream keeps its handle across captures) gets a captured memset in front of
@@ -53,13 +47,12 @@ def gemm_workspace(device: torch.device, N: int = 0, K: int = 0) -> torch.Tensor
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream)
     ws = _WORKSPACES.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
-    lib = _lib.load()
-    nbytes = lib.mxq_gemm_workspace_bytes_for(N, K) if N > 0 and K > 0 else lib.mxq_gemm_workspace_bytes()
-    if ws is None or ws.numel() < nbytes:
+    if ws is None:
+        nbytes = _lib.load().mxq_gemm_workspace_bytes()
         ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        ws[:_ws_head()].zero_()
+        ws[:_WS_HEAD].zero_()
     elif capturing:
-        ws[:_ws_head()].zero_()
+        ws[:_WS_HEAD].zero_()
     return ws
 
 
@@ -112,7 +105,7 @@ def reset_gemm_workspace(device: Optional[torch.device] = None):
     for (dev_index, _stream), ws in list(_WORKSPACES.items()):
         if device is None or (device.index if device.index is not None else torch.cuda.current_device()) == dev_index:
             torch.cuda.synchronize(dev_index)
-            ws[:_ws_head()].zero_()
+            ws[:_WS_HEAD].zero_()
             torch.cuda.synchronize(dev_index)
 
 
@@ -265,7 +258,7 @@ def dequant(p: PackedMXQ) -> torch.Tensor:
     return out
 
 
-GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "nocoop": 10}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
+GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
 
 
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
@@ -312,7 +305,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         elif path == "auto" and M <= 4:                          # GEMV: no workspace involved
             rc = lib.mxq_linear_f16(*args, _stream(x2))
         else:
-            ws = gemm_workspace(x2.device, p.N, p.K) if path in ("auto", "gemm", "fused", "gemm8", "gemm9", "nocoop") else None
+            ws = gemm_workspace(x2.device) if path in ("auto", "gemm", "fused", "gemm8", "gemm9") else None
             wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
             if path == "auto":
                 rc = lib.mxq_linear_f16_ws(*args, wsp, wsn, _stream(x2))

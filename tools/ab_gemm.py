@@ -47,14 +47,14 @@ def make_call(v, x, p, wd, out):
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (v, rc)
         return call
-    if v in ("dense", "dense2"):     # dense2: two DMA waves x 8 pieces instead of four x 4 (experiment)           # the hoisted mode's MFMA kernel alone, on the dequantised weight
+    if v == "dense":                 # the hoisted mode's MFMA kernel alone, on the dequantised weight
         fn = prof_lib().mxq_prof_gemm8_dense_f16
         fn.restype = ctypes.c_int
-        fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
         M = x.shape[0]
 
         def call():
-            rc = fn(x.data_ptr(), wd.data_ptr(), out.data_ptr(), M, p.N, p.K, int(v == "dense2"),
+            rc = fn(x.data_ptr(), wd.data_ptr(), out.data_ptr(), M, p.N, p.K,
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (v, rc)
         return call
@@ -73,7 +73,6 @@ def main():
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008", help="NxK list")
     ap.add_argument("--json", default=None)
     ap.add_argument("--reps", type=int, default=20, help="launches per graph")
-    ap.add_argument("--dbgenv", default=None, help="set MXQ_COOP_DBG to this AFTER the checked warm-up launches (debug builds)")
     ap.add_argument("--nocheck", action="store_true", help="skip the result check (debug builds with parts switched off)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -96,14 +95,11 @@ def main():
             if not v.startswith("abl") and not args.nocheck:
                 err = ((out.float() - yref).abs().max() / yref.abs().max()).item()
                 assert err < 1e-3, (v, N, K, err)
-            if args.dbgenv is not None and v == "gemm8":
-                os.environ["MXQ_COOP_DBG"] = args.dbgenv
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
                 for _ in range(args.reps):
                     call()
             graphs[v] = gr
-            os.environ.pop("MXQ_COOP_DBG", None)
         ts = {v: [] for v in variants}
         for _ in range(args.rounds):
             for v in variants:

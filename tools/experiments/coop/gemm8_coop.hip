@@ -36,6 +36,7 @@
 // another workgroup.  Slots and counters cross XCDs (one L2 each): slot traffic is agent-scope relaxed atomics
 // (global_store / load ... sc1), ordered against the counter bump by s_waitcnt vmcnt(0).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "mxq_dequant.h"
 #include "mxq_format.h"
@@ -75,12 +76,18 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ void bufdma16(rsrc_t rsrc, uint32_t voff, uint32_t soff, void* l) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
 }
+// the same with sc1 (aux bit 4): served by L2, never by this CU's L1 -- for bytes another workgroup wrote in this launch
+__device__ __forceinline__ void bufdma16_sc1(rsrc_t rsrc, uint32_t voff, uint32_t soff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 16);
+}
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 
 // XCD-aware tile order (speed only): tiles are dealt to the 8 XCDs as compact 2-D blocks (4 x 2 regions)
-__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+// cls (coop mode, speed only): the production class of the workgroup on this tile -- the (up to) eight workgroups that
+// run one weight panel at the same time get eight different classes
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn, int& cls) {
     if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0) {
         const int e = bid & 7, l = bid >> 3;
         const int rm = tiles_m >> 2, rn = tiles_n >> 1;
@@ -91,6 +98,7 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
         const int pw = left < 16 ? left : 16;
         tm = (e & 3) * rm + j / pw;
         tn = (e >> 2) * rn + p * 16 + j % pw;
+        cls = (e & 3) * 2 + ((j / pw) & 1);
         return;
     }
     const int nwg = tiles_m * tiles_n;
@@ -98,6 +106,30 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     tm = lin % tiles_m;
     tn = lin / tiles_m;
+    cls = tm & 7;
+}
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    int cls;
+    tile_of_block(bid, tiles_m, tiles_n, tm, tn, cls);
+}
+// Tile t of a persistent workgroup's sequence; false = past the end.  COOP (cooperative-dequant mode): all token tiles of
+// a weight panel carry the same t & 7, i.e. (as workgroups are observed to be placed) run on ONE XCD, whose L2 then holds
+// the panel's fp16 image between the workgroup that writes a chunk and the ones that read it (speed only: a reader
+// trusts nothing but flags raised on its own XCD).  The index space is padded to 8 panels per group: t with
+// tn >= tiles_n do not exist, and since tn grows with t for a given workgroup, its first missing tile ends its sequence.
+template <bool COOP>
+__device__ __forceinline__ bool map_tile(int t, int tiles_m, int tiles_n, int dp_tiles, int& tm, int& tn, int& cls) {
+    if (t >= dp_tiles) return false;
+    if constexpr (COOP) {
+        const int e = t & 7, l = t >> 3;
+        tm = l % tiles_m;
+        tn = (l / tiles_m) * 8 + e;
+        cls = tm & 7;
+        return tn < tiles_n;
+    } else {
+        tile_of_block(t, tiles_m, tiles_n, tm, tn, cls);
+        return true;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,6 +681,8 @@ __device__ __forceinline__ void deq_segment(Deq& c, const Deq& nxt, int wave, in
 // their summation order are those of the fused mode, so the two modes agree bit for bit.
 struct WDma {
     rsrc_t rsrc;         // weight rows n0 .. of this tile (range-checked: rows beyond N read as zeros)
+    int two;             // profiling experiment: 1 = this wave issues 8 pieces (rows 64 d ..), 2 = none
+    uint32_t voff2[4];
     uint32_t voff[4];
     uint32_t k0;
     int d, NT;
@@ -660,13 +694,36 @@ __device__ __forceinline__ void wdma_setup(WDma& w, const uint16_t* __restrict__
     w.k0 = (uint32_t)kt0 * (BK * 2);
     w.d = wave - N_MMA;
     w.NT = nsteps;
+    w.two = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = w.d * 32 + i * 8 + (lane >> 3);
         w.voff[i] = (uint32_t)row * (uint32_t)K * 2u + ((((uint32_t)lane & 7u) ^ ((uint32_t)row & 7u)) << 4);
+        w.voff2[i] = 0;
+    }
+}
+__device__ __forceinline__ void wdma_two(WDma& w, int K, int lane) {   // experiment: 2 DMA waves x 8 pieces
+    if (w.d >= 2) { w.two = 2; return; }
+    w.two = 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = w.d * 64 + i * 8 + (lane >> 3), row2 = row + 32;
+        w.voff[i] = (uint32_t)row * (uint32_t)K * 2u + ((((uint32_t)lane & 7u) ^ ((uint32_t)row & 7u)) << 4);
+        w.voff2[i] = (uint32_t)row2 * (uint32_t)K * 2u + ((((uint32_t)lane & 7u) ^ ((uint32_t)row2 & 7u)) << 4);
     }
 }
 __device__ __forceinline__ void issue_w(const WDma& w, char* smem, int t) {
+#ifdef MXQ_PROFILING
+    if (w.two == 2) return;
+    if (w.two == 1) {
+        char* dst = smem + OFF_WD + (t % WD_SLOTS) * W_STAGE + w.d * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bufdma16(w.rsrc, w.voff[i], w.k0 + (uint32_t)t * (BK * 2), dst + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bufdma16(w.rsrc, w.voff2[i], w.k0 + (uint32_t)t * (BK * 2), dst + 4096 + i * 1024);
+        return;
+    }
+#endif
     char* dst = smem + OFF_WD + (t % WD_SLOTS) * W_STAGE + w.d * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) bufdma16(w.rsrc, w.voff[i], w.k0 + (uint32_t)t * (BK * 2), dst + i * 1024);
@@ -679,11 +736,20 @@ __device__ __forceinline__ void wdma_prologue_issue(const WDma& w, char* smem) {
 template <class Next>
 __device__ __forceinline__ void wdma_segment(const WDma& w, char* smem, bool pre, Next&& next) {
     if (!pre) wdma_prologue_issue(w, smem);
-    if (w.NT > 1 && !pre) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (w.NT > 1 && !pre && w.two == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
     int t = 0;
+#ifdef MXQ_PROFILING
+    if (w.two == 1) {
+        for (; t + 2 < w.NT; ++t) {
+            issue_w(w, smem, t + 2);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+#endif
     for (; t + 2 < w.NT; ++t) {
         issue_w(w, smem, t + 2);                                   // slot (t+2) % 3 was last read in step t-1
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // this step's 4 DMAs stay in flight
@@ -696,13 +762,413 @@ __device__ __forceinline__ void wdma_segment(const WDma& w, char* smem, bool pre
     next();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// cooperative-dequant mode ("coop"): the workgroups that share a weight panel dequantise it ONCE between them
+// ------------------------------------------------------------------------------------------------
+// The fused kernel dequantises every 128 x 64 weight tile once per 256 tokens; at 2048 tokens the eight workgroups
+// (tm = 0..7) of a 128-channel panel all convert the same packed words at the same time, and that conversion -- not
+// the MFMAs -- is the critical path of their K-steps (header of deq_segment_h).  Here every chunk tile of the panel
+// is converted by ONE of them into an fp16 scratch image in global memory (L2 / Infinity Cache resident), published
+// with a flag, and streamed into everybody's LDS ring by LDS-DMA exactly as the hoisted mode streams a dequantised
+// weight: the MFMA waves run the DENSE loop unchanged, the conversion work per workgroup drops to 1/8, and there is no
+// separate dequant pass (the image of chunk c is written while the K-steps c-23 .. c-15 run).
+//
+//   scratch image of chunk tile (tn, c): 16 KB at ((tn * NT + c) * 16 KB), 16-byte cell (row, slot) at
+//     (slot * 128 + row) * 16 -- a producer's store instruction writes eight whole 128-B lines, a consumer's DMA
+//     piece reads eight whole lines (slots XOR-swizzled on the way into LDS like the x tile).
+//   flags[(tn * NT + c) * 2 + p] = epoch + 1 once rows 64p .. 64p+63 of that tile are in the scratch; `epoch` is a
+//     word of the workspace that the last workgroup to finish a launch increments (hipGraph-replay safe, no memset
+//     between launches; the flags of earlier launches never match).
+//   waves 8, 9 = DMA waves (half p = 0, 1): wave p loads the flag of (chunk s+4, half p) in K-step s, checks the
+//     flag of chunk s+2 (loaded two steps earlier) and issues that half's eight DMA pieces.  A flag that is not up
+//     yet is polled for a bounded time; after that the wave converts the half ITSELF, stores it, and goes on --
+//     nobody ever depends on another workgroup making progress (a duplicate conversion writes the same bytes).
+//   waves 10, 11 = producer waves (half p = 0, 1): workgroup class m (tile_of_block: the eight classes of a panel
+//     run concurrently) converts chunk 8j + COOP_LEAD + m during K-steps 8j .. 8j+7 -- loads in step 8j, the two
+//     32-row passes in steps 8j+2..8j+5, sc1 stores behind each -- and raises its flag in step 8j+9, behind the counted
+//     wait that covers the stores.  (A first version ran production on the DMA waves: vmcnt retires in issue order,
+//     so every DMA wait younger than a write-through store also waited for that store's acknowledgement, ~1.5 us per
+//     octet.  Two DMA waves with 8 pieces each keep the dense kernel's speed: profiles/r02_coop_*.)  The chunks below
+//     COOP_LEAD come from the tile's prologue (class m: chunks m and m + 8, one (chunk, half) per W wave).
+//   The producers' K loop is unrolled by 8 ("octet"), the DMA waves' by 4, so that every wait is a constant count of
+//   younger vector-memory operations; loads that return registers are inline asm (the compiler would wait for them
+//   with a drain, and pads no hazards inside asm: COOP_LD).  All cross-workgroup traffic is sc1 (write-through
+//   stores, L1-bypassing loads and DMAs): the hand-off forms of MI355X_MICROARCH.md "Hand-offs measured with sc1
+//   loads"; producer and consumer of a half are single waves, so no barrier is part of any hand-off.
+constexpr int COOP_LEAD = 15;
+constexpr int COOP_CTL_INTS = 1024;            // control words in front of the flags: [0] epoch, [1] finished workgroups
+constexpr uint32_t COOP_OFF = 0x80000000u;     // an soffset that puts any access beyond its buffer: loads 0, stores dropped
+
+struct CoopRegs { uint32_t a, b, c, z0, z1, sc, q0x, q0y, q1x, q1y; };
+
+template <int LAYOUT>
+struct CoopW {
+    static constexpr bool COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
+    static constexpr int BYTES = COMPACT ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
+    const char* qw;          // packed weight
+    const uint32_t* flags;   // flag words
+    rsrc_t srs, frs;         // scratch / flags as buffers (stores, DMA)
+    uint32_t e1;             // what a ready flag holds in this launch
+    int p, NT;               // the wave's half of the 128 tile rows
+    int dbg;
+    uint32_t img;
+    mutable uint32_t acc[16];
+    // per tile
+    uint32_t ct0;            // chunk-tile index of the panel's chunk 0
+    int cls;                 // production class of this workgroup on this tile
+    uint32_t dv[8];          // DMA source offsets inside a chunk tile (per lane)
+    uint32_t pv[2][7];       // production load offsets inside the packed weight at chunk 0 (per lane, per pass): A B C Z0 Z1 SC QQ
+    uint32_t sv[2];          // production store offset inside a chunk tile (res[0]; res[i] at + i * 2 KB)
+    int H;                   // the lane's column half
+    float s4[2], z4[2];
+};
+
+// (s_nop 4: the base may have been written by a VALU instruction just before -- an SGPR spill reload is a v_readlane --
+// and a vector-memory instruction that reads an SGPR needs 5 wait states behind such a write; the compiler pads its
+// own instructions, never the inside of an asm statement)
+#define COOP_LD(op, dst, voff, base, extra) \
+    asm volatile("s_nop 4\n\t" op " %0, %1, %2" extra : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#define COOP_WAIT1(n, r0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "n"(n) : "memory")
+
+template <int LAYOUT>
+__device__ __forceinline__ void coop_tile_setup(CoopW<LAYOUT>& k, int lane, int N, int K, int tn, int cls,
+                                                const float4* __restrict__ rowmeta) {
+    constexpr bool COMPACT = CoopW<LAYOUT>::COMPACT;
+    const int NT = k.NT;
+    k.ct0 = (uint32_t)tn * (uint32_t)NT;
+    k.cls = cls;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = k.p * 64 + i * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ (row & 7);
+        k.dv[i] = (uint32_t)(slot * 128 + row) * 16u;
+    }
+    k.H = lane >> 5;
+    const int H = k.H;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int row = k.p * 64 + ps * 32 + (lane & 31), r = row & 15;
+        int rb = (tn * BN + row) >> 4;                // row-block; beyond the weight: any valid one (its rows are never stored)
+        rb = rb < (N >> 4) ? rb : (N >> 4) - 1;
+        const uint32_t blk = (uint32_t)rb * (uint32_t)NT * (uint32_t)CoopW<LAYOUT>::BYTES;
+        k.pv[ps][0] = blk + (uint32_t)((2 * H * 16 + r) * 4);                          // A: codes of 2-bit group 2H
+        k.pv[ps][1] = blk + (uint32_t)(((H ? 48 : 16) + r) * 4);                       // B: group 1 | 4-bit half 0
+        k.pv[ps][2] = blk + (uint32_t)(((H ? 64 : 16) + r) * 4);                       // C: (unused) | 4-bit half 1
+        if constexpr (COMPACT) {
+            k.pv[ps][3] = blk + (uint32_t)((MXQC_OFF_Z2H * 2 + 2 * H * 16 + r) * 2);   // Z0 (fp16)
+            k.pv[ps][4] = blk + (uint32_t)((MXQC_OFF_Z2H * 2 + 16 + r) * 2);           // Z1 (fp16)
+            k.pv[ps][5] = blk + (uint32_t)((MXQC_OFF_SC * 2 + r) * 2);
+            k.pv[ps][6] = blk + (uint32_t)((MXQC_OFF_QQ + 4 * H) * 4);
+        } else {
+            k.pv[ps][3] = blk + (uint32_t)((MXQ_OFF_Z2 + 2 * H * 16 + r) * 4);
+            k.pv[ps][4] = blk + (uint32_t)((MXQ_OFF_Z2 + 16 + r) * 4);
+            k.pv[ps][5] = blk + (uint32_t)((MXQ_OFF_SC * 2 + r) * 2);
+            k.pv[ps][6] = blk + (uint32_t)((MXQ_OFF_QQ + 4 * H) * 4);
+        }
+        k.sv[ps] = (uint32_t)((4 * H) * 128 + row) * 16u;
+        int gn = tn * BN + row;
+        gn = gn < N ? gn : N - 1;
+        const float4 rm = rowmeta[gn];
+        k.s4[ps] = mxq_scale(rm.z, rm.w, (uint32_t)rm.y);
+        k.z4[ps] = rm.x;
+    }
+}
+
+// production, part 0: the ten loads of the lane's 32 weights of chunk cp (cp < NT), pass PS (rows 32 PS .. of the half)
+template <int LAYOUT, int PS>
+__device__ __forceinline__ void coop_prod_load(const CoopW<LAYOUT>& k, int cp, CoopRegs& p) {
+    const char* sb = k.qw + (size_t)cp * CoopW<LAYOUT>::BYTES;
+    COOP_LD("global_load_dword", p.a, k.pv[PS][0], sb, "");
+    COOP_LD("global_load_dword", p.b, k.pv[PS][1], sb, "");
+    COOP_LD("global_load_dword", p.c, k.pv[PS][2], sb, "");
+    if constexpr (CoopW<LAYOUT>::COMPACT) {
+        COOP_LD("global_load_ushort", p.z0, k.pv[PS][3], sb, "");
+        COOP_LD("global_load_ushort", p.z1, k.pv[PS][4], sb, "");
+    } else {
+        COOP_LD("global_load_dword", p.z0, k.pv[PS][3], sb, "");
+        COOP_LD("global_load_dword", p.z1, k.pv[PS][4], sb, "");
+    }
+    COOP_LD("global_load_ushort", p.sc, k.pv[PS][5], sb, "");
+    COOP_LD("global_load_dword", p.q0x, k.pv[PS][6], sb, "");
+    COOP_LD("global_load_dword", p.q0y, k.pv[PS][6], sb, " offset:4");
+    COOP_LD("global_load_dword", p.q1x, k.pv[PS][6], sb, " offset:8");
+    COOP_LD("global_load_dword", p.q1y, k.pv[PS][6], sb, " offset:12");
+}
+// "every production register has arrived once at most NWAIT younger vector-memory operations are outstanding"
+template <int NWAIT>
+__device__ __forceinline__ void coop_prod_wait(CoopRegs& p) {
+    asm volatile("s_waitcnt vmcnt(%10)"
+                 : "+v"(p.a), "+v"(p.b), "+v"(p.c), "+v"(p.z0), "+v"(p.z1), "+v"(p.sc), "+v"(p.q0x), "+v"(p.q0y),
+                   "+v"(p.q1x), "+v"(p.q1y)
+                 : "n"(NWAIT)
+                 : "memory");
+}
+// part 1: 2-bit group 2H -> slots 4H, 4H+1 (the same arithmetic as convert_pk)
+template <int LAYOUT>
+__device__ __forceinline__ void coop_convert0(const CoopW<LAYOUT>& k, const CoopRegs& p, u32x4 (&res)[4]) {
+    uint32_t o[8];
+    float z0;
+    if constexpr (CoopW<LAYOUT>::COMPACT) z0 = (float)__builtin_bit_cast(_Float16, (uint16_t)p.z0);
+    else z0 = __uint_as_float(p.z0);
+    mxq_deq2x16(p.a, mxq_scale(__uint_as_float(p.q0x), __uint_as_float(p.q0y), (p.sc >> (8 * k.H)) & 15u), z0, o);
+    res[0] = (u32x4){o[0], o[1], o[2], o[3]};
+    res[1] = (u32x4){o[4], o[5], o[6], o[7]};
+}
+// part 2: H = 0: 2-bit group 1; H = 1: the 4-bit quarter -> slots 4H+2, 4H+3
+template <int LAYOUT, int PS>
+__device__ __forceinline__ void coop_convert1(const CoopW<LAYOUT>& k, const CoopRegs& p, u32x4 (&res)[4]) {
+    uint32_t o[8];
+    if (k.H == 0) {
+        float z1;
+        if constexpr (CoopW<LAYOUT>::COMPACT) z1 = (float)__builtin_bit_cast(_Float16, (uint16_t)p.z1);
+        else z1 = __uint_as_float(p.z1);
+        mxq_deq2x16(p.b, mxq_scale(__uint_as_float(p.q1x), __uint_as_float(p.q1y), (p.sc >> 4) & 15u), z1, o);
+    } else {
+        mxq_deq4x8(p.b, k.s4[PS], k.z4[PS], o);
+        mxq_deq4x8(p.c, k.s4[PS], k.z4[PS], o + 4);
+    }
+    res[2] = (u32x4){o[0], o[1], o[2], o[3]};
+    res[3] = (u32x4){o[4], o[5], o[6], o[7]};
+}
+// the lane's 4 x 16 bytes -> the scratch image of chunk tile cp (dropped when !en)
+template <int LAYOUT, int PS>
+__device__ __forceinline__ void coop_store(const CoopW<LAYOUT>& k, int cp, bool en, const u32x4 (&res)[4]) {
+    uint32_t so = en ? (k.ct0 + (uint32_t)cp) * (uint32_t)W_STAGE : COOP_OFF;
+    if (en && (k.dbg & 512)) so = (k.ct0 / (uint32_t)k.NT * 24u + (uint32_t)cp % 24u) * (uint32_t)W_STAGE;
+    if (en && (k.dbg & 1024)) so += k.img;     // timing experiment: the stores go where nobody reads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(res[i], k.srs, k.sv[PS] + (uint32_t)i * 2048u, so, 0);
+}
+template <int LAYOUT>
+__device__ __forceinline__ void coop_flag_store(const CoopW<LAYOUT>& k, int cp, bool en) {
+    const uint32_t so = en ? ((k.ct0 + (uint32_t)cp) * 2u + (uint32_t)k.p) * 4u : COOP_OFF;
+    __builtin_amdgcn_raw_buffer_store_b32(k.e1, k.frs, 0u, so, 0);
+}
+// flag of (chunk c, half p) into a register (asynchronous: pair with a counted wait); c beyond the panel: any valid flag
+template <int LAYOUT>
+__device__ __forceinline__ void coop_flag_load(const CoopW<LAYOUT>& k, int c, uint32_t& f) {
+    const int cc = c < k.NT ? c : k.NT - 1;
+    const uint32_t* fp = k.flags + ((size_t)(k.ct0 + (uint32_t)cc) * 2u + (uint32_t)k.p);
+    const uint32_t zero = 0;
+    COOP_LD("global_load_dword", f, zero, fp, " sc1");
+}
+// the eight DMA pieces of (chunk c, half p) into ring slot c % 3 (c beyond the panel: zeros, no traffic)
+template <int LAYOUT>
+__device__ __forceinline__ void coop_issue_w(const CoopW<LAYOUT>& k, char* smem, int c) {
+    char* dst = smem + OFF_WD + (c % WD_SLOTS) * W_STAGE + k.p * 8192;
+    uint32_t so = c < k.NT ? (k.ct0 + (uint32_t)c) * (uint32_t)W_STAGE : COOP_OFF;
+    if (c < k.NT && (k.dbg & 512)) so = (k.ct0 / (uint32_t)k.NT * 24u + (uint32_t)c % 24u) * (uint32_t)W_STAGE;
+    if (k.dbg & 16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bufdma16(k.srs, k.dv[i], so, dst + i * 1024);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bufdma16_sc1(k.srs, k.dv[i], so, dst + i * 1024);
+}
+// (chunk c, half p) produced here and now, synchronously (prologue chunks; fallback of a DMA wave whose flag stays
+// down); en = false: nothing is stored
+template <int LAYOUT>
+__device__ __forceinline__ void coop_produce_now(const CoopW<LAYOUT>& k, int c, bool en) {
+    CoopRegs p0, p1;
+    u32x4 r0[4], r1[4];
+    coop_prod_load<LAYOUT, 0>(k, c, p0);
+    coop_prod_load<LAYOUT, 1>(k, c, p1);
+    coop_prod_wait<0>(p0);
+    coop_prod_wait<0>(p1);
+    coop_convert0(k, p0, r0);
+    coop_convert1<LAYOUT, 0>(k, p0, r0);
+    coop_store<LAYOUT, 0>(k, c, en, r0);
+    coop_convert0(k, p1, r1);
+    coop_convert1<LAYOUT, 1>(k, p1, r1);
+    coop_store<LAYOUT, 1>(k, c, en, r1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    coop_flag_store(k, c, en);
+}
+// make sure (chunk c, half p) is in the scratch: bounded poll (~COOP_POLLS round trips), then do it ourselves
+constexpr int COOP_POLLS = 6;
+template <int LAYOUT>
+__device__ __forceinline__ void coop_ensure_slow(const CoopW<LAYOUT>& k, int c) {
+    for (int i = 0; i < COOP_POLLS; ++i) {
+        uint32_t f;
+        coop_flag_load(k, c, f);
+        COOP_WAIT1(0, f);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane(f) == k.e1) return;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    coop_produce_now(k, c, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- DMA wave: one K-step s = s0 + Q.  Queue per step: [flag load of chunk s+4] [8 pieces of chunk s+2]; the
+// prologue's [F(2)] [D(0)] [F(3)] [D(1)] have the same shape, so the counts hold from step 0 on.
+template <int LAYOUT, int Q>
+__device__ __forceinline__ bool coop_dma_step(const CoopW<LAYOUT>& k, char* smem, int s, uint32_t (&f)[4]) {
+    if (s >= k.NT) return false;
+    const u64t st0 = (k.dbg & 256) ? stamp() : 0;
+    __builtin_amdgcn_sched_barrier(0);
+    if (k.dbg & 4) {
+        coop_issue_w(k, smem, s + 2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        return true;
+    }
+    COOP_WAIT1(17, f[(Q + 2) & 3]);      // the flag of chunk s+2 (loaded in step s-2): younger are D x 8, F, D x 8
+    if (__builtin_expect(s + 2 < k.NT && (uint32_t)__builtin_amdgcn_readfirstlane(f[(Q + 2) & 3]) != k.e1, 0)) coop_ensure_slow(k, s + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    coop_flag_load(k, s + 4, f[Q & 3]);
+    coop_issue_w(k, smem, s + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k.dbg & 256) {
+        const u64t st1 = stamp();
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        const u64t st2 = stamp();
+        __builtin_amdgcn_s_barrier();
+        const u64t st3 = stamp();
+        k.acc[Q] += (uint32_t)(st1 - st0);
+        k.acc[4 + Q] += (uint32_t)(st2 - st1);
+        k.acc[8 + Q] += (uint32_t)(st3 - st2);
+        return true;
+    }
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // chunk s+1's pieces (issued in step s-1) have landed
+    __builtin_amdgcn_s_barrier();
+    return true;
+}
+// One whole tile on DMA wave p.  Barrier for barrier the twin of wdma_segment / deq_segment (two prologue barriers, one
+// per K-step).
+template <int LAYOUT>
+__device__ __forceinline__ void coop_dma_tile(const CoopW<LAYOUT>& k, char* smem) {
+    const int NT = k.NT;
+    const u64t tt0 = (k.dbg & 256) ? stamp() : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the previous tile's trailing (zero) DMAs
+    coop_produce_now(k, k.cls, true);                       // prologue chunk `cls`, this wave's half
+    uint32_t f[4] = {0, 0, 0, 0};
+    coop_flag_load(k, 0, f[0]);
+    coop_flag_load(k, 1, f[1]);
+    COOP_WAIT1(0, f[0]);
+    COOP_WAIT1(0, f[1]);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane(f[0]) != k.e1) coop_ensure_slow(k, 0);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane(f[1]) != k.e1) coop_ensure_slow(k, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    coop_flag_load(k, 2, f[2]);
+    coop_issue_w(k, smem, 0);
+    coop_flag_load(k, 3, f[3]);
+    coop_issue_w(k, smem, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");        // chunk 0 has landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    const u64t tt1 = (k.dbg & 256) ? stamp() : 0;
+    k.acc[12] += (uint32_t)(tt1 - tt0);
+    for (int s0 = 0; s0 < NT; s0 += 4) {
+        if (!coop_dma_step<LAYOUT, 0>(k, smem, s0 + 0, f)) break;
+        if (!coop_dma_step<LAYOUT, 1>(k, smem, s0 + 1, f)) break;
+        if (!coop_dma_step<LAYOUT, 2>(k, smem, s0 + 2, f)) break;
+        if (!coop_dma_step<LAYOUT, 3>(k, smem, s0 + 3, f)) break;
+    }
+    // the last steps' flag loads are still in flight: their registers stay live until they have landed
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+    if (k.dbg & 256) k.acc[13] += (uint32_t)(stamp() - tt1);
+}
+
+// ---- producer wave: one K-step s = s0 + O of an octet that converts (chunk cp, half p); cq / enq: the chunk of the
+// PREVIOUS octet, whose flag goes up in step 1.  The wave's queue per octet: [20 loads] (step 0), [flag store] (1),
+// [4 stores] (3), [4 stores] (5).
+template <int LAYOUT, int O>
+__device__ __forceinline__ bool coop_prod_step(const CoopW<LAYOUT>& k, int s, CoopRegs& p0, CoopRegs& p1, u32x4 (&res)[4],
+                                               int cp, bool en, int cq, bool enq) {
+    if (s >= k.NT) return false;
+    if (k.dbg & 8) { __builtin_amdgcn_s_barrier(); return true; }
+    const u64t st0 = (k.dbg & 256) ? stamp() : 0;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (O == 0) {
+        const int cl = cp < k.NT ? cp : k.NT - 1;
+        if (!(k.dbg & 32)) {
+            coop_prod_load<LAYOUT, 0>(k, cl, p0);
+            coop_prod_load<LAYOUT, 1>(k, cl, p1);
+        }
+    }
+    if constexpr (O == 1) {
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // the previous octet's stores are acknowledged
+        coop_flag_store(k, cq, enq);
+    }
+    if constexpr (O == 2) {
+        coop_prod_wait<11>(p0);                              // younger: pass 1's ten loads, the flag store
+        if (!(k.dbg & 65)) coop_convert0(k, p0, res);
+    }
+    if constexpr (O == 3) {
+        if (!(k.dbg & 65)) coop_convert1<LAYOUT, 0>(k, p0, res);
+        coop_store<LAYOUT, 0>(k, cp, en && !(k.dbg & (2 | 32 | 64 | 128)), res);
+    }
+    if constexpr (O == 4) {
+        coop_prod_wait<5>(p1);                               // younger: the flag store, pass 0's four stores
+        if (!(k.dbg & 65)) coop_convert0(k, p1, res);
+    }
+    if constexpr (O == 5) {
+        if (!(k.dbg & 65)) coop_convert1<LAYOUT, 1>(k, p1, res);
+        coop_store<LAYOUT, 1>(k, cp, en && !(k.dbg & (2 | 32 | 64 | 128)), res);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (k.dbg & 256) {
+        const u64t st1 = stamp();
+        __builtin_amdgcn_s_barrier();
+        const u64t st2 = stamp();
+        k.acc[O] += (uint32_t)(st1 - st0);
+        k.acc[8 + O] += (uint32_t)(st2 - st1);
+        return true;
+    }
+    __builtin_amdgcn_s_barrier();
+    return true;
+}
+template <int LAYOUT>
+__device__ __forceinline__ void coop_prod_tile(const CoopW<LAYOUT>& k, char* smem) {
+    const int NT = k.NT;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {   // prologue chunk cls + 8 (below COOP_LEAD for classes 0..6), this wave's half
+        const int c1 = k.cls + 8;
+        const bool en1 = c1 < COOP_LEAD && c1 < NT;
+        coop_produce_now(k, en1 ? c1 : k.cls, en1);
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    int cq = 0;
+    bool enq = false;
+    for (int s0 = 0; s0 < NT; s0 += 8) {
+        CoopRegs p0 = {}, p1 = {};
+        u32x4 res[4] = {};
+        const int cp = s0 + COOP_LEAD + k.cls;
+        const bool en = cp < NT;
+        bool live = coop_prod_step<LAYOUT, 0>(k, s0 + 0, p0, p1, res, cp, en, cq, enq);
+        // (a tile that ends inside the octet before the production loads of step 0 were consumed: they are asm loads,
+        // so their registers must not die while the loads are in flight)
+        if (live && !coop_prod_step<LAYOUT, 1>(k, s0 + 1, p0, p1, res, cp, en, cq, enq)) {
+            coop_prod_wait<0>(p0);
+            coop_prod_wait<0>(p1);
+            break;                             // step 1 did not run: the previous octet's flag is still owed (below)
+        }
+        if (live && !coop_prod_step<LAYOUT, 2>(k, s0 + 2, p0, p1, res, cp, en, cq, enq)) { coop_prod_wait<0>(p0); coop_prod_wait<0>(p1); live = false; }
+        if (live && !coop_prod_step<LAYOUT, 3>(k, s0 + 3, p0, p1, res, cp, en, cq, enq)) { coop_prod_wait<0>(p1); live = false; }
+        if (live && !coop_prod_step<LAYOUT, 4>(k, s0 + 4, p0, p1, res, cp, en, cq, enq)) { coop_prod_wait<0>(p1); live = false; }
+        if (live) live = coop_prod_step<LAYOUT, 5>(k, s0 + 5, p0, p1, res, cp, en, cq, enq);
+        if (live) live = coop_prod_step<LAYOUT, 6>(k, s0 + 6, p0, p1, res, cp, en, cq, enq);
+        if (live) live = coop_prod_step<LAYOUT, 7>(k, s0 + 7, p0, p1, res, cp, en, cq, enq);
+        // step 1 has raised the previous octet's flag; an octet cut short converts a chunk beyond the panel (cp >= NT)
+        cq = cp;
+        enq = live && en;
+        if (!live) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    coop_flag_store(k, cq, enq);               // (the last whole octet's chunk, if it existed)
+}
+
 #define MXQ_LANE_ID(ln) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln))
 
 // grid = dp_grid persistent workgroups, which deal the first dp_tiles tiles round-robin (tile = block + k * dp_grid:
 // blocks b and b + 8 share an XCD and dp_grid is a multiple of 8 or the tile count itself, so a workgroup's tiles
 // keep its XCD's label) and overlap one tile's output with the next one's first DMAs, + 8 * units stream-K
 // workgroups for the `tail` tiles beyond them.
-template <int ABL, int LAYOUT>
+template <int ABL, int LAYOUT, bool COOP = false>
 __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* __restrict__ x,
                                                                const uint32_t* __restrict__ qweight,
                                                                const float4* __restrict__ rowmeta,
@@ -731,32 +1197,100 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
 
     if (bid < dp_grid) {
         // ---- persistent data-parallel workgroup: whole tiles bid, bid + dp_grid, ...
-        int tm, tn;
-        tile_of_block(bid, tiles_m, tiles_n, tm, tn);
+        int tm, tn, cls;
+        bool valid = map_tile<COOP>(bid, tiles_m, tiles_n, dp_tiles, tm, tn, cls);
         if (wave < N_MMA) {
             int ln;
             MXQ_LANE_ID(ln);
             XDma cur, nxt;
-            xdma_setup(cur, x, M, K, tm * BM, 0, wave, ln);
-            mma_prologue_issue<ABL>(cur, smem, wave, NT);
-            for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
+            if (valid) {
+                xdma_setup(cur, x, M, K, tm * BM, 0, wave, ln);
+                mma_prologue_issue<ABL>(cur, smem, wave, NT);
+            }
+            for (int tile = bid; valid; tile += dp_grid) {
                 MXQ_LANE_ID(ln);   // recomputed per tile and opaque: nothing lane-derived is hoisted (and spilled) across the loop
                 const int m0 = tm * BM, n0 = tn * BN;
-                const bool more = tile + dp_grid < dp_tiles;
-                if (more) tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
-                mma_segment<ABL, LAYOUT == LAYOUT_DENSE16>(smem, wave, ln, NT, cur, true, y, M, N, m0, n0, NT, sk, [&] {
+                const bool more = map_tile<COOP>(tile + dp_grid, tiles_m, tiles_n, dp_tiles, tm, tn, cls);
+                mma_segment<ABL, LAYOUT == LAYOUT_DENSE16 || COOP>(smem, wave, ln, NT, cur, true, y, M, N, m0, n0, NT, sk, [&] {
                     if (more) {
                         xdma_setup(nxt, x, M, K, tm * BM, 0, wave, ln);
                         mma_prologue_issue<ABL>(nxt, smem, wave, NT);
                     }
                 });
                 cur = nxt;
+                valid = more;
+            }
+        } else if constexpr (COOP) {
+            // cooperative-dequant mode: ws = the fp16 scratch image, cnt = control words + flags (launch8)
+            int ln;
+            MXQ_LANE_ID(ln);
+            CoopW<LAYOUT> k;
+            k.qw = (const char*)qweight;
+            // this workgroup's XCD: it raises and trusts only flags of its own XCD's block (the image of a chunk travels
+            // through that XCD's L2: plain stores, L1-bypassing loads; another XCD's L2 is not coherent with it)
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+            const uint32_t fl_words = (uint32_t)tiles_n * (uint32_t)NT * 2u;
+            k.flags = (const uint32_t*)cnt + COOP_CTL_INTS + (size_t)xcc * fl_words;
+            k.img = (uint32_t)tiles_n * (uint32_t)NT * (uint32_t)W_STAGE;
+            k.srs = make_rsrc(ws, k.img * ((units & 1024) ? 2u : 1u));
+            k.frs = make_rsrc(k.flags, fl_words * 4u);
+            const int wd = wave - N_MMA;          // 0, 1: DMA waves; 2, 3: producer waves
+            k.p = wd & 1;
+            k.NT = NT;
+            k.dbg = units;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) k.acc[i] = 0;
+            u64t rt0 = 0, mt0 = 0;
+            if (k.dbg & 256) {
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+                mt0 = stamp();
+            }
+            {
+                uint32_t e;
+                const uint32_t zero = 0;
+                COOP_LD("global_load_dword", e, zero, cnt, " sc1");
+                COOP_WAIT1(0, e);
+                k.e1 = (uint32_t)__builtin_amdgcn_readfirstlane(e) + 1u;
+            }
+            for (int tile = bid; valid; tile += dp_grid) {
+                MXQ_LANE_ID(ln);
+                coop_tile_setup(k, ln, N, K, tn, cls, rowmeta);
+                valid = map_tile<COOP>(tile + dp_grid, tiles_m, tiles_n, dp_tiles, tm, tn, cls);
+                if (wd < 2) coop_dma_tile(k, smem);
+                else coop_prod_tile(k, smem);
+            }
+            if ((k.dbg & 256) && wd == 0) {
+                u64t rt1;
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+                k.acc[14] = (uint32_t)(rt1 - rt0);
+                k.acc[15] = (uint32_t)(stamp() - mt0);
+            }
+            if ((k.dbg & 256) && bid == 8 && (wd == 0 || wd == 2) && ln == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cnt[64 + wd * 8 + i] = (int)k.acc[i];
+            }
+            // the launch is over for this workgroup's scratch traffic; the LAST workgroup to say so moves the epoch on
+            // (every flag of this launch stops matching) and re-arms the count
+            if (wd == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int old = 0;
+                if (ln == 0) old = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if (old == (int)gridDim.x - 1 && ln == 0) {
+                    __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cnt, (int)k.e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         } else if constexpr (LAYOUT == LAYOUT_DENSE16) {
             int ln;
             MXQ_LANE_ID(ln);
             WDma cur, nxt;
             wdma_setup(cur, (const uint16_t*)qweight, N, K, tn * BN, 0, NT, wave, ln);
+#ifdef MXQ_PROFILING
+            if (rowmeta) wdma_two(cur, K, ln);     // mxq_prof_gemm8_dense_f16(two = 1)
+#endif
             wdma_prologue_issue(cur, smem);
             for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
                 MXQ_LANE_ID(ln);
@@ -765,6 +1299,9 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
                 wdma_segment(cur, smem, true, [&] {
                     if (more) {
                         wdma_setup(nxt, (const uint16_t*)qweight, N, K, tn * BN, 0, NT, wave, ln);
+#ifdef MXQ_PROFILING
+                        if (rowmeta) wdma_two(nxt, K, ln);
+#endif
                         wdma_prologue_issue(nxt, smem);
                     }
                 });
@@ -885,10 +1422,23 @@ int cu_count() {
 }
 
 constexpr size_t CNT_BYTES = 64 * 1024;   // K-step counters at the head of the workspace (>= 8*units*N_MMA ints)
+// workspace = [stream-K counters 64 KB][coop control words + flags 512 KB][stream-K slots | coop scratch image]; the
+// first HEAD_BYTES must be zero when the buffer is first used (the kernels keep them consistent afterwards)
+constexpr size_t COOP_HEAD_BYTES = 512 * 1024;
+constexpr size_t HEAD_BYTES = CNT_BYTES + COOP_HEAD_BYTES;
+constexpr int COOP_MIN_TILES_M = 8, COOP_MIN_NT = 24;
 
+size_t coop_scratch_bytes(int N, int K) { return (size_t)((N + BN - 1) / BN) * (size_t)(K / BK) * W_STAGE; }
+bool coop_shape_ok(int N, int K) {
+    const size_t ct = (size_t)((N + BN - 1) / BN) * (size_t)(K / BK);
+    return K / BK >= COOP_MIN_NT && COOP_CTL_INTS * 4 + ct * 64 <= COOP_HEAD_BYTES && ct * W_STAGE < ((size_t)1 << 31);
+}
+
+// mode: 0 = automatic, 1 = stream-K split of the tail forced (tests), 2 = never the cooperative-dequant mode
 template <int ABL, int LAYOUT = MXQ_LAYOUT_MIXED>
 static int launch8(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                   void* workspace, size_t ws_bytes, bool force, hipStream_t stream) {
+                   void* workspace, size_t ws_bytes, int mode, hipStream_t stream) {
+    const bool force = mode == 1;
     // the DMA descriptors address one tile's rows with 32-bit offsets: 256 rows of x, 8 row-blocks of packed weights
     // 32-bit offsets: 256 rows of x per DMA descriptor; the whole packed weight behind one (offsets < 2^31)
     if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(N / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 31))
@@ -901,7 +1451,7 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     const int cus = cu_count() / 8 * 8, units = cus / 8;
     int dp_tiles = tiles, tail = 0;
     if (workspace && tiles % cus != 0 && units * 8 * N_MMA * sizeof(int) <= CNT_BYTES &&
-        ws_bytes >= CNT_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
+        ws_bytes >= HEAD_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
         const int t8 = (tiles % cus) / 8;   // tail tiles per XCD (the first tail % 8 XCDs hold one more)
         // Splitting the tail costs ~20 us (every unit parks 128 KB of fp32 partials, the finishers read them back)
         // and saves the idle share of one tile time, (1 - tail/CUs) * NT K-steps of ~1 us: worth it from ~24 idle
@@ -913,36 +1463,61 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
         }
     }
     const int dp_grid = dp_tiles < cus ? dp_tiles : cus;   // persistent: at most one data-parallel workgroup per CU
+    if constexpr (ABL == 0 && (LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC)) {
+        // cooperative-dequant mode: from 8 token tiles on (a panel's chunk is converted once per 8 workgroups), whole
+        // tiles only, and only with a workspace that holds the fp16 image of this weight
+        if (mode != 2 && !getenv("MXQ_NO_COOP") && workspace && tail == 0 && tiles_m >= COOP_MIN_TILES_M && coop_shape_ok(N, K) &&
+            ws_bytes >= HEAD_BYTES + coop_scratch_bytes(N, K)) {
+            e = hipFuncSetAttribute((const void*)mxq_gemm8_f16_kernel<ABL, LAYOUT, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+            if (e != hipSuccess) return (int)e;
+            const int ctiles = tiles_m * ((tiles_n + 7) / 8) * 8;   // map_tile<true>: padded to 8 panels per group
+            const int cgrid = ctiles < cus ? ctiles : cus;
+            mxq_gemm8_f16_kernel<ABL, LAYOUT, true><<<cgrid, THREADS, SMEM_BYTES, stream>>>(
+                (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m,
+                tiles_n, ctiles, cgrid, 0, getenv("MXQ_COOP_DBG") ? atoi(getenv("MXQ_COOP_DBG")) : 0,
+                (float*)((char*)workspace + HEAD_BYTES), (int*)((char*)workspace + CNT_BYTES));
+            return (int)hipGetLastError();
+        }
+    }
     const int grid = dp_grid + (tail ? cus : 0);
     mxq_gemm8_f16_kernel<ABL, LAYOUT><<<grid, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
-        dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace);
+        dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + HEAD_BYTES), (int*)workspace);
     return (int)hipGetLastError();
 }
 
 }   // namespace
 
-size_t mxq_gemm8_workspace_bytes() { return CNT_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
+size_t mxq_gemm8_workspace_bytes() { return HEAD_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
+size_t mxq_gemm8_workspace_head_bytes() { return HEAD_BYTES; }
+// ... that also holds the cooperative-dequant mode's fp16 image of an [N, K] weight
+size_t mxq_gemm8_workspace_bytes_for(int N, int K) {
+    const size_t base = mxq_gemm8_workspace_bytes();
+    if (N <= 0 || K <= 0 || !coop_shape_ok(N, K)) return base;
+    const size_t coop = HEAD_BYTES + coop_scratch_bytes(N, K);
+    return coop > base ? coop : base;
+}
 
 int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         void* workspace, size_t ws_bytes, int force, hipStream_t stream) {
-    return launch8<0>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, force != 0, stream);
+                         void* workspace, size_t ws_bytes, int mode, hipStream_t stream) {
+    return launch8<0>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, mode, stream);
 }
 
 int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream) {
     switch (layout) {
-        case MXQ_LAYOUT_MIXED: return launch8<0, MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
-        case MXQ_LAYOUT_W2G16: return launch8<0, MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
-        case MXQ_LAYOUT_W4ROW: return launch8<0, MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
-        case MXQ_LAYOUT_MIXEDC: return launch8<0, MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
+        case MXQ_LAYOUT_MIXED: return launch8<0, MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
+        case MXQ_LAYOUT_W2G16: return launch8<0, MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
+        case MXQ_LAYOUT_W4ROW: return launch8<0, MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
+        case MXQ_LAYOUT_MIXEDC: return launch8<0, MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
     }
     return -1;
 }
 
 // hoisted-dequant mode: w16 = dense fp16 [N, K] weight (the dequant kernel's output); same tiles, no stream-K tail
 int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, hipStream_t stream) {
-    return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, false, stream);
+    return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, 0, stream);
 }
 
 #ifdef MXQ_PROFILING
@@ -953,24 +1528,24 @@ extern "C" int mxq_prof_gemm8_ablate_f16(const void* x, const void* qweight, con
                                          int K, int abl, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     switch (abl) {
-        case 0: return launch8<0>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 1: return launch8<1>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 2: return launch8<2>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 4: return launch8<4>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 5: return launch8<5>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 6: return launch8<6>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 256: return launch8<256>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 260: return launch8<260>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-        case 1024: return launch8<1024>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // correct results
-        case 2048: return launch8<2048>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // correct results
-        case 2050: return launch8<2050>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 0: return launch8<0>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 1: return launch8<1>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 2: return launch8<2>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 4: return launch8<4>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 5: return launch8<5>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 6: return launch8<6>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 256: return launch8<256>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 260: return launch8<260>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
+        case 1024: return launch8<1024>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);   // correct results
+        case 2048: return launch8<2048>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);   // correct results
+        case 2050: return launch8<2050>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, 0, stream);
     }
     return -1;   // MXQ_E_SHAPE: not an ablation this build carries
 }
 
-// the hoisted mode's MFMA kernel alone on an already dequantised fp16 weight (the dense yardstick of tools/ab_gemm.py)
-extern "C" int mxq_prof_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, void* stream_) {
-    return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, false, (hipStream_t)stream_);
+// the hoisted mode's MFMA kernel alone on an already dequantised fp16 weight
+extern "C" int mxq_prof_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, int two, void* stream_) {
+    return launch8<0, LAYOUT_DENSE16>(x, w16, two ? x : nullptr, y, M, N, K, nullptr, 0, 0, (hipStream_t)stream_);
 }
 
 // Diagnostic build with cycle stamps (cdna guide section 7, "In-kernel stamps"): dbg receives, per workgroup and wave,

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE GEMM kernel variant at ONE shape a few times (for rocprofv3 --pmc runs).
-    python3 tools/gemm_prof.py gemm8 2048 4096 4096 [iters] [layout: mixed | w2g16 | w4row] [dbg]
-dbg (debug builds of the cooperative mode only): MXQ_COOP_DBG for the SECOND half of the launches."""
+    python3 tools/gemm_prof.py gemm8 2048 4096 4096 [iters] [layout: mixed | w2g16 | w4row]"""
 import os
 import sys
 
@@ -19,11 +18,7 @@ W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
 p = packing.quantize_pack(W) if layout == "mixed" else packing.quantize_pack_uniform(W, layout)
 x = torch.randn(M, K, generator=g, device=dev).half()
 out = torch.empty(M, N, device=dev, dtype=torch.float16)
-dbg = sys.argv[7] if len(sys.argv) > 7 else None
-for it in range(iters):
-    if dbg is not None and it == iters // 2:
-        torch.cuda.synchronize()
-        os.environ["MXQ_COOP_DBG"] = dbg
+for _ in range(iters):
     if layout == "mixed":
         packing.linear(x, p, out=out, path=variant)
     else:
