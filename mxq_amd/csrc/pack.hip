@@ -187,22 +187,66 @@ __device__ __forceinline__ void find_params16(float lo, float hi, float maxq, fl
     s = qs * (scode - qz);
 }
 
-__global__ __launch_bounds__(256) void mxq_quantize_pack_kernel(const void* __restrict__ W, int dtype,
-                                                                const uint8_t* __restrict__ dead,
-                                                                uint32_t* __restrict__ qweight,
-                                                                float4* __restrict__ rowmeta, int N, int K) {
+// 16 waves per 16-row block (a wave takes the chunks c = w mod 16) and the next chunk's loads issued before the
+// current one is worked on: the kernel is a stream of 32-byte loads per lane with ~300 VALU ops between them, and
+// with the 4 waves per block of round 1 (one wave per SIMD, one load pair in flight each) it ran at the bytes in
+// flight, 1.4-2.1 TB/s (profiles/r02_kernels_bench.txt).
+constexpr int QP_WAVES = 16;
+struct Raw16 { uint4 a, b, c, d; };   // 16 elements as loaded: 32 bytes (16-bit dtypes) or 64 bytes (fp32)
+__device__ __forceinline__ void load16_raw(const void* W, int dtype, int64_t off, Raw16& t) {
+    if (dtype == MXQ_DTYPE_F32) {
+        const uint4* p = (const uint4*)((const float*)W + off);
+        t.a = p[0]; t.b = p[1]; t.c = p[2]; t.d = p[3];
+    } else {
+        const uint4* p = (const uint4*)((const uint16_t*)W + off);
+        t.a = p[0]; t.b = p[1];
+    }
+}
+__device__ __forceinline__ void cvt16(const Raw16& t, int dtype, float v[16]) {
+    if (dtype == MXQ_DTYPE_F16) {
+        const uint32_t w[8] = {t.a.x, t.a.y, t.a.z, t.a.w, t.b.x, t.b.y, t.b.z, t.b.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 h = __builtin_bit_cast(h2, w[i]);
+            v[2 * i] = (float)h[0];
+            v[2 * i + 1] = (float)h[1];
+        }
+    } else if (dtype == MXQ_DTYPE_BF16) {
+        const uint32_t w[8] = {t.a.x, t.a.y, t.a.z, t.a.w, t.b.x, t.b.y, t.b.z, t.b.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    } else {
+        const uint32_t w[16] = {t.a.x, t.a.y, t.a.z, t.a.w, t.b.x, t.b.y, t.b.z, t.b.w,
+                                t.c.x, t.c.y, t.c.z, t.c.w, t.d.x, t.d.y, t.d.z, t.d.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __uint_as_float(w[i]);
+    }
+}
+
+__global__ __launch_bounds__(QP_WAVES * 64) void mxq_quantize_pack_kernel(const void* __restrict__ W, int dtype,
+                                                                         const uint8_t* __restrict__ dead,
+                                                                         uint32_t* __restrict__ qweight,
+                                                                         float4* __restrict__ rowmeta, int N, int K) {
     const int NC = K / 64, NC4 = (NC + 3) / 4;
     const int rb = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, qt = lane >> 4;
     const int n = rb * 16 + r;
-    __shared__ float red[2][4][16];
+    __shared__ float red[2][QP_WAVES][16];
     float mn4 = INFINITY, mx4 = -INFINITY;
     float v[16];
+    Raw16 nxt = {};
 
-    for (int c = wave; c < NC; c += 4) {
+    if (wave < NC) load16_raw(W, dtype, (int64_t)n * K + wave * 64 + qt * 16, nxt);
+    for (int c = wave; c < NC; c += QP_WAVES) {
         const int k0 = c * 64 + qt * 16;
-        load16(W, dtype, (int64_t)n * K + k0, v);
+        const Raw16 cur = nxt;
+        if (c + QP_WAVES < NC) load16_raw(W, dtype, (int64_t)n * K + k0 + QP_WAVES * 64, nxt);
+        cvt16(cur, dtype, v);
         if (dead) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -237,20 +281,28 @@ __global__ __launch_bounds__(256) void mxq_quantize_pack_kernel(const void* __re
         }
         if (qt == 0) ((uint16_t*)tile)[mxq_sc_u16(r)] = (uint16_t)(sci | (sc1 << 4) | (sc2 << 8));
     }
+    // the 4-bit arm's first slices are on their way while the row ranges are reduced (c = 4 * wave + qt: qt plays the
+    // role of the chunk slot in pass 2)
+    const bool has4 = 4 * wave + qt < NC;
+    if (has4) load16_raw(W, dtype, (int64_t)n * K + (4 * wave + qt) * 64 + 48, nxt);
     if (qt == 3) { red[0][wave][r] = mn4; red[1][wave][r] = mx4; }
     __syncthreads();
-    float lo4 = fminf(fminf(red[0][0][r], red[0][1][r]), fminf(red[0][2][r], red[0][3][r]));
-    float hi4 = fmaxf(fmaxf(red[1][0][r], red[1][1][r]), fmaxf(red[1][2][r], red[1][3][r]));
+    float lo4 = red[0][0][r], hi4 = red[1][0][r];
+#pragma unroll
+    for (int w = 1; w < QP_WAVES; ++w) { lo4 = fminf(lo4, red[0][w][r]); hi4 = fmaxf(hi4, red[1][w][r]); }
     float z4, sc4, s4, qs4, qz4;
     find_params16(lo4, hi4, 15.0f, z4, sc4, s4, qs4, qz4);
     if (wave == 0 && qt == 0) rowmeta[n] = make_float4(z4, sc4, qs4, qz4);
     const float sd4 = fmaxf(s4, 1e-9f);
 
-    for (int c4 = wave; c4 < NC4; c4 += 4) {
-        const int c = c4 * 4 + qt;   // qt plays the role of the chunk slot here
+    for (int c4 = wave; c4 < NC4; c4 += QP_WAVES) {
+        const int c = c4 * 4 + qt;
+        const Raw16 cur = nxt;
+        const int cn = c + 4 * QP_WAVES;
+        if (cn < NC) load16_raw(W, dtype, (int64_t)n * K + cn * 64 + 48, nxt);
         if (c >= NC) continue;
         const int k0 = c * 64 + 48;
-        load16(W, dtype, (int64_t)n * K + k0, v);
+        cvt16(cur, dtype, v);
         if (dead) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -473,7 +525,7 @@ int mxq_launch_compact(const void* qweight_exact, void* qweight_compact, int N, 
 
 int mxq_launch_quantize_pack(const void* W, int dtype, const uint8_t* dead, void* qweight, void* rowmeta, int N,
                              int K, hipStream_t stream) {
-    mxq_quantize_pack_kernel<<<(unsigned)(N / 16), 256, 0, stream>>>(W, dtype, dead, (uint32_t*)qweight,
+    mxq_quantize_pack_kernel<<<(unsigned)(N / 16), QP_WAVES * 64, 0, stream>>>(W, dtype, dead, (uint32_t*)qweight,
                                                                       (float4*)rowmeta, N, K);
     return (int)hipGetLastError();
 }
