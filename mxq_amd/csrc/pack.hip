@@ -187,6 +187,66 @@ __device__ __forceinline__ void find_params16(float lo, float hi, float maxq, fl
     s = qs * (scode - qz);
 }
 
+// q = clamp(rne(x / sd + z), 0, maxq) (quantizer.py:14-16) for 16 values.  An IEEE division is ~10 VALU ops; here
+// a' = fl(x * v_rcp_f32(sd)) stands in for a = fl(x / sd) behind a screen: |a' - a| <= |a| * 2^-22 (v_rcp_f32 is good to
+// 1 ulp, plus the two roundings), so t' = fl(a' + z) is within |a'| * 2^-21 + 2^-19 of t = fl(a + z) for |t| < 17
+// (two ulps of slack on the bound, one ulp of t at that magnitude), and both are first clamped to [-1, maxq + 1], where
+// nothing changes the final code.  If every value of the WAVE keeps its clamped t' farther than that from the nearest
+// rounding boundary (k + 0.5), the codes are those of the exact formula; otherwise -- ties included, and any NaN / Inf,
+// whose key compares false -- the wave takes the division.  Typical weights: 1-2 % of the wave iterations.
+template <int MAXQ>
+__device__ __forceinline__ float quant_key(float x, float r, float z, float& q) {
+    const float a = x * r;
+    const float t = __builtin_amdgcn_fmed3f(a + z, -1.0f, (float)(MAXQ + 1));
+    const float n = rintf(t);
+    q = __builtin_amdgcn_fmed3f(n, 0.0f, (float)MAXQ);
+    return (0.5f - fabsf(t - n)) - fmaf(fabsf(a), 0x1p-21f, 0x1p-19f);
+}
+template <int MAXQ>
+__device__ __forceinline__ float quant_exact(float x, float sd, float z) {
+    return fminf(fmaxf(rintf(x / sd + z), 0.0f), (float)MAXQ);
+}
+__device__ __forceinline__ uint32_t quant2x16(const float (&v)[16], float sd, float z) {
+    const float r = __builtin_amdgcn_rcpf(sd);
+    float key = INFINITY;
+    uint32_t word = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float q;
+        key = fminf(key, quant_key<3>(v[j], r, z, q));
+        word |= (uint32_t)q << mxq_bit2(j);
+    }
+    if (__any(!(key > 0.0f))) {
+        word = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) word |= (uint32_t)quant_exact<3>(v[j], sd, z) << mxq_bit2(j);
+    }
+    return word;
+}
+__device__ __forceinline__ void quant4x16(const float (&v)[16], float sd, float z, uint32_t& w0, uint32_t& w1) {
+    const float r = __builtin_amdgcn_rcpf(sd);
+    float key = INFINITY;
+    w0 = 0;
+    w1 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float q0, q1;
+        key = fminf(key, quant_key<15>(v[j], r, z, q0));
+        key = fminf(key, quant_key<15>(v[j + 8], r, z, q1));
+        w0 |= (uint32_t)q0 << mxq_bit4(j);
+        w1 |= (uint32_t)q1 << mxq_bit4(j);
+    }
+    if (__any(!(key > 0.0f))) {
+        w0 = 0;
+        w1 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            w0 |= (uint32_t)quant_exact<15>(v[j], sd, z) << mxq_bit4(j);
+            w1 |= (uint32_t)quant_exact<15>(v[j + 8], sd, z) << mxq_bit4(j);
+        }
+    }
+}
+
 // 16 waves per 16-row block (a wave takes the chunks c = w mod 16) and the next chunk's loads issued before the
 // current one is worked on: the kernel is a stream of 32-byte loads per lane with ~300 VALU ops between them, and
 // with the 4 waves per block of round 1 (one wave per SIMD, one load pair in flight each) it ran at the bytes in
@@ -259,12 +319,7 @@ __global__ __launch_bounds__(QP_WAVES * 64) void mxq_quantize_pack_kernel(const 
         float z, scode, s, qs, qz;
         find_params16(lo, hi, 3.0f, z, scode, s, qs, qz);
         const float sd = fmaxf(s, 1e-9f);
-        uint32_t word = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float q = fminf(fmaxf(rintf(v[j] / sd + z), 0.0f), 3.0f);
-            word |= (uint32_t)q << mxq_bit2(j);
-        }
+        const uint32_t word = quant2x16(v, sd, z);
         const uint32_t sci = (uint32_t)scode;
         const uint32_t sc1 = __shfl(sci, r + 16, 64), sc2 = __shfl(sci, r + 32, 64);
         uint32_t* tile = qweight + ((int64_t)rb * NC + c) * MXQ_BLK_DW;
@@ -308,14 +363,8 @@ __global__ __launch_bounds__(QP_WAVES * 64) void mxq_quantize_pack_kernel(const 
             for (int j = 0; j < 16; ++j)
                 if (dead[k0 + j]) v[j] = 0.0f;
         }
-        uint32_t w0 = 0, w1 = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float q0 = fminf(fmaxf(rintf(v[j] / sd4 + z4), 0.0f), 15.0f);
-            const float q1 = fminf(fmaxf(rintf(v[j + 8] / sd4 + z4), 0.0f), 15.0f);
-            w0 |= (uint32_t)q0 << mxq_bit4(j);
-            w1 |= (uint32_t)q1 << mxq_bit4(j);
-        }
+        uint32_t w0, w1;
+        quant4x16(v, sd4, z4, w0, w1);
         uint32_t* tile = qweight + ((int64_t)rb * NC + c) * MXQ_BLK_DW;
         tile[mxq_c4(0, r)] = w0;
         tile[mxq_c4(1, r)] = w1;
@@ -329,7 +378,7 @@ __global__ __launch_bounds__(QP_WAVES * 64) void mxq_quantize_pack_kernel(const 
 // Same workgroup shape as mxq_quantize_pack_kernel: 16 rows x (4 waves over the chunks).
 // ------------------------------------------------------------------------------------ //
 template <int LAYOUT>
-__global__ __launch_bounds__(256) void mxq_quantize_uniform_kernel(const void* __restrict__ W, int dtype,
+__global__ __launch_bounds__(QP_WAVES * 64) void mxq_quantize_uniform_kernel(const void* __restrict__ W, int dtype,
                                                                    uint32_t* __restrict__ qweight,
                                                                    float4* __restrict__ rowmeta, int N, int K) {
     const int NC = K / 64;
@@ -340,7 +389,7 @@ __global__ __launch_bounds__(256) void mxq_quantize_uniform_kernel(const void* _
     constexpr int BLK = LAYOUT == MXQ_LAYOUT_W4ROW ? 128 : 144;
     float v[16];
     if constexpr (LAYOUT == MXQ_LAYOUT_W2G16) {
-        for (int c = wave; c < NC; c += 4) {
+        for (int c = wave; c < NC; c += QP_WAVES) {
             load16(W, dtype, (int64_t)n * K + c * 64 + qt * 16, v);
             float lo = v[0], hi = v[0];
 #pragma unroll
@@ -348,10 +397,7 @@ __global__ __launch_bounds__(256) void mxq_quantize_uniform_kernel(const void* _
             float z, scode, s, qs, qz;
             find_params16(lo, hi, 3.0f, z, scode, s, qs, qz);
             const float sd = fmaxf(s, 1e-9f);
-            uint32_t word = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                word |= (uint32_t)fminf(fmaxf(rintf(v[j] / sd + z), 0.0f), 3.0f) << mxq_bit2(j);
+            const uint32_t word = quant2x16(v, sd, z);
             const uint32_t sci = (uint32_t)scode;
             const uint32_t s1 = __shfl(sci, r + 16, 64), s2 = __shfl(sci, r + 32, 64), s3 = __shfl(sci, r + 48, 64);
             uint32_t* blk = qweight + ((int64_t)rb * NC + c) * BLK;
@@ -365,9 +411,9 @@ __global__ __launch_bounds__(256) void mxq_quantize_uniform_kernel(const void* _
         }
         if (wave == 0 && qt == 0) rowmeta[n] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-        __shared__ float red[2][4][16];
+        __shared__ float red[2][QP_WAVES][16];
         float mn = INFINITY, mx = -INFINITY;
-        for (int c = wave; c < NC; c += 4) {
+        for (int c = wave; c < NC; c += QP_WAVES) {
             load16(W, dtype, (int64_t)n * K + c * 64 + qt * 16, v);
 #pragma unroll
             for (int j = 0; j < 16; ++j) { mn = fminf(mn, v[j]); mx = fmaxf(mx, v[j]); }
@@ -376,20 +422,17 @@ __global__ __launch_bounds__(256) void mxq_quantize_uniform_kernel(const void* _
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         if (qt == 0) { red[0][wave][r] = mn; red[1][wave][r] = mx; }
         __syncthreads();
-        const float lo = fminf(fminf(red[0][0][r], red[0][1][r]), fminf(red[0][2][r], red[0][3][r]));
-        const float hi = fmaxf(fmaxf(red[1][0][r], red[1][1][r]), fmaxf(red[1][2][r], red[1][3][r]));
+        float lo = red[0][0][r], hi = red[1][0][r];
+#pragma unroll
+        for (int w = 1; w < QP_WAVES; ++w) { lo = fminf(lo, red[0][w][r]); hi = fmaxf(hi, red[1][w][r]); }
         float z4, sc4, s4, qs4, qz4;
         find_params16(lo, hi, 15.0f, z4, sc4, s4, qs4, qz4);
         if (wave == 0 && qt == 0) rowmeta[n] = make_float4(z4, sc4, qs4, qz4);
         const float sd4 = fmaxf(s4, 1e-9f);
-        for (int c = wave; c < NC; c += 4) {
+        for (int c = wave; c < NC; c += QP_WAVES) {
             load16(W, dtype, (int64_t)n * K + c * 64 + qt * 16, v);
-            uint32_t w0 = 0, w1 = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                w0 |= (uint32_t)fminf(fmaxf(rintf(v[j] / sd4 + z4), 0.0f), 15.0f) << mxq_bit4(j);
-                w1 |= (uint32_t)fminf(fmaxf(rintf(v[j + 8] / sd4 + z4), 0.0f), 15.0f) << mxq_bit4(j);
-            }
+            uint32_t w0, w1;
+            quant4x16(v, sd4, z4, w0, w1);
             uint32_t* blk = qweight + ((int64_t)rb * NC + c) * BLK;
             blk[mxq_w4_c4(qt, 0, r)] = w0;
             blk[mxq_w4_c4(qt, 1, r)] = w1;
@@ -533,10 +576,10 @@ int mxq_launch_quantize_pack(const void* W, int dtype, const uint8_t* dead, void
 int mxq_launch_quantize_uniform(const void* W, int dtype, void* qweight, void* rowmeta, int N, int K, int layout,
                                 hipStream_t stream) {
     if (layout == MXQ_LAYOUT_W2G16)
-        mxq_quantize_uniform_kernel<MXQ_LAYOUT_W2G16><<<(unsigned)(N / 16), 256, 0, stream>>>(
+        mxq_quantize_uniform_kernel<MXQ_LAYOUT_W2G16><<<(unsigned)(N / 16), QP_WAVES * 64, 0, stream>>>(
             W, dtype, (uint32_t*)qweight, (float4*)rowmeta, N, K);
     else
-        mxq_quantize_uniform_kernel<MXQ_LAYOUT_W4ROW><<<(unsigned)(N / 16), 256, 0, stream>>>(
+        mxq_quantize_uniform_kernel<MXQ_LAYOUT_W4ROW><<<(unsigned)(N / 16), QP_WAVES * 64, 0, stream>>>(
             W, dtype, (uint32_t*)qweight, (float4*)rowmeta, N, K);
     return (int)hipGetLastError();
 }

@@ -133,6 +133,52 @@ def test_quantize_random_vs_oracle(dev, N, K, dt):
     assert np.array_equal(w.view(np.uint16), ref["w_deq32"].astype(np.float16).view(np.uint16))
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+def test_quantize_pack_division_screen_adversarial(dev, dt):
+    """The quantise kernels replace x / s by x * rcp(s) behind a rounding-boundary screen (csrc/pack.hip quant_key) and
+    fall back to the division per wave: inputs built to sit ON and NEXT TO the boundaries -- values on a k/2 grid of the
+    group's own scale (exact ties), groups riding on large offsets (|x / s| ~ 1e3: the bound grows with it), tiny and
+    huge ranges, constant groups, one-ulp neighbours of ties -- must give the oracle's codes bit for bit."""
+    from mxq_amd import packing
+    g = torch.Generator().manual_seed(7)
+    N, K = 64, 1024
+    W = torch.empty(N, K)
+    for n in range(N):
+        for c in range(K // 16):
+            kind = (n + 3 * c) % 8
+            step = float(2.0 ** torch.randint(-12, 3, (1,), generator=g).item())
+            kk = torch.randint(0, 7, (16,), generator=g).float() * 0.5            # multiples of half a step: ties
+            if kind == 0:
+                v = kk * step
+            elif kind == 1:
+                v = 1000.0 * step + kk * step                                       # large offset
+            elif kind == 2:
+                v = -517.0 * step + kk * step
+            elif kind == 3:
+                v = torch.full((16,), 0.37 * step)                                  # constant group
+            elif kind == 4:
+                v = torch.randn(16, generator=g) * 1e-6
+            elif kind == 5:
+                v = torch.randn(16, generator=g) * 3e3                              # (finite in fp16)
+            elif kind == 6:
+                v = kk * step
+                v = torch.nextafter(v, torch.full_like(v, 1e9)) if dt == torch.float32 else v * (1 + 2.0 ** -9)
+            else:
+                v = torch.randn(16, generator=g) * step
+            W[n, c * 16:(c + 1) * 16] = v
+    W = W.to(dt)
+    ref = O.mxq_quantize(W.float().numpy())
+    p = packing.quantize_pack(W.to(dev))
+    got = packing.unpack(p)
+    for k in KEYS:
+        assert np.array_equal(got[k].cpu().numpy(), ref[k]), k
+    for layout in ("w2g16", "w4row"):
+        refu = O.uniform_quantize(W.float().numpy(), layout)
+        gotu = packing.expand_uniform(packing.quantize_pack_uniform(W.to(dev), layout))[1]
+        for k in ("codes", "sc", "zero", "qs", "qz"):
+            assert np.array_equal(gotu[k].cpu().numpy().reshape(refu[k].shape), refu[k]), (layout, k)
+
+
 def test_mxqgpt_driver_api(dev, g1):
     """MXQGPT(layer).add_batch / fasterquant / free as nas_quant calls them (prune.py:385-414)."""
     from mxq_amd.lib.mxqgpt import MXQGPT
