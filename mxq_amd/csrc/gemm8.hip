@@ -359,11 +359,15 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
 
     int t = 1;
     Stamps st = {0, 0, 0, 0};
+    u64t rt0 = 0;
+    if constexpr ((ABL & EXP_STAMPS) != 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
     for (; t + 2 < NT; ++t) mma_step<ABL, true, DENSE>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
     if constexpr ((ABL & EXP_STAMPS) != 0) {   // this workgroup's wave: {work, wait, barrier, steps} cycle sums
+        u64t rt1;                              // + the same span on the constant 100 MHz clock (high half of word 3): the core clock held
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
         if (lane == 0 && sk.ws) {
             u64t* d = (u64t*)sk.ws + ((int64_t)blockIdx.x * (N_MMA + N_DEQ) + wave) * 4;
-            d[0] = st.work; d[1] = st.wait; d[2] = st.bar; d[3] = st.n;
+            d[0] = st.work; d[1] = st.wait; d[2] = st.bar; d[3] = st.n | ((rt1 - rt0) << 32);
         }
     }
     for (; t < NT; ++t) mma_step<ABL, false, DENSE>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);

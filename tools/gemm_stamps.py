@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--k", type=int, default=4096)
     ap.add_argument("--abl", default="0,2048,1024,4,2")
     ap.add_argument("--lib", default="mxq_amd/libmxq_hip_prof.so")
+    ap.add_argument("--launches", type=int, default=200)
     args = ap.parse_args()
     lib = ctypes.CDLL(os.path.join(ROOT, args.lib))
     fn = lib.mxq_prof_gemm8_stamps_f16
@@ -37,18 +38,22 @@ def main():
     grid = ((M + 255) // 256) * ((N + 127) // 128)
     for abl in [int(a) for a in args.abl.split(",")]:
         dbg = torch.zeros(grid * 12 * 4, dtype=torch.int64, device=dev)
-        for _ in range(20):   # warm clocks; the last launch's sums are read
+        for _ in range(args.launches):   # sustained load; the last launch's sums are read
             rc = fn(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), y.data_ptr(), M, N, K, abl, dbg.data_ptr(),
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0, rc
         torch.cuda.synchronize()
-        d = dbg.view(grid, 12, 4).double().cpu()
+        raw = dbg.view(grid, 12, 4).cpu()
+        rt = (raw[:, :8, 3] >> 32).double()                     # 100 MHz ticks over the stamped K-steps
+        d = raw.double()
+        d[:, :, 3] = (raw[:, :, 3] & 0xFFFFFFFF).double()
         steps = d[:, :, 3].clamp(min=1)
         per = d[:, :, :3] / steps[:, :, None]            # cycles per K-step
         for name, sl in (("MFMA waves 0-7", slice(0, 8)),):
             w = per[:, sl, :].mean(dim=(0, 1))
-            print(f"abl {abl:5d} {name:28s} work {w[0]:7.0f}  wait {w[1]:6.0f}  barrier {w[2]:6.0f}  total {w.sum():7.0f} cycles/step",
-                  flush=True)
+            ghz = (d[:, sl, :3].sum(dim=2) / rt.clamp(min=1) / 10.0).mean().item()
+            print(f"abl {abl:5d} {name:28s} work {w[0]:7.0f}  wait {w[1]:6.0f}  barrier {w[2]:6.0f}  total {w.sum():7.0f} cycles/step"
+                  f"   core clock held {ghz:.2f} GHz", flush=True)
 
 
 if __name__ == "__main__":
