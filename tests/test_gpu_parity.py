@@ -873,10 +873,11 @@ def test_kat_test_correct_gemv(dev, g6):
             full((N,), 1, np.float16), full((N // 8,), 0, np.int32), 32)   # unsupported group size raises
 
 
-def test_proto_and_awq_gemv_random_vs_oracle(dev):
+@pytest.mark.parametrize("B", [1, 2, 5])     # 5: two batch blocks of the in-kernel batch loop, the second one ragged
+def test_proto_and_awq_gemv_random_vs_oracle(dev, B):
     import mxq_inference_engine as eng
-    rng = np.random.default_rng(3)
-    OC, IC, B = 64, 4096, 2
+    rng = np.random.default_rng(3 + B)
+    OC, IC = 64, 4096
     ri = lambda shape: rng.integers(0, 2 ** 32, shape, dtype=np.uint64).astype(np.uint32)
     x = (rng.standard_normal((B, IC)) * 0.5).astype(np.float16)
     ops = dict(weight=ri((OC, 256)), weight_last=ri((OC, 64)), zs=ri((OC, 32)),
