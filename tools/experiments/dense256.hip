@@ -1,9 +1,10 @@
 // EXPERIMENT RECORD (round 2, second session) -- not built, not part of the product.
-// A 256 x 256-tile MFMA kernel for the hoisted-dequant mode (dense fp16 weight), written into csrc/gemm8.hip's anonymous
-// namespace (it uses that file's helpers: swz, bufdma16, make_rsrc, tile_of_block, MXQ_FENCE, MXQ_LANE_ID, cu_count) and
-// exposed through two profiling entries for tools/ab_gemm.py (variants dense256 / dense256e).  Correct on every shape
-// tried (<= 1e-3 against the fp32 product at 4096 and 32768 tokens).  Measurements and verdict:
-// profiles/r02_gemmx_experiment.txt ("dense256").
+// A 256 x 256-tile MFMA kernel for the hoisted-dequant mode (dense fp16 weight).  It was compiled inside csrc/gemm8.hip's
+// anonymous namespace (it uses that file's helpers: swz, bufdma16, make_rsrc, tile_of_block, MXQ_FENCE, MXQ_LANE_ID,
+// stamp, cu_count) and driven through the profiling entries at the end (tools/ab_gemm.py variants dense256 / dense256e /
+// dense256p / dense256s / dense256s2 / dense256s3 / dense256h = modes 0..6; dense256_clock.py = stamps + clock).
+// Every mode is correct on every shape tried (<= 1e-3 against the fp32 product; 2300 / 4096 / 32768 tokens, ragged
+// edges, K = 128).  Measurements and verdict: profiles/r02_gemmx_experiment.txt ("dense256").
 // ------------------------------------------------------------------------------------------------
 // hoisted-dequant mode, 256 x 256 tile ("dense256")
 // ------------------------------------------------------------------------------------------------
@@ -50,6 +51,11 @@ __device__ __forceinline__ void issue_ws(const Dma2& d, char* smem, int wave, in
 #pragma unroll
     for (int i = 0; i < 4; ++i) bufdma16(d.wr, d.wv[i], (uint32_t)t * (BK * 2), dst + i * 1024);
 }
+// one piece of step t's tiles (q = 0..3: x, 4..7: weight); soff = t * 128, or an offset beyond the buffers: zeros, no traffic
+__device__ __forceinline__ void issue_piece(const Dma2& d, char* smem, int wave, int t, uint32_t soff, int q) {
+    if (q < 4) bufdma16(d.xr, d.xv[q], soff, smem + OFF_A2 + (t & 1) * A2 + wave * 4096 + q * 1024);
+    else bufdma16(d.wr, d.wv[q - 4], soff, smem + OFF_W2 + (t & 1) * W2 + wave * 4096 + (q - 4) * 1024);
+}
 __device__ __forceinline__ void load_frags2(const char* smem, int t, int kk, int wm, int wn, int fr, int fq, FragW& wf, FragX& xf) {
     const char* a = smem + OFF_A2 + (t & 1) * A2;
     const char* w = smem + OFF_W2 + (t & 1) * W2;
@@ -95,6 +101,38 @@ __device__ __forceinline__ void store_tile2(const f32x4 (&acc)[4][8], uint16_t* 
     }
 }
 
+// MODE 3's K loop for one stagger order (FIRST = the wave issues its DMA piece BEFORE each row of 8 MFMAs; its SIMD partner after)
+template <bool FIRST, int SLEEP>
+__device__ __forceinline__ void steps_staggered(char* smem, const Dma2& cur, int wave, int NT, int wm, int wn, int fr, int fq,
+                                                f32x4 (&acc)[4][8], FragW& wf0, FragX& xf0, FragW& wf1, FragX& xf1) {
+    for (int t = 1; t < NT; ++t) {
+        if constexpr (SLEEP > 0) {      // the stagger: the SIMD partner (wm = 1) starts its step half a row-and-piece period later
+            if (wm) __builtin_amdgcn_s_sleep(SLEEP);
+        }
+        const uint32_t so = t + 1 < NT ? (uint32_t)(t + 1) * (BK * 2) : 0x80000000u;
+#define D256_ROW(SET_W, SET_X, R, Q)                                                   \
+        if constexpr (FIRST) { issue_piece(cur, smem, wave, t + 1, so, Q); MXQ_FENCE(); } \
+        mfma_rows2<R, R + 1>(acc, SET_W, SET_X);                                       \
+        MXQ_FENCE();                                                                   \
+        if constexpr (!FIRST) { issue_piece(cur, smem, wave, t + 1, so, Q); MXQ_FENCE(); }
+        D256_ROW(wf1, xf1, 0, 0)
+        load_frags2(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
+        MXQ_FENCE();
+        D256_ROW(wf1, xf1, 1, 1)
+        D256_ROW(wf1, xf1, 2, 2)
+        D256_ROW(wf1, xf1, 3, 3)
+        load_frags2(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
+        MXQ_FENCE();
+        D256_ROW(wf0, xf0, 0, 4)
+        D256_ROW(wf0, xf0, 1, 5)
+        D256_ROW(wf0, xf0, 2, 6)
+        D256_ROW(wf0, xf0, 3, 7)
+#undef D256_ROW
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 // Tile order: XCD e (= t & 7) owns the token-tile rows [e * tiles_m / 8, (e + 1) * tiles_m / 8) and walks them in bands of
 // 4 rows x blocks of 8 panels, so that the 32 workgroups of an XCD run 4 x tiles against 8 weight tiles (both 32 KB per
 // K-step here); needs tiles_m % 32 == 0, otherwise the order of the 256 x 128 kernel.
@@ -121,23 +159,33 @@ __device__ __forceinline__ void tile_of_block2(int t, int tiles_m, int tiles_n, 
     tile_of_block(t, tiles_m, tiles_n, tm, tn);
 }
 
-template <bool EARLY>
+template <int MODE>
 __global__ __launch_bounds__(THREADS2) void mxq_dense256_f16_kernel(const uint16_t* __restrict__ x,
                                                                     const uint16_t* __restrict__ w,
                                                                     uint16_t* __restrict__ y, int M, int N, int K,
-                                                                    int tiles_m, int tiles_n, int tiles, int grid) {
+                                                                    int tiles_m, int tiles_n, int tiles, int grid,
+                                                                    unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NT = K / BK;
     const int wm = wave >> 2, wn = wave & 3;
+    u64t rt0 = 0, mt0 = 0, stw = 0, stl = 0, stv = 0, stb = 0, stn = 0;
+    if (dbg) {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+        mt0 = stamp();
+    }
     int tm, tn;
     tile_of_block2(blockIdx.x, tiles_m, tiles_n, tm, tn);
     int ln;
     MXQ_LANE_ID(ln);
+    constexpr bool EARLY = MODE == 1;
     Dma2 cur, nxt;
     dma_setup(cur, x, w, M, N, K, tm * BM2, tn * BN2, wave, ln);
     issue_xs(cur, smem, wave, 0);
     issue_ws(cur, smem, wave, 0);
+    if constexpr (MODE == 2 || MODE == 6) {
+        if (NT > 1) { issue_xs(cur, smem, wave, 1); issue_ws(cur, smem, wave, 1); }
+    }
     for (int tile = blockIdx.x; tile < tiles; tile += grid) {
         MXQ_LANE_ID(ln);
         const int fr = ln & 15, fq = ln >> 4;
@@ -151,6 +199,104 @@ __global__ __launch_bounds__(THREADS2) void mxq_dense256_f16_kernel(const uint16
             for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         FragW wf0, wf1;
         FragX xf0, xf1;
+        if constexpr (MODE == 2) {
+            // Two barriers per K-step.  B_a: every wave holds step t's fragments -> stage t & 1 is free, and the DMAs of
+            // step t+2 go into it at once; B_b: the DMAs of step t+1 (issued a step and a half ago) have landed
+            // (vmcnt(8): only the 8 pieces just issued stay in flight).
+            if (NT > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            load_frags2(smem, 0, 0, wm, wn, fr, fq, wf0, xf0);
+            load_frags2(smem, 0, 1, wm, wn, fr, fq, wf1, xf1);
+            mfma_rows2<0, 2>(acc, wf0, xf0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                   // B_a(0)
+            if (NT > 2) { issue_xs(cur, smem, wave, 2); issue_ws(cur, smem, wave, 2); }
+            mfma_rows2<2, 4>(acc, wf0, xf0);
+            if (NT > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                   // B_b(0)
+            for (int t = 1; t < NT; ++t) {
+                const bool issue = t + 2 < NT;
+                mfma_rows2<0, 1>(acc, wf1, xf1);
+                MXQ_FENCE();
+                load_frags2(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
+                MXQ_FENCE();
+                mfma_rows2<1, 4>(acc, wf1, xf1);
+                MXQ_FENCE();
+                load_frags2(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
+                MXQ_FENCE();
+                mfma_rows2<0, 2>(acc, wf0, xf0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                               // B_a(t)
+                if (issue) { issue_xs(cur, smem, wave, t + 2); issue_ws(cur, smem, wave, t + 2); }
+                MXQ_FENCE();
+                mfma_rows2<2, 4>(acc, wf0, xf0);
+                if (issue) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                               // B_b(t)
+            }
+            if (more) {
+                dma_setup(nxt, x, w, M, N, K, tm * BM2, tn * BN2, wave, ln);
+                issue_xs(nxt, smem, wave, 0);
+                issue_ws(nxt, smem, wave, 0);
+                if (NT > 1) { issue_xs(nxt, smem, wave, 1); issue_ws(nxt, smem, wave, 1); }
+            }
+        } else if constexpr (MODE == 6) {
+            // Half-step stagger between the two waves of a SIMD (wm = 0 "A", wm = 1 "B"): a K-step is two phases, X1 = the
+            // previous step's kk = 1 MFMAs + this step's fragment reads, X2 = this step's kk = 0 MFMAs, one barrier per
+            // phase; B runs one phase behind A, so a SIMD always has one wave reading fragments and one only multiplying.
+            // Stage t & 1 is free once A (global phase 2t) and B (2t+1) hold step t's fragments; DMA(t+2) is issued by
+            // everybody in global phase 2t+2 and awaited at the end of 2t+3, a full K-step later.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wm) __builtin_amdgcn_s_barrier();              // B idles through global phase 0
+            for (int t = 0; t < NT; ++t) {
+                // ---- X1(t)
+                if (!wm && t >= 1 && t + 1 < NT) { issue_xs(cur, smem, wave, t + 1); issue_ws(cur, smem, wave, t + 1); }
+                MXQ_FENCE();
+                if (t >= 1) mfma_rows2<0, 1>(acc, wf1, xf1);
+                MXQ_FENCE();
+                load_frags2(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
+                MXQ_FENCE();
+                if (t >= 1) mfma_rows2<1, 4>(acc, wf1, xf1);
+                MXQ_FENCE();
+                load_frags2(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (wm && t >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                // ---- X2(t)
+                if (wm && t + 2 < NT) { issue_xs(cur, smem, wave, t + 2); issue_ws(cur, smem, wave, t + 2); }
+                MXQ_FENCE();
+                mfma_rows2<0, 4>(acc, wf0, xf0);
+                if (!wm && t >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(wm && t == NT - 1)) __builtin_amdgcn_s_barrier();
+            }
+            if (more) {
+                dma_setup(nxt, x, w, M, N, K, tm * BM2, tn * BN2, wave, ln);
+                issue_xs(nxt, smem, wave, 0);
+                issue_ws(nxt, smem, wave, 0);
+                if (NT > 1) { issue_xs(nxt, smem, wave, 1); issue_ws(nxt, smem, wave, 1); }
+            }
+        } else if constexpr (MODE >= 3) {
+            // One barrier per K-step (stage (t+1) & 1 is free from the start of step t), but the 8 DMA pieces of step t+1 go
+            // out ONE per row of 8 MFMAs, and the two waves of a SIMD (wm = 0 / 1) take "piece, row" and "row, piece" turns:
+            // a piece costs its wave ~100+ cycles of issue, during which the partner's MFMAs keep the pipe busy.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (NT > 1) { issue_xs(cur, smem, wave, 1); issue_ws(cur, smem, wave, 1); }
+            load_frags2(smem, 0, 0, wm, wn, fr, fq, wf0, xf0);
+            load_frags2(smem, 0, 1, wm, wn, fr, fq, wf1, xf1);
+            mfma_rows2<0, 4>(acc, wf0, xf0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            steps_staggered<true, (MODE >= 4 ? MODE - 2 : 0)>(smem, cur, wave, NT, wm, wn, fr, fq, acc, wf0, xf0, wf1, xf1);
+            if (more) {
+                dma_setup(nxt, x, w, M, N, K, tm * BM2, tn * BN2, wave, ln);
+                issue_xs(nxt, smem, wave, 0);
+                issue_ws(nxt, smem, wave, 0);
+            }
+        } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // step 0's tiles (and the previous tile's output stores)
         __builtin_amdgcn_s_barrier();
         // step 0: no previous half
@@ -164,9 +310,8 @@ __global__ __launch_bounds__(THREADS2) void mxq_dense256_f16_kernel(const uint16
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int t = 1; t < NT; ++t) {
-            // MFMAs of (t-1, kk = 1) and (t, kk = 0); fragment reads of step t; the DMAs of step t+1 (slot (t+1) & 1 was
-            // last read in step t-1), spread behind groups of MFMAs
             const bool issue = t + 1 < NT;
+            const u64t s0 = dbg ? stamp() : 0;
             mfma_rows2<0, 1>(acc, wf1, xf1);
             MXQ_FENCE();
             load_frags2(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
@@ -186,6 +331,17 @@ __global__ __launch_bounds__(THREADS2) void mxq_dense256_f16_kernel(const uint16
             if (!EARLY && issue) issue_ws(cur, smem, wave, t + 1);
             MXQ_FENCE();
             mfma_rows2<2, 4>(acc, wf0, xf0);
+            if (dbg) {
+                const u64t s1 = stamp();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const u64t s2 = stamp();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const u64t s3 = stamp();
+                __builtin_amdgcn_s_barrier();
+                const u64t s4 = stamp();
+                stw += s1 - s0; stl += s2 - s1; stv += s3 - s2; stb += s4 - s3; stn += 1;
+                continue;
+            }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -195,26 +351,49 @@ __global__ __launch_bounds__(THREADS2) void mxq_dense256_f16_kernel(const uint16
             issue_xs(nxt, smem, wave, 0);
             issue_ws(nxt, smem, wave, 0);
         }
+        }
         mfma_rows2<0, 4>(acc, wf1, xf1);     // (NT-1, kk = 1)
         store_tile2(acc, y, M, N, m0, n0, wm, wn, fr, fq);
         cur = nxt;
     }
+    if (dbg && blockIdx.x == 8 && threadIdx.x == 0) {
+        u64t rt1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+        dbg[0] = stamp() - mt0;
+        dbg[1] = rt1 - rt0;
+    }
+    if (dbg && blockIdx.x == 8 && (threadIdx.x & 63) == 0) {
+        unsigned long long* d = dbg + 2 + wave * 5;
+        d[0] = stw; d[1] = stl; d[2] = stv; d[3] = stb; d[4] = stn;
+    }
 }
 
-template <bool EARLY>
-int launch(const void* x, const void* w16, void* y, int M, int N, int K, hipStream_t stream) {
+template <int MODE>
+int launch(const void* x, const void* w16, void* y, int M, int N, int K, hipStream_t stream, unsigned long long* dbg = nullptr) {
     if ((int64_t)BM2 * K * 2 >= ((int64_t)1 << 32)) return -1;
-    hipError_t e = hipFuncSetAttribute((const void*)mxq_dense256_f16_kernel<EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2);
+    hipError_t e = hipFuncSetAttribute((const void*)mxq_dense256_f16_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2);
     if (e != hipSuccess) return (int)e;
     const int tiles_m = (M + BM2 - 1) / BM2, tiles_n = (N + BN2 - 1) / BN2, tiles = tiles_m * tiles_n;
     const int cus = cu_count() / 8 * 8;
     const int grid = tiles < cus ? tiles : cus;
-    mxq_dense256_f16_kernel<EARLY><<<grid, THREADS2, SMEM2, stream>>>((const uint16_t*)x, (const uint16_t*)w16, (uint16_t*)y, M, N,
-                                                             K, tiles_m, tiles_n, tiles, grid);
+    mxq_dense256_f16_kernel<MODE><<<grid, THREADS2, SMEM2, stream>>>((const uint16_t*)x, (const uint16_t*)w16, (uint16_t*)y, M, N,
+                                                             K, tiles_m, tiles_n, tiles, grid, dbg);
     return (int)hipGetLastError();
 }
 }   // namespace d256
 
-// profiling entries (inside #ifdef MXQ_PROFILING of gemm8.hip):
-// extern "C" int mxq_prof_dense256_f16(...)  { return d256::launch<false>(x, w16, y, M, N, K, stream); }   // DMAs mid-step
-// extern "C" int mxq_prof_dense256e_f16(...) { return d256::launch<true>(x, w16, y, M, N, K, stream); }    // DMAs at the head
+#ifdef MXQ_PROFILING
+extern "C" int mxq_prof_dense256_clock(const void* x, const void* w16, void* y, int M, int N, int K, void* dbg, void* stream_) {
+    return d256::launch<1>(x, w16, y, M, N, K, (hipStream_t)stream_, (unsigned long long*)dbg);
+}
+extern "C" int mxq_prof_dense256_f16(const void* x, const void* w16, void* y, int M, int N, int K, int mode, void* stream_) {
+    if (mode == 6) return d256::launch<6>(x, w16, y, M, N, K, (hipStream_t)stream_);
+    if (mode == 5) return d256::launch<5>(x, w16, y, M, N, K, (hipStream_t)stream_);
+    if (mode == 4) return d256::launch<4>(x, w16, y, M, N, K, (hipStream_t)stream_);
+    if (mode == 3) return d256::launch<3>(x, w16, y, M, N, K, (hipStream_t)stream_);
+    if (mode == 2) return d256::launch<2>(x, w16, y, M, N, K, (hipStream_t)stream_);
+    if (mode == 1) return d256::launch<1>(x, w16, y, M, N, K, (hipStream_t)stream_);
+    return d256::launch<0>(x, w16, y, M, N, K, (hipStream_t)stream_);
+}
+
+#endif
