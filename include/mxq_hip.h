@@ -87,8 +87,8 @@ int mxq_dequant_f16(const void* qweight, const void* rowmeta, void* w16, int N, 
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream);
 /* The code paths of mxq_linear_f16, exposed for benchmarking / testing: streaming GEMV (M <= 4), skinny MFMA kernel
- * (4 < M <= 32: every packed byte read once, a lane dequantises the MFMA operand it owns; the reference re-reads the
- * weights once per batch row, gemv_mxq_cuda.cu:261-262), prefill GEMM (M > 32).  mxq_skinny_f16 accepts 1 <= M <= 32
+ * (4 < M <= 48: every packed byte read once, a lane dequantises the MFMA operand it owns; the reference re-reads the
+ * weights once per batch row, gemv_mxq_cuda.cu:261-262), prefill GEMM (M > 48).  mxq_skinny_f16 accepts 1 <= M <= 64
  * and layout MXQ_LAYOUT_MIXED (0) or MXQ_LAYOUT_MIXEDC (3, compact metadata, below). */
 int mxq_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
                    void* stream);

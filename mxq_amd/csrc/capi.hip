@@ -112,7 +112,7 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
 int mxq_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
                    void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
-    if (M > 32 || (layout != MXQ_LAYOUT_MIXED && layout != MXQ_LAYOUT_MIXEDC)) return MXQ_E_SHAPE;
+    if (M > 64 || (layout != MXQ_LAYOUT_MIXED && layout != MXQ_LAYOUT_MIXEDC)) return MXQ_E_SHAPE;
     return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
 }
 
@@ -226,7 +226,7 @@ int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void
                    void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-    if (M <= 32) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
+    if (M <= 48) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
     return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
 }
 
@@ -246,7 +246,7 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-    if (M <= 32) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
+    if (M <= 48) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
     return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

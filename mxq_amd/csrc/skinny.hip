@@ -1,4 +1,4 @@
-// Skinny quantised Linear for 4 < M <= 32 tokens (small-batch decode / speculative verification):
+// Skinny quantised Linear for 4 < M <= 48 tokens, up to 64 on request (small-batch decode / speculative verification):
 //   y[m, n] = sum_k x[m, k] * fp16(scale * (q - zero))[n, k], fp32 accumulate, fp16 out.
 //
 // The reference's kernel handles batch rows by re-reading the weights once per row (gridDim.z,
@@ -14,7 +14,8 @@
 //     four-bit code words (kq >= 2).  The 4-entry LUT of a 2-bit group is built by both lanes that share it;
 //   * the B operand (8 consecutive activations of token lane & 15) comes straight from global memory / L2 with one
 //     16-byte load per lane (x is at most 32 x K fp16: L2-resident, too big for an LDS copy at 32 tokens);
-//   * per chunk 2 x MT MFMAs (MT = 1 or 2 blocks of 16 tokens); the waves' partial tiles meet in LDS.
+//   * per chunk 2 x MT MFMAs (MT = 1..4 blocks of 16 tokens; beyond 48 tokens the prefill kernel's tile is the faster
+//     one on the MLP shapes: 54 vs 50 us at 64 tokens, but 41 vs 49 us at 48); the waves' partial tiles meet in LDS.
 // D^T = W . x^T as in the prefill kernel: a lane ends with 4 consecutive channels of one token.
 // Layouts: mixed with exact (v1) or compact metadata.
 #include <hip/hip_runtime.h>
@@ -170,16 +171,21 @@ int launch_c(const void* x, const void* qweight, const void* rowmeta, void* y, i
     if (M <= 16)
         return big ? launch_t<1, 512, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream)
                    : launch_t<1, 1024, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream);
-    return big ? launch_t<2, 512, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream)
-               : launch_t<2, 1024, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream);
+    if (M <= 32)
+        return big ? launch_t<2, 512, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream)
+                   : launch_t<2, 1024, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream);
+    if (M <= 48)
+        return big ? launch_t<3, 512, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream)
+                   : launch_t<3, 1024, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream);
+    return launch_t<4, 512, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream);   // (16 waves would spill at 128 VGPRs)
 }
 
 }   // namespace
 
-// 1 <= M <= 32; layout MXQ_LAYOUT_MIXED or MXQ_LAYOUT_MIXEDC
+// 1 <= M <= 64; layout MXQ_LAYOUT_MIXED or MXQ_LAYOUT_MIXEDC
 int mxq_launch_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                           int layout, hipStream_t stream) {
-    if (M < 1 || M > 32) return -1;
+    if (M < 1 || M > 64) return -1;
     if (layout == MXQ_LAYOUT_MIXED) return launch_c<false>(x, qweight, rowmeta, y, M, N, K, stream);
     if (layout == MXQ_LAYOUT_MIXEDC) return launch_c<true>(x, qweight, rowmeta, y, M, N, K, stream);
     return -1;

@@ -264,8 +264,8 @@ GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9}   # inc
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
     """y = x @ dequant(p).T for x [..., K] fp16 -> [..., N] fp16 (fp32 accumulation).
 
-    path: "auto" (GEMV kernel for <= 4 tokens, skinny MFMA kernel for 5..32, prefill GEMM beyond), "gemm", "gemv",
-    "skinny" (1..32 tokens), "hoist" (dequant hoisted out of the token loop; "auto" / "gemm" take it from
+    path: "auto" (GEMV kernel for <= 4 tokens, skinny MFMA kernel for 5..48, prefill GEMM beyond), "gemm", "gemv",
+    "skinny" (1..64 tokens), "hoist" (dequant hoisted out of the token loop; "auto" / "gemm" take it from
     HOIST_MIN_TOKENS tokens on), "fused" (never hoist), or an explicit GEMM
     kernel: "gemm1" (128x128 tile), "gemm8" (256x128 tile, wave-specialised, persistent, stream-K tail), "gemm9"
     (gemm8 splitting its tail whenever that is structurally possible: tests)."""
@@ -288,7 +288,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         return linear_hoisted(x, p, out=out)
     lib = _lib.load()
     args = (x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K)
-    if path == "skinny" or (p.compact and path == "auto" and 4 < M <= 32):
+    if path == "skinny" or (p.compact and path == "auto" and 4 < M <= 48):
         with torch.cuda.device(x.device):
             _lib.check(lib.mxq_skinny_f16(*args, 3 if p.compact else 0, _stream(x2)), "mxq_skinny_f16")
         return out.reshape(*x.shape[:-1], p.N)

@@ -526,7 +526,7 @@ def test_attn_decode_kernel_across_the_prefetched_rows(dev, pos):
     assert ((out.float() - want).abs().max() / want.abs().max()).item() < 4e-3
 
 
-@pytest.mark.parametrize("M", [1, 5, 8, 16, 17, 32])
+@pytest.mark.parametrize("M", [1, 5, 8, 16, 17, 32, 33, 48, 64])
 @pytest.mark.parametrize("N,K", [(64, 256), (256, 704), (4096, 4096), (11008, 4096), (4096, 11008)])
 @pytest.mark.parametrize("compact", [False, True])
 def test_skinny_mfma_vs_oracle(dev, M, N, K, compact):
@@ -576,7 +576,7 @@ def test_skinny_integer_exact_and_nonfinite(dev):
     y = packing.linear(xt, pk, path="skinny")
     assert torch.isnan(y[3]).all() and torch.isfinite(y[[i for i in range(M) if i != 3]]).all()
     with pytest.raises(ValueError):
-        packing.linear(torch.zeros(33, K, dtype=torch.float16, device=dev), pk, path="skinny")
+        packing.linear(torch.zeros(65, K, dtype=torch.float16, device=dev), pk, path="skinny")
 
 
 @pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])

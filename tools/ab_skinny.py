@@ -15,7 +15,7 @@ from mxq_amd import packing  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ms", default="1,4,5,8,16,32,64")
+    ap.add_argument("--ms", default="1,4,5,8,16,32,33,48,64")
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008")
     ap.add_argument("--compact", action="store_true")
     args = ap.parse_args()
@@ -30,7 +30,7 @@ def main():
             out = torch.empty(M, N, device=dev, dtype=torch.float16)
             parts = []
             for path in ("gemv", "skinny", "gemm"):
-                if (path == "gemv" and M > 4) or (path == "skinny" and M > 32):
+                if (path == "gemv" and M > 4) or (path == "skinny" and M > 64):
                     continue
                 packing.linear(x, base, out=out, path=path)
                 torch.cuda.synchronize()
