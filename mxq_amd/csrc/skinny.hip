@@ -15,7 +15,7 @@
 //   * the B operand (8 consecutive activations of token lane & 15) comes straight from global memory / L2 with one
 //     16-byte load per lane (x is at most 32 x K fp16: L2-resident, too big for an LDS copy at 32 tokens);
 //   * per chunk 2 x MT MFMAs (MT = 1..4 blocks of 16 tokens; beyond 48 tokens the prefill kernel's tile is the faster
-//     one on the MLP shapes: 54 vs 50 us at 64 tokens, but 41 vs 49 us at 48); the waves' partial tiles meet in LDS.
+//     one on the MLP shapes: 54 vs 51 us at 64 tokens, but 42 vs 50 us at 48); the waves' partial tiles meet in LDS.
 // D^T = W . x^T as in the prefill kernel: a lane ends with 4 consecutive channels of one token.
 // Layouts: mixed with exact (v1) or compact metadata.
 #include <hip/hip_runtime.h>
