@@ -2,7 +2,7 @@
 // A 256 x 256-tile MFMA kernel for the hoisted-dequant mode (dense fp16 weight).  It was compiled inside csrc/gemm8.hip's
 // anonymous namespace (it uses that file's helpers: swz, bufdma16, make_rsrc, tile_of_block, MXQ_FENCE, MXQ_LANE_ID,
 // stamp, cu_count) and driven through the profiling entries at the end (tools/ab_gemm.py variants dense256 / dense256e /
-// dense256p / dense256s / dense256s2 / dense256s3 / dense256h = modes 0..6; dense256_clock.py = stamps + clock).
+// dense256p / dense256s / dense256s2 / dense256s3 / dense256h / (7: priority toggling) / dense256pp = modes 0..8; dense256_clock.py = stamps + clock).
 // Every mode is correct on every shape tried (<= 1e-3 against the fp32 product; 2300 / 4096 / 32768 tokens, ragged
 // edges, K = 128).  Measurements and verdict: profiles/r02_gemmx_experiment.txt ("dense256").
 // ------------------------------------------------------------------------------------------------
@@ -133,6 +133,32 @@ __device__ __forceinline__ void steps_staggered(char* smem, const Dma2& cur, int
     }
 }
 
+
+// ---- MODE 8, "ping-pong": the two waves of a SIMD never multiply at the same time.  Phase 2t: the A waves (wm = 0) run
+// step t's 64 MFMAs from registers while the B waves read step t's fragments; phase 2t+1: B multiplies, A reads step
+// t+1's fragments and issues ALL of DMA(t+2) (16 pieces per A wave: rows 64 wn .. of both tiles).  One barrier per
+// phase.  A multiplying wave has every operand in registers: a bare MFMA stream at the pipe's rate.
+struct Dma3 { rsrc_t xr, wr; uint32_t v[8]; };
+__device__ __forceinline__ void dma3_setup(Dma3& d, const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, int M,
+                                           int N, int K, int m0, int n0, int wn, int lane) {
+    const int rx = M - m0 < BM2 ? M - m0 : BM2, rw = N - n0 < BN2 ? N - n0 : BN2;
+    d.xr = make_rsrc(x + (int64_t)m0 * K, (uint32_t)rx * (uint32_t)K * 2u);
+    d.wr = make_rsrc(w + (int64_t)n0 * K, (uint32_t)rw * (uint32_t)K * 2u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wn * 64 + i * 8 + (lane >> 3);
+        d.v[i] = (uint32_t)row * (uint32_t)K * 2u + ((((uint32_t)lane & 7u) ^ ((uint32_t)row & 7u)) << 4);
+    }
+}
+__device__ __forceinline__ void issue3(const Dma3& d, char* smem, int wn, int t) {
+    char* dx = smem + OFF_A2 + (t & 1) * A2 + wn * 8192;
+    char* dw = smem + OFF_W2 + (t & 1) * W2 + wn * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bufdma16(d.xr, d.v[i], (uint32_t)t * (BK * 2), dx + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bufdma16(d.wr, d.v[i], (uint32_t)t * (BK * 2), dw + i * 1024);
+}
+
 // Tile order: XCD e (= t & 7) owns the token-tile rows [e * tiles_m / 8, (e + 1) * tiles_m / 8) and walks them in bands of
 // 4 rows x blocks of 8 panels, so that the 32 workgroups of an XCD run 4 x tiles against 8 weight tiles (both 32 KB per
 // K-step here); needs tiles_m % 32 == 0, otherwise the order of the 256 x 128 kernel.
@@ -178,6 +204,75 @@ __global__ __launch_bounds__(THREADS2) void mxq_dense256_f16_kernel(const uint16
     tile_of_block2(blockIdx.x, tiles_m, tiles_n, tm, tn);
     int ln;
     MXQ_LANE_ID(ln);
+    if constexpr (MODE == 8) {
+        Dma3 cur3;
+        if (wm == 0) {
+            dma3_setup(cur3, x, w, M, N, K, tm * BM2, tn * BN2, wn, ln);
+            issue3(cur3, smem, wn, 0);
+            if (NT > 1) issue3(cur3, smem, wn, 1);
+        }
+        for (int tile = blockIdx.x; tile < tiles; tile += grid) {
+            MXQ_LANE_ID(ln);
+            const int fr = ln & 15, fq = ln >> 4;
+            const int m0 = tm * BM2, n0 = tn * BN2;
+            const bool more = tile + grid < tiles;
+            if (more) tile_of_block2(tile + grid, tiles_m, tiles_n, tm, tn);
+            f32x4 acc[4][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            FragW wf0, wf1;
+            FragX xf0, xf1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // DMA(0), DMA(1) (A waves) and the previous tile's stores
+            __builtin_amdgcn_s_barrier();
+            if (wm == 0) {
+                // phase -1: A reads step 0's fragments
+                load_frags2(smem, 0, 0, wm, wn, fr, fq, wf0, xf0);
+                load_frags2(smem, 0, 1, wm, wn, fr, fq, wf1, xf1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                for (int t = 0; t < NT; ++t) {
+                    // phase 2t: multiply step t
+                    mfma_rows2<0, 4>(acc, wf0, xf0);
+                    mfma_rows2<0, 4>(acc, wf1, xf1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // DMA(t+1), issued two phases ago, has landed
+                    __builtin_amdgcn_s_barrier();
+                    // phase 2t+1: stage t & 1 is free (B read it in phase 2t): all of DMA(t+2); step t+1's fragments
+                    if (t + 2 < NT) issue3(cur3, smem, wn, t + 2);
+                    if (t + 1 < NT) {
+                        load_frags2(smem, t + 1, 0, wm, wn, fr, fq, wf0, xf0);
+                        load_frags2(smem, t + 1, 1, wm, wn, fr, fq, wf1, xf1);
+                    } else {
+                        // the last phase of the tile (B multiplies): this tile's output, the next tile's first DMAs
+                        if (more) {
+                            dma3_setup(cur3, x, w, M, N, K, tm * BM2, tn * BN2, wn, ln);
+                            issue3(cur3, smem, wn, 0);
+                            if (NT > 1) issue3(cur3, smem, wn, 1);
+                        }
+                        store_tile2(acc, y, M, N, m0, n0, wm, wn, fr, fq);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            } else {
+                __builtin_amdgcn_s_barrier();                               // phase -1: B idles
+                for (int t = 0; t < NT; ++t) {
+                    // phase 2t: read step t's fragments
+                    load_frags2(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
+                    load_frags2(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    // phase 2t+1: multiply step t
+                    mfma_rows2<0, 4>(acc, wf0, xf0);
+                    mfma_rows2<0, 4>(acc, wf1, xf1);
+                    __builtin_amdgcn_s_barrier();
+                }
+                store_tile2(acc, y, M, N, m0, n0, wm, wn, fr, fq);
+            }
+        }
+        return;
+    }
     constexpr bool EARLY = MODE == 1;
     Dma2 cur, nxt;
     dma_setup(cur, x, w, M, N, K, tm * BM2, tn * BN2, wave, ln);
@@ -387,6 +482,7 @@ extern "C" int mxq_prof_dense256_clock(const void* x, const void* w16, void* y, 
     return d256::launch<1>(x, w16, y, M, N, K, (hipStream_t)stream_, (unsigned long long*)dbg);
 }
 extern "C" int mxq_prof_dense256_f16(const void* x, const void* w16, void* y, int M, int N, int K, int mode, void* stream_) {
+    if (mode == 8) return d256::launch<8>(x, w16, y, M, N, K, (hipStream_t)stream_);
     if (mode == 6) return d256::launch<6>(x, w16, y, M, N, K, (hipStream_t)stream_);
     if (mode == 5) return d256::launch<5>(x, w16, y, M, N, K, (hipStream_t)stream_);
     if (mode == 4) return d256::launch<4>(x, w16, y, M, N, K, (hipStream_t)stream_);
@@ -395,5 +491,6 @@ extern "C" int mxq_prof_dense256_f16(const void* x, const void* w16, void* y, in
     if (mode == 1) return d256::launch<1>(x, w16, y, M, N, K, (hipStream_t)stream_);
     return d256::launch<0>(x, w16, y, M, N, K, (hipStream_t)stream_);
 }
+
 
 #endif
