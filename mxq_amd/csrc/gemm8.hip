@@ -111,20 +111,17 @@ struct SkSeg {
     int j;            // tile index inside the XCD's tail
     int first;        // 1: the segment starts at the unit's range start (slot 0), else slot 1
 };
-typedef unsigned long long u64;
+// A wave's 16 KB slot, 16 bytes per lane and fragment: ONE sc1 (write-through / L1-bypassing) 16-byte access per fragment,
+// 1 KB contiguous per instruction.  (Round 2 began with two 8-byte agent-scope atomics per fragment: 8-byte accesses run at
+// 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md; nothing here needs atomicity -- a slot is read only after the
+// K-step count that its writer bumped behind s_waitcnt vmcnt(0) is complete.)
 __device__ __forceinline__ void st_agent(float* slot, int f, int lane, f32x4 v) {
-    union { f32x4 v4; u64 q[2]; } c;
-    c.v4 = v;
-    u64* p = (u64*)slot + (f * 2) * 64 + lane;
-    __hip_atomic_store(p, c.q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p + 64, c.q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const rsrc_t r = make_rsrc(slot, 16384u);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (uint32_t)(f * 64 + lane) * 16u, 0u, 16);
 }
 __device__ __forceinline__ f32x4 ld_agent(const float* slot, int f, int lane) {
-    union { f32x4 v4; u64 q[2]; } c;
-    const u64* p = (const u64*)slot + (f * 2) * 64 + lane;
-    c.q[0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    c.q[1] = __hip_atomic_load(p + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return c.v4;
+    const rsrc_t r = make_rsrc(slot, 16384u);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (uint32_t)(f * 64 + lane) * 16u, 0u, 16));
 }
 __device__ __forceinline__ int sk_bound(int u, int S, int units) { return (int)((uint32_t)u * (uint32_t)S / (uint32_t)units); }
 
