@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--abl", default="0,2048,1024,4,2")
     ap.add_argument("--lib", default="mxq_amd/libmxq_hip_prof.so")
     ap.add_argument("--launches", type=int, default=200)
+    ap.add_argument("--per-wave", action="store_true")
     args = ap.parse_args()
     lib = ctypes.CDLL(os.path.join(ROOT, args.lib))
     fn = lib.mxq_prof_gemm8_stamps_f16
@@ -54,6 +55,10 @@ def main():
             ghz = (d[:, sl, :3].sum(dim=2) / rt.clamp(min=1) / 10.0).mean().item()
             print(f"abl {abl:5d} {name:28s} work {w[0]:7.0f}  wait {w[1]:6.0f}  barrier {w[2]:6.0f}  total {w.sum():7.0f} cycles/step"
                   f"   core clock held {ghz:.2f} GHz", flush=True)
+        if args.per_wave:      # the two MFMA waves of a SIMD (w and w + 4) are not served alike: the older one goes first
+            for wv in range(8):
+                w = per[:, wv, :].mean(dim=0)
+                print(f"          MFMA wave {wv} (SIMD {wv % 4})       work {w[0]:7.0f}  wait {w[1]:6.0f}  barrier {w[2]:6.0f}", flush=True)
 
 
 if __name__ == "__main__":
