@@ -14,10 +14,10 @@ for _ in range(30):
 torch.cuda.synchronize()
 vals = dbg.cpu().tolist()
 mt, rt = vals[0], vals[1]
-for w in range(8):
-    sw, sl, sv, sb, n = vals[2 + 5 * w: 7 + 5 * w]
+for wv in range(8):
+    sw, sl, sv, sb, n = vals[2 + 5 * wv: 7 + 5 * wv]
     n = max(n, 1)
-    print(f"  wave {w}: per K-step work {sw / n:7.0f}  lgkm wait {sl / n:5.0f}  vm wait {sv / n:6.0f}  barrier {sb / n:6.0f}  total {(sw + sl + sv + sb) / n:7.0f} cycles ({n} steps)")
+    print(f"  wave {wv}: per K-step work {sw / n:7.0f}  lgkm wait {sl / n:5.0f}  vm wait {sv / n:6.0f}  barrier {sb / n:6.0f}  total {(sw + sl + sv + sb) / n:7.0f} cycles ({n} steps)")
 print(f"dense256e, 32768 x 4096^2: kernel {rt / 100:.1f} us on the 100 MHz clock, {mt} core cycles -> {mt / rt / 10:.2f} GHz held")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
