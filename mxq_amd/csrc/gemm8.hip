@@ -64,6 +64,9 @@ constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K
 
 // profiling-only switches (template parameter ABL; product build = 0)
 constexpr int ABL_NO_MFMA = 2, ABL_NO_DEQ = 4, ABL_NO_XDMA = 1, ABL_NO_STORE = 256;
+// 16: the dequant waves skip the 4-bit arm (its loads and its conversion); 32: the OLDER MFMA wave of each SIMD (waves 0-3)
+// carries 30 independent VALU ops per K-step -- what taking that arm over would cost it.  Timing only.
+constexpr int ABL_NO_Q4 = 16, ABL_MMA_VALU = 32;
 // scheduling experiments (correct results): issue priorities of the two roles
 constexpr int EXP_NO_PRIO = 1024, EXP_MMA_PRIO = 2048, EXP_STAMPS = 4096;
 
@@ -203,6 +206,17 @@ __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, in
     load_frags<DENSE>(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
     MXQ_FENCE();
     mfma_rows<0, 2, ABL>(acc, wf0, xf0);
+    MXQ_FENCE();
+    if constexpr ((ABL & ABL_MMA_VALU) != 0) {
+        if (wave < 4) {
+            float b0 = (float)t, b1 = b0 + 1.f, b2 = b0 + 2.f, b3 = b0 + 3.f, b4 = b0 + 4.f;
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1\n\tv_add_f32 %2, %2, %2\n\tv_add_f32 %3, %3, %3\n\tv_add_f32 %4, %4, %4"
+                             : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4));
+            asm volatile("" ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4));
+        }
+    }
     MXQ_FENCE();
     if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) issue_x<2, 4>(xd, smem, wave, t + 2);
     MXQ_FENCE();
@@ -467,7 +481,7 @@ struct PkOf<MXQ_LAYOUT_W4ROW> { typedef Pk4 type; };
 // first had them copied into a 4-slot LDS ring by LDS-DMA and read back from there: the two DMA pieces per wave and
 // step cost their issuer 100-185 cycles apiece next to MFMAs, on the one wave per SIMD whose ~90-op chain is the
 // critical path of a K-step (-2..4 % per launch without them; bit-identical results).
-template <int LAYOUT, int H>
+template <int LAYOUT, int H, bool NOQ4 = false>
 __device__ __forceinline__ void load_pk(const Deq& c, int t, typename PkOf<LAYOUT>::type& k) {
     constexpr int BYTES = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : LAYOUT == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
     // wave-uniform by construction; said explicitly, or a K offset selected between two tiles' descriptors counts as
@@ -494,7 +508,7 @@ __device__ __forceinline__ void load_pk(const Deq& c, int t, typename PkOf<LAYOU
         k.c[1] = dw((MIXED ? mxq_c2(1, c.r) : mxq_w2_c2(1, c.r)) + g0 * 16);
         k.z[1] = zero_of(g0 + 1);
         k.qq[1] = (f32x2){__uint_as_float(dw(QQ0 + g0 * 2 + 2)), __uint_as_float(dw(QQ0 + g0 * 2 + 3))};
-    } else {
+    } else if constexpr (!NOQ4) {
         k.c[2] = dw(mxq_c4(0, c.r));
         k.c[3] = dw(mxq_c4(1, c.r));
     }
@@ -511,7 +525,7 @@ __device__ __forceinline__ void widen_pk(typename PkOf<LAYOUT>::type& k) {   // 
 
 // chunk t: preloaded packed words -> fp16 W16[t & 1]
 // chunk's packed words -> the thread's 32 fp16 weights (4 x 16 bytes: W16 slots s0 .. s0+3 of its row)
-template <int LAYOUT, int H>
+template <int LAYOUT, int H, bool NOQ4 = false>
 __device__ __forceinline__ void convert_pk(const Deq& c, const typename PkOf<LAYOUT>::type& k, u32x4 (&res)[4]) {
     uint32_t o[8];
     if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
@@ -529,7 +543,7 @@ __device__ __forceinline__ void convert_pk(const Deq& c, const typename PkOf<LAY
         res[1] = (u32x4){o[4], o[5], o[6], o[7]};
         if (LAYOUT == MXQ_LAYOUT_W2G16 || H == 0) {
             mxq_deq2x16(k.c[1], mxq_scale(k.qq[1][0], k.qq[1][1], (k.scw >> (4 * g0 + 4)) & 15u), __uint_as_float(k.z[1]), o);
-        } else {
+        } else if constexpr (!NOQ4) {
             mxq_deq4x8(k.c[2], c.s4, c.z4, o);
             mxq_deq4x8(k.c[3], c.s4, c.z4, o + 4);
         }
@@ -591,14 +605,14 @@ __device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const floa
         d.k0 = over ? nxt.k0 : c.k0;
         const int b0 = over ? 0 : base;
 #pragma unroll
-        for (int i = 0; i < R; ++i) load_pk<LAYOUT, H>(d, b0 + i, S[i]);
+        for (int i = 0; i < R; ++i) load_pk<LAYOUT, H, (ABL & ABL_NO_Q4) != 0>(d, b0 + i, S[i]);
     };
     auto burst = [&](int base) {               // convert the loaded group, then fetch the one after it
         if constexpr (!(ABL & ABL_NO_DEQ)) {
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 widen_pk<LAYOUT>(S[i]);
-                convert_pk<LAYOUT, H>(c, S[i], res[i]);
+                convert_pk<LAYOUT, H, (ABL & ABL_NO_Q4) != 0>(c, S[i], res[i]);
             }
         }
         load_group(base + R);
@@ -965,6 +979,9 @@ extern "C" int mxq_prof_gemm8_ablate_f16(const void* x, const void* qweight, con
         case 1024: return launch8<1024>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // correct results
         case 2048: return launch8<2048>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // correct results
         case 2050: return launch8<2050>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 16: return launch8<16>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 32: return launch8<32>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 48: return launch8<48>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
     }
     return -1;   // MXQ_E_SHAPE: not an ablation this build carries
 }
