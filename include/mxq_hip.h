@@ -190,13 +190,6 @@ int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const voi
 int mxq_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
                           int part_slots, void* token, void* stream);
 
-/* Decode-harness glue, no reference counterpart: a loads-only pass over [p, p + bytes) (p 16-byte aligned; the tail
- * bytes % 16 is skipped) that pulls the range through the memory-side Infinity Cache.  Launched on a side stream
- * under the current GEMV, it keeps the HBM streaming while that GEMV is in its arithmetic phase, and the NEXT GEMV
- * finds its weights in the cache.  `sink` (nullable) is a scratch word the kernel may write; nothing else is
- * written. */
-int mxq_prefetch(const void* p, size_t bytes, int workgroups, void* sink, void* stream);
-
 /* MXAsymQuantizer.forward (utils_quant.py:316-462; 2-D, layerwise=False branch):
  * fake-quantise w[rows, cols] of `dtype` into out (same shape/dtype), bit-identical to
  * the reference in fp32 / bf16 / fp16.  cols % 64 == 0. */
@@ -228,7 +221,8 @@ int mxq_actquant_fwd(const void* x, void* out, void* range_ws, int64_t n_seg, in
 
 /* gemv_forward_cuda(in_feats, kernel, scaling_factors, zeros, group_size)
  * (gemv_cuda.h:4-9; operand layout gemv_cuda.cu:45-59): x f16[B, IC], kernel i32[OC, IC/8],
- * scales f16[OC, sf_w], zeros i32[OC, zeros_w], group_size in {32, 64, 128}; y f16[B, OC]. */
+ * scales f16[OC, sf_w], zeros i32[OC, zeros_w], group_size in {32, 64, 128}; y f16[B, OC].
+ * x and kernel 16-byte aligned and IC % 32 == 0 (the codes are read with 16-byte loads), else MXQ_E_ALIGN / _SHAPE. */
 int mxq_gemv_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int B,
                      int IC, int OC, int group_size, void* stream);
 

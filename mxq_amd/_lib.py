@@ -56,7 +56,6 @@ SIGNATURES = {
     "mxq_gemv_f16_layout": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_gemv_fused_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "mxq_lmhead_argmax_f16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    "mxq_prefetch": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
     "mxq_attn_decode_f16": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     "mxq_fakequant_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_fakequant_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),

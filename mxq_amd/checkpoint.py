@@ -56,7 +56,8 @@ def save_packed(model: nn.Module, directory: str) -> str:
     q = quantized_modules(model)
     if not q:
         raise ValueError("model holds no QuantLinear module: nothing packed to save")
-    cfg = {"format": FORMAT, "format_version": 1,
+    # format_version: 1 = every module carries exact metadata (fmt v1); 2 = at least one module is compact (fmt v2)
+    cfg = {"format": FORMAT, "format_version": 2 if any(m.compact for m in q.values()) else 1,
            "quantized": {n: {"in_features": m.in_features, "out_features": m.out_features, "bias": m.bias is not None,
                              "metadata": "compact" if m.compact else "exact"}
                          for n, m in q.items()}}

@@ -150,13 +150,6 @@ int mxq_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const vo
     return mxq_launch_lmhead_argmax_f16(h, norm_w, eps, w, V, K, part, part_slots, token, (hipStream_t)stream);
 }
 
-int mxq_prefetch(const void* p, size_t bytes, int workgroups, void* sink, void* stream) {
-    if (!p) return MXQ_E_NULL;
-    if (((uintptr_t)p & 15) != 0) return MXQ_E_ALIGN;
-    if (workgroups <= 0 || workgroups > 65536) return MXQ_E_SHAPE;
-    return mxq_launch_prefetch(p, bytes, workgroups, sink, (hipStream_t)stream);
-}
-
 // ---- uniform layouts of the config-5 sweep ---------------------------------------------------
 static bool layout_ok(int l) {
     return l == MXQ_LAYOUT_MIXED || l == MXQ_LAYOUT_W2G16 || l == MXQ_LAYOUT_W4ROW || l == MXQ_LAYOUT_MIXEDC;
@@ -309,10 +302,12 @@ int mxq_fakequant_bwd(const void* grad_out, const void* w, void* grad_in, int64_
 int mxq_gemv_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int B,
                      int IC, int OC, int group_size, void* stream) {
     if (!x || !kernel || !scales || !zeros || !y) return MXQ_E_NULL;
-    if (B <= 0 || OC <= 0 || IC <= 0 || IC % 8 != 0) return MXQ_E_SHAPE;
+    // the code matrix is read with 16-byte loads, one group index per 32 weights: rows of IC / 8 dwords must be
+    // whole 16-byte units (IC % 32 == 0) and the matrix itself 16-byte aligned
+    if (B <= 0 || OC <= 0 || IC <= 0 || IC % 32 != 0) return MXQ_E_SHAPE;
     if (group_size != 32 && group_size != 64 && group_size != 128) return MXQ_E_SHAPE;   // gemv_cuda.cu:371-397
     if (IC % group_size != 0) return MXQ_E_SHAPE;
-    if (!aligned16(x)) return MXQ_E_ALIGN;
+    if (!aligned16(x) || !aligned16(kernel)) return MXQ_E_ALIGN;
     return mxq_launch_gemv_awq_f16(x, kernel, scales, zeros, y, B, IC, OC, group_size, (hipStream_t)stream);
 }
 

@@ -262,22 +262,6 @@ __global__ __launch_bounds__(64) void lmhead_final_kernel(const float* __restric
     if (lane == 0) *token = besti == 0x7FFFFFFF ? 0 : besti;
 }
 
-// Infinity-Cache prefetch: a loads-only pass over a byte range.  The decode GEMVs are a chain of dependent launches
-// that each spend part of their time in arithmetic with the HBM idle; a prefetch of the NEXT launches' weights, running
-// on a side stream under the current one, keeps the HBM streaming and leaves the weights in the 256 MiB memory-side
-// cache, from where the GEMV's loads return sooner.  16 bytes per lane and load, 4 loads in flight per lane.
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, size_t n16, uint32_t* sink) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t acc = 0;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-        acc ^= a.x ^ b.y ^ c.z ^ d.w;
-    }
-    for (; i < n16; i += stride) acc ^= p[i].x;
-    if (sink != nullptr && acc == 0x5bd1e995u) *sink = acc;      // keeps the loads alive; sink is a scratch word
-}
-
 }   // namespace
 
 int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
@@ -292,12 +276,6 @@ int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, c
     lmhead_argmax_kernel<<<wgs, LMH_THREADS, 0, stream>>>((const uint16_t*)h, (const uint16_t*)norm_w, eps,
                                                           (const uint16_t*)w, V, pv, pi);
     lmhead_final_kernel<<<1, 64, 0, stream>>>(pv, pi, wgs, (int64_t*)token);
-    return (int)hipGetLastError();
-}
-
-int mxq_launch_prefetch(const void* p, size_t bytes, int workgroups, void* sink, hipStream_t stream) {
-    if (bytes < 16) return 0;
-    prefetch_kernel<<<workgroups, 256, 0, stream>>>((const uint4*)p, bytes / 16, (uint32_t*)sink);
     return (int)hipGetLastError();
 }
 

@@ -35,7 +35,7 @@ int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* 
                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream);
-// skinny MFMA kernel, 1 <= M <= 32 (skinny.hip); layout MXQ_LAYOUT_MIXED or MXQ_LAYOUT_MIXEDC
+// skinny MFMA kernel, 1 <= M <= 64 (skinny.hip; the dispatch uses it for 5..48 tokens); layout MXQ_LAYOUT_MIXED or MXQ_LAYOUT_MIXEDC
 int mxq_launch_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                           int layout, hipStream_t stream);
 int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
@@ -49,7 +49,6 @@ int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* ro
                               hipStream_t stream);
 int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
                                  int part_slots, void* token, hipStream_t stream);
-int mxq_launch_prefetch(const void* p, size_t bytes, int workgroups, void* sink, hipStream_t stream);
 int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                                const void* sin_t, void* out, int heads, int head_dim, int max_ctx,
                                hipStream_t stream);

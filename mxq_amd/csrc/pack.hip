@@ -192,8 +192,15 @@ __device__ __forceinline__ void find_params16(float lo, float hi, float maxq, fl
 // 1 ulp, plus the two roundings), so t' = fl(a' + z) is within |a'| * 2^-21 + 2^-19 of t = fl(a + z) for |t| < 17
 // (two ulps of slack on the bound, one ulp of t at that magnitude), and both are first clamped to [-1, maxq + 1], where
 // nothing changes the final code.  If every value of the WAVE keeps its clamped t' farther than that from the nearest
-// rounding boundary (k + 0.5), the codes are those of the exact formula; otherwise -- ties included, and any NaN / Inf,
-// whose key compares false -- the wave takes the division.  Typical weights: 1-2 % of the wave iterations.
+// rounding boundary (k + 0.5), the codes are those of the exact formula; otherwise -- ties included -- the wave takes
+// the division.  Typical weights: 1-2 % of the wave iterations.  Non-finite input, stated exactly:
+//   * an infinite weight makes a' infinite, its key -inf: the wave takes the division;
+//   * a NaN weight has a NaN key, which v_min_f32 DROPS (it returns its non-NaN operand), so it stays on the fast
+//     path; its code is 0 there (v_med3_f32 with a NaN operand returns the minimum of the others, -1, clamped to 0)
+//     and 0 on the division path (fmaxf(NaN, 0) = 0) -- the same code either way, no other element is affected
+//     (tests: test_quantize_pack_nonfinite_and_huge_scale);
+//   * v_rcp_f32 flushes a denormal result to zero, so for sd > 2^126 a' would be 0 with a positive key: such a
+//     group is sent to the division by rcp_usable() below.
 template <int MAXQ>
 __device__ __forceinline__ float quant_key(float x, float r, float z, float& q) {
     const float a = x * r;
@@ -206,6 +213,8 @@ template <int MAXQ>
 __device__ __forceinline__ float quant_exact(float x, float sd, float z) {
     return fminf(fmaxf(rintf(x / sd + z), 0.0f), (float)MAXQ);
 }
+// false when 1 / sd is not a normal number (sd > 2^126, or sd NaN): the reciprocal was flushed and proves nothing
+__device__ __forceinline__ bool rcp_usable(float r) { return r >= 0x1p-126f; }
 __device__ __forceinline__ uint32_t quant2x16(const float (&v)[16], float sd, float z) {
     const float r = __builtin_amdgcn_rcpf(sd);
     float key = INFINITY;
@@ -216,7 +225,7 @@ __device__ __forceinline__ uint32_t quant2x16(const float (&v)[16], float sd, fl
         key = fminf(key, quant_key<3>(v[j], r, z, q));
         word |= (uint32_t)q << mxq_bit2(j);
     }
-    if (__any(!(key > 0.0f))) {
+    if (__any(!(key > 0.0f) || !rcp_usable(r))) {
         word = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) word |= (uint32_t)quant_exact<3>(v[j], sd, z) << mxq_bit2(j);
@@ -236,7 +245,7 @@ __device__ __forceinline__ void quant4x16(const float (&v)[16], float sd, float 
         w0 |= (uint32_t)q0 << mxq_bit4(j);
         w1 |= (uint32_t)q1 << mxq_bit4(j);
     }
-    if (__any(!(key > 0.0f))) {
+    if (__any(!(key > 0.0f) || !rcp_usable(r))) {
         w0 = 0;
         w1 = 0;
 #pragma unroll

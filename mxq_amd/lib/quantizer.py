@@ -11,8 +11,9 @@ quantise-and-pack kernel on the given slice (``mxq_quantize_pack_layout``: per-r
 zero-point, 4-bit second-order scale coding over 16 consecutive rows -- quantizer.py:81-121) followed by the
 integer unpack; ``scale`` / ``zero`` / ``quant_scale`` / ``qq_scale.scale`` / ``qq_scale.zero`` / ``maxq`` then
 hold exactly the reference's values.  ``quantize(x)`` / ``quantize_dequantize(x)`` on the tensor the parameters
-were found on return the kernel's codes / dequantised values; on any OTHER tensor they apply the stored
-parameters with the reference's formula (quantizer.py:5-20) as elementwise device ops.  GPU only, like
+were found on (held alive by the object, so a recycled address can never pass for it) return the kernel's codes /
+dequantised values; on any OTHER tensor they apply the stored parameters with the reference's formula
+(quantizer.py:5-20) as elementwise torch device ops -- GPU arithmetic, but not the HIP kernel.  GPU only, like
 everything in this package; unsupported configurations raise instead of approximating.
 
 ``GroupView`` is the read-only view over one group of an already packed weight that ``MXQGPT.quantizer(chunk,
@@ -39,7 +40,8 @@ class Quantizer:
         self.scale = torch.zeros(shape)
         self.zero = torch.zeros(shape)
         self.bits = None
-        self._src = None        # (data_ptr, shape, version) of the tensor find_params ran on
+        self._src = None        # identity of the tensor find_params ran on (see _src_key)
+        self._src_ref = None    # ... and the tensor itself: while it is held its memory cannot be recycled
         self._codes = None
         self._deq = None
 
@@ -94,10 +96,19 @@ class Quantizer:
         self.maxq = self.maxq.to(x.device)
         self._codes = got["codes"][:, take].float()
         self._deq = w16[:, take].float()                            # fp16(scale * (q - zero)): exact in fp32
-        self._src = (x.data_ptr(), tuple(x.shape), x._version, x.dtype)
+        self._src = self._src_key(x)
+        self._src_ref = x       # keeps the storage alive: a freed temporary's address would otherwise be handed to the
+                                # next same-shape temporary (version 0, same dtype, other data) and match by accident
+
+    @staticmethod
+    def _src_key(x):
+        return (x.untyped_storage().data_ptr(), x.storage_offset(), tuple(x.shape), tuple(x.stride()), x.dtype,
+                x._version)
 
     def _is_source(self, x) -> bool:
-        return self._src is not None and (x.data_ptr(), tuple(x.shape), x._version, x.dtype) == self._src
+        """True only for the very tensor (or an identical view of the very storage, unmodified since) that
+        ``find_params`` ran on; that tensor is held in ``_src_ref``, so the comparison cannot alias a recycled block."""
+        return self._src_ref is not None and self._src_key(x) == self._src
 
     def quantize(self, x):
         if not self.ready():

@@ -93,6 +93,9 @@ def test_argument_validation_rejects_before_any_launch(lib):
     assert lib.mxq_actquant_fwd(P, P, P, 4, 250, 1, 1, 8, 1, 2, None) == E_SHAPE
     # the reference extension's formats
     assert lib.mxq_gemv_awq_f16(P, P, P, P, P, 1, 4096, 4096, 48, None) == E_SHAPE    # group size
+    assert lib.mxq_gemv_awq_f16(P, Q, P, P, P, 1, 4096, 4096, 128, None) == E_ALIGN   # codes are read 16 bytes at a time
+    assert lib.mxq_gemv_awq_f16(P, P, P, P, P, 1, 4104, 4096, 8, None) == E_SHAPE     # IC % 32 (rows of whole 16-B units)
+    assert not hasattr(lib, "mxq_prefetch")                                           # round-2 experiment: a record, not ABI
     assert lib.mxq_gemv_proto_f16(P, P, P, P, P, P, P, P, P, 1, 2048, 4096, 16, None) == E_SHAPE   # IC must be 4096
     assert lib.mxq_gemm_workspace_bytes() == 64 * 1024 + 256 * 2 * 256 * 128 * 4 or lib.mxq_gemm_workspace_bytes() > 64 * 1024
 

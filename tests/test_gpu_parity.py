@@ -179,6 +179,38 @@ def test_quantize_pack_division_screen_adversarial(dev, dt):
             assert np.array_equal(gotu[k].cpu().numpy().reshape(refu[k].shape), refu[k]), (layout, k)
 
 
+def test_quantize_pack_nonfinite_and_huge_scale(dev):
+    """ADVICE r2 on the division screen (csrc/pack.hip): (a) scales beyond 2^126, where v_rcp_f32 flushes its result
+    to zero, must still give the oracle's codes (such groups are sent to the IEEE division); (b) a NaN weight gets
+    code 0 and leaves every other code and parameter of the tensor untouched (min / max ignore it, its key is dropped
+    by v_min_f32: the fast path and the division path agree on 0)."""
+    from mxq_amd import packing
+    g = torch.Generator().manual_seed(11)
+    W = torch.randn(32, 128, generator=g) * 0.02
+    W[:16] = (torch.rand(16, 128, generator=g) - 0.5) * 3.2e38          # s0 = range / 3 ~ 1e38 > 2^126
+    f = (0.85 + 0.01 * torch.arange(16.0))                              # the rows' ranges differ: the 4-bit coded scale
+    W[:16, :16] *= f[:, None] * 0.99                                    # of group 0 stays ~1e38 > 2^126 (equal ranges
+    W[:16, 0] = -1.6e38 * f                                             # would collapse it to 1.0, quantizer.py:90-92)
+    W[:16, 1] = 1.6e38 * f
+    ref = O.mxq_quantize(W.numpy())
+    s_grp0 = ref["qs2"][0, 0] * (ref["sc2"][:16, 0].astype(np.float32) - ref["qz2"][0, 0])
+    assert (s_grp0 > 2.0 ** 126).all()                                  # the case the test is about
+    got = packing.unpack(packing.quantize_pack(W.to(dev)))
+    for k in KEYS:
+        assert np.array_equal(got[k].cpu().numpy(), ref[k]), k
+    Wn = torch.randn(32, 128, generator=g) * 0.02
+    Wn[21, 3] = Wn[21, 4]                                               # a duplicate: removing it changes no statistic
+    base = packing.unpack(packing.quantize_pack(Wn.to(dev)))
+    Wn[21, 3] = float("nan")
+    nan = packing.unpack(packing.quantize_pack(Wn.to(dev)))
+    assert int(nan["codes2"][21, 3]) == 0
+    for k in KEYS:
+        a, b = base[k].clone(), nan[k].clone()
+        if k == "codes2":
+            a[21, 3] = b[21, 3] = 0
+        assert torch.equal(a, b), k
+
+
 def test_mxqgpt_driver_api(dev, g1):
     """MXQGPT(layer).add_batch / fasterquant / free as nas_quant calls them (prune.py:385-414)."""
     from mxq_amd.lib.mxqgpt import MXQGPT
@@ -249,6 +281,35 @@ def test_quantizer_reference_api_g8(dev):
         Quantizer().configure(bits=2, perchannel=True, sym=True, qq_scale_bits=4)
     with pytest.raises(ValueError):
         q.find_params(Wf.cpu(), weight=True)
+
+
+def test_quantizer_source_cache_survives_recycled_address(dev):
+    """find_params on a temporary that is freed, then quantize() of ANOTHER temporary of the same shape
+    (the caching allocator hands out the same address, version 0, same dtype) must apply the formula to the tensor
+    passed in (quantizer.py:5-20), never return the first tensor's cached codes."""
+    from mxq_amd.lib.quantizer import Quantizer
+    g = torch.Generator().manual_seed(5)
+    A = (torch.randn(64, 16, generator=g) * 0.02).to(dev)
+    B = (torch.randn(64, 16, generator=g) * 0.05).to(dev)
+    q = Quantizer()
+    q.configure(bits=2, perchannel=True, sym=False, qq_scale_bits=4)
+    tmp = A.clone()
+    addr = tmp.data_ptr()
+    q.find_params(tmp, weight=True)
+    codes_a = q.quantize(tmp).clone()
+    del tmp
+    for _ in range(4):                       # without the held reference the very next clone reuses A's block
+        other = B.clone()
+        want = torch.clamp(torch.round(other / q.scale.clamp_min(1e-9) + q.zero), 0, 3)
+        assert torch.equal(q.quantize(other), want)
+        assert other.data_ptr() != addr      # the source is held alive by the Quantizer
+        del other
+    assert not torch.equal(codes_a, want)    # (the two data sets really differ)
+    # an identical view of the held source still hits the kernel's codes; a modified source does not
+    src = q._src_ref
+    assert torch.equal(q.quantize(src[:]), codes_a)
+    src.mul_(1.5)
+    assert torch.equal(q.quantize(src), torch.clamp(torch.round(src / q.scale.clamp_min(1e-9) + q.zero), 0, 3))
 
 
 def test_quantizer_reproduces_fasterquant_loop_g1(dev, g1):
