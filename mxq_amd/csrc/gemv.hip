@@ -39,6 +39,12 @@
 
 namespace {
 
+// cache policy of the WEIGHT loads (raw_buffer_load aux bits: 2 = nt).  The weights of a decode GEMV are read once,
+// by one CU each; x, rowmeta and everything re-read stay on the default policy.  A/B: profiles/r03_gemv_nt_ab.txt
+#ifndef MXQ_GEMV_WAUX
+#define MXQ_GEMV_WAUX 0
+#endif
+
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     auto load_tile = [&](int c4) {                      // c4 >= NC4 or a chunk >= NC: out of range = zeros, no traffic
         Tile t = {};
         const int so = c4 * (4 * BLK_DW * 4);           // wave-uniform
-        auto dw = [&](int idx) { return __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off + idx * 4, so, 0); };
+        auto dw = [&](int idx) { return __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off + idx * 4, so, MXQ_GEMV_WAUX); };
         if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) t.c4w[i] = dw(mxq_w4_c4(i >> 1, i & 1, r));
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
             for (int g = 0; g < NG2; ++g) {
                 t.c2w[g] = dw(MIXED ? mxq_c2(g, r) : mxq_w2_c2(g, r));
                 if constexpr (COMPACT)                  // fp16 zero-point (widened where it is used)
-                    t.z2w[g] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane_off + mxqc_z2_u16(g, r) * 2, so, 0);
+                    t.z2w[g] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane_off + mxqc_z2_u16(g, r) * 2, so, MXQ_GEMV_WAUX);
                 else
                     t.z2w[g] = dw(MIXED ? mxq_z2(g, r) : mxq_w2_z2(g, r));
                 const int q = COMPACT ? mxqc_qq(g) : mxq_qq(g);     // SC / QQ: same offsets in v1 and W2G16
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
                 t.c4w[0] = dw(mxq_c4(0, r));
                 t.c4w[1] = dw(mxq_c4(1, r));
             }
-            t.scw = __builtin_amdgcn_raw_buffer_load_b16(rs, lane_off + (COMPACT ? mxqc_sc_u16(r) : mxq_sc_u16(r)) * 2, so, 0);
+            t.scw = __builtin_amdgcn_raw_buffer_load_b16(rs, lane_off + (COMPACT ? mxqc_sc_u16(r) : mxq_sc_u16(r)) * 2, so, MXQ_GEMV_WAUX);
         }
         return t;
     };

@@ -33,6 +33,18 @@ import torch
 import torch.distributed as dist
 
 
+class _StagedRecv:
+    """irecv of a device tensor over a backend that only moves host memory (gloo): the transfer lands in a host
+    buffer and ``wait`` copies it onto the device (stream-ordered), so the caller sees the same contract as RCCL's."""
+
+    def __init__(self, work, host, dst):
+        self.work, self.host, self.dst = work, host, dst
+
+    def wait(self):
+        self.work.wait()
+        self.dst.copy_(self.host)
+
+
 def layer_range(rank: int, world: int, n_layers: int) -> range:
     """Layers owned by ``rank``: contiguous, sizes differ by at most one."""
     return range(n_layers * rank // world, n_layers * (rank + 1) // world)
@@ -58,6 +70,36 @@ class LayerPipeline:
             return group_rank
         return dist.get_global_rank(self.group, group_rank)
 
+    # -- transport --------------------------------------------------------------------------------
+    # RCCL ("nccl") takes device tensors and orders the transfer against the current stream.  gloo moves HOST memory:
+    # handed a device tensor it reads / writes the raw pointer from the CPU with no stream ordering at all (on this
+    # platform device memory is host-visible, so nothing fails -- the peer just receives stale bytes: found by the
+    # world-2 decode rehearsal of round 3, profiles/r03_decode_world2_rehearsal.log).  Device tensors over gloo are
+    # therefore staged through host memory here: .cpu() synchronises with the producing stream, copy_() back is
+    # stream-ordered.  CPU tensors (the gloo unit tests) and RCCL go straight through.
+    def _staged(self, t: torch.Tensor) -> bool:
+        return t.is_cuda and dist.get_backend(self.group) != "nccl"
+
+    def _send(self, t: torch.Tensor, dst: int) -> None:
+        dist.send(t.cpu() if self._staged(t) else t, dst=dst, group=self.group)
+
+    def _recv(self, t: torch.Tensor, src: int) -> None:
+        if self._staged(t):
+            host = torch.empty(t.shape, dtype=t.dtype)
+            dist.recv(host, src=src, group=self.group)
+            t.copy_(host)
+        else:
+            dist.recv(t, src=src, group=self.group)
+
+    def _isend(self, t: torch.Tensor, dst: int):
+        return dist.isend(t.cpu() if self._staged(t) else t, dst=dst, group=self.group)
+
+    def _irecv(self, t: torch.Tensor, src: int):
+        if self._staged(t):
+            host = torch.empty(t.shape, dtype=t.dtype)
+            return _StagedRecv(dist.irecv(host, src=src, group=self.group), host, t)
+        return dist.irecv(t, src=src, group=self.group)
+
     @property
     def is_first(self) -> bool:
         return self.rank == 0
@@ -70,13 +112,13 @@ class LayerPipeline:
     def recv_hidden(self, buf: torch.Tensor) -> torch.Tensor:
         """Receive the previous stage's output into ``buf`` (no-op on the first stage)."""
         if self.world > 1 and not self.is_first:
-            dist.recv(buf, src=self._peer(self.rank - 1), group=self.group)
+            self._recv(buf, self._peer(self.rank - 1))
         return buf
 
     def send_hidden(self, h: torch.Tensor) -> None:
         """Send this stage's output to the next stage (no-op on the last stage)."""
         if self.world > 1 and not self.is_last:
-            dist.send(h.contiguous(), dst=self._peer(self.rank + 1), group=self.group)
+            self._send(h.contiguous(), self._peer(self.rank + 1))
 
     # -- prefill-style streaming of micro-batches -------------------------------------------------
     def run_microbatches(self, stage_fn: Callable[[torch.Tensor], torch.Tensor], inputs: List[torch.Tensor],
@@ -101,11 +143,11 @@ class LayerPipeline:
         src = self._peer(self.rank - 1) if not self.is_first else None
         dst = self._peer(self.rank + 1) if not self.is_last else None
         if not self.is_first and n:
-            rwork[0] = dist.irecv(rbuf[0], src=src, group=self.group)
+            rwork[0] = self._irecv(rbuf[0], src)
         for b in range(n):
             if not self.is_first:
                 if b + 1 < n:                   # slot (b+1) % 2 last held micro-batch b-1, consumed by stage_fn(b-1)
-                    rwork[(b + 1) % 2] = dist.irecv(rbuf[(b + 1) % 2], src=src, group=self.group)
+                    rwork[(b + 1) % 2] = self._irecv(rbuf[(b + 1) % 2], src)
                 rwork[b % 2].wait()
                 x = rbuf[b % 2]
             else:
@@ -118,7 +160,7 @@ class LayerPipeline:
                 if sbuf[s] is None:
                     sbuf[s] = torch.empty_like(h, memory_format=torch.contiguous_format)
                 sbuf[s].copy_(h)
-                swork[s] = dist.isend(sbuf[s], dst=dst, group=self.group)
+                swork[s] = self._isend(sbuf[s], dst)
             elif collect:
                 outs.append(h.clone() if (rbuf is not None and any(h is r for r in rbuf)) else h)
         for w in swork:
@@ -149,11 +191,11 @@ class LayerPipeline:
             if self.is_last:
                 token_buf.copy_(head_fn(h).reshape(-1)[:1])
                 if self.world > 1:
-                    dist.send(token_buf, dst=self._peer(0), group=self.group)
+                    self._send(token_buf, self._peer(0))
             else:
                 self.send_hidden(h)
                 if self.is_first:
-                    dist.recv(token_buf, src=self._peer(self.world - 1), group=self.group)
+                    self._recv(token_buf, self._peer(self.world - 1))
             if keeps:
                 generated[step:step + 1].copy_(token_buf)     # stays on the device: no host sync per token
         return generated.tolist()

@@ -84,7 +84,7 @@ def main():
     toks = run(args.tokens)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    bytes_tok = torch.tensor([stage.packed_bytes()], device=dev, dtype=torch.float64)
+    bytes_tok = torch.tensor([stage.packed_bytes()], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(bytes_tok)
     verified = None
