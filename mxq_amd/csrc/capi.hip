@@ -215,11 +215,18 @@ int mxq_linear_f16_hoisted(const void* x, const void* qweight, const void* rowme
     return mxq_launch_gemm8_dense_f16(x, w16_scratch, y, M, N, K, (hipStream_t)stream);
 }
 
+// Token counts served by the mid-M split-K kernel (midm.hip): above the skinny kernel's range, below the point
+// where the prefill kernel's 256 x 128 tiles win again -- from 256 tokens on at every Llama shape
+// (tools/midm_bench.py, profiles/r03_midM.txt)
+static const int MIDM_MAX_TOKENS = 192;
+
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
     if (M <= 48) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
+    if (M <= 256)   // no workspace: the mid-M kernel without its K split (one slice per tile)
+        return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, nullptr, 0, 0, 0, (hipStream_t)stream);
     return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
 }
 
@@ -240,6 +247,9 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
     if (M <= 48) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
+    if (M <= MIDM_MAX_TOKENS && workspace)
+        return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
+                                   (hipStream_t)stream);
     return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -249,6 +259,9 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
     if (variant == 0) return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
     if (variant == 1) return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+    if (variant == 10)   // the mid-M split-K kernel at any token count (tests, tools)
+        return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
+                                   (hipStream_t)stream);
     if (variant == 8 || variant == 9)
         return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 9,
                                     (hipStream_t)stream);

@@ -38,6 +38,10 @@ int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta,
 // skinny MFMA kernel, 1 <= M <= 64 (skinny.hip; the dispatch uses it for 5..48 tokens); layout MXQ_LAYOUT_MIXED or MXQ_LAYOUT_MIXEDC
 int mxq_launch_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                           int layout, hipStream_t stream);
+// mid-size token counts (48 < M <= ~1024): split-K over workgroups + combine (midm.hip); layout MXQ_LAYOUT_MIXED / MIXEDC;
+// workspace nullable (no split then); bm 0 | 64 | 128, splits 0 = automatic
+int mxq_launch_midm_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
+                        void* workspace, size_t ws_bytes, int bm, int splits, hipStream_t stream);
 int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
                                int K, int layout, hipStream_t stream);
 int mxq_launch_quantize_uniform(const void* W, int dtype, void* qweight, void* rowmeta, int N, int K, int layout,

@@ -30,28 +30,45 @@ def _stream(t: torch.Tensor) -> int:
 
 
 _WORKSPACES: Dict[tuple, torch.Tensor] = {}
+_WS_EAGER: Dict[tuple, bool] = {}    # key -> the buffer was created AND zeroed outside any graph capture
 _WS_HEAD = 65536      # bytes of K-step counters at the head of a workspace (include/mxq_hip.h)
+MIDM_MAX_TOKENS = 192     # capi.hip: token counts that mxq_linear_f16_ws hands to the mid-M split-K kernel (no counters)
 
 
-def gemm_workspace(device: torch.device) -> torch.Tensor:
-    """Scratch buffer of the stream-K prefill GEMM (include/mxq_hip.h: mxq_linear_f16_ws), one per
-    (device, stream): launches on one stream run in order and may share it, launches on different
-    streams may not.  Its counter head must be zero when a launch starts; the kernels leave it zeroed.
+def gemm_workspace(device: torch.device, counters: bool = True) -> torch.Tensor:
+    """Scratch buffer of the stream-K prefill GEMM and of the mid-M kernel's partial tiles (include/mxq_hip.h:
+    mxq_linear_f16_ws), one per (device, stream): launches on one stream run in order and may share it, launches on
+    different streams may not.  Its counter head must be zero when a stream-K launch starts; the kernels leave it
+    zeroed.
 
-    Eager use: the head is zeroed once, when the buffer is created.  Under hipGraph capture the buffer handed out
-    (new or cached -- torch's capture stream keeps its handle across captures) gets a captured memset in front of
-    EVERY captured launch: a buffer first created under capture has never been zeroed for real until a replay
-    runs, and an earlier capture's memset belongs to a graph that may never be replayed.  Graphs captured on the
-    same capture stream share this buffer: replay them one at a time (or capture on distinct streams)."""
-    stream = torch.cuda.current_stream(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream)
-    ws = _WORKSPACES.get(key)
+    A buffer created in eager mode is zeroed once, then and there, and needs nothing more: every launch (eager or
+    replayed from a graph) finds the counters as the previous one left them -- zero.  A buffer FIRST created under
+    hipGraph capture has never been zeroed for real until a replay runs, and an earlier capture's memset belongs to a
+    graph that may never be replayed: such a buffer gets a captured memset in front of EVERY captured launch that uses
+    the counters (4.5 us per launch in the graph: round 3 found it inside every graph-replay timing of round 2).  So
+    the buffer that captured launches use is created and zeroed together with the first EAGER buffer of the device:
+    run one eager ``linear`` (or ``gemm_workspace(device)``) before capturing, as every tool here does, and no memset
+    is captured.  All graphs of a device share that buffer: replay them one at a time.
+
+    ``counters=False``: the caller's kernel uses the buffer beyond the head only (the mid-M kernel's partial tiles):
+    no memset is ever captured for it."""
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
     capturing = torch.cuda.is_current_stream_capturing()
+    # captured launches share ONE buffer per device (torch captures on a side stream of its own, so a per-stream key
+    # would always be born under capture); it is created and zeroed EAGERLY, together with the first eager buffer
+    key = (dev_index, "capture") if capturing else (dev_index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
     if ws is None:
         nbytes = _lib.load().mxq_gemm_workspace_bytes()
         ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
         ws[:_WS_HEAD].zero_()
-    elif capturing:
+        _WS_EAGER[key] = not capturing
+        ckey = (dev_index, "capture")
+        if not capturing and ckey not in _WORKSPACES:
+            cws = _WORKSPACES[ckey] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            cws[:_WS_HEAD].zero_()
+            _WS_EAGER[ckey] = True
+    elif capturing and counters and not _WS_EAGER.get(key, False):
         ws[:_WS_HEAD].zero_()
     return ws
 
@@ -107,6 +124,7 @@ def reset_gemm_workspace(device: Optional[torch.device] = None):
             torch.cuda.synchronize(dev_index)
             ws[:_WS_HEAD].zero_()
             torch.cuda.synchronize(dev_index)
+            _WS_EAGER[(dev_index, _stream)] = True
 
 
 def _need_gpu(*ts: torch.Tensor):
@@ -258,7 +276,7 @@ def dequant(p: PackedMXQ) -> torch.Tensor:
     return out
 
 
-GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
+GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
 
 
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
@@ -305,7 +323,9 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         elif path == "auto" and M <= 4:                          # GEMV: no workspace involved
             rc = lib.mxq_linear_f16(*args, _stream(x2))
         else:
-            ws = gemm_workspace(x2.device) if path in ("auto", "gemm", "fused", "gemm8", "gemm9") else None
+            midm = path == "midm" or (path == "auto" and M <= MIDM_MAX_TOKENS)
+            ws = (gemm_workspace(x2.device, counters=not midm)
+                  if path in ("auto", "gemm", "fused", "gemm8", "gemm9", "midm") else None)
             wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
             if path == "auto":
                 rc = lib.mxq_linear_f16_ws(*args, wsp, wsn, _stream(x2))

@@ -342,7 +342,7 @@ def test_quantizer_reproduces_fasterquant_loop_g1(dev, g1):
 # ----------------------------------------------------------------------------------------
 # dequant-GEMM / GEMV
 # ----------------------------------------------------------------------------------------
-GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9"]      # packing.GEMM_PATHS: every kernel the product library ships
+GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm"]      # packing.GEMM_PATHS: every kernel the product library ships
 
 
 def _packed_case(dev, N, K, seed):
@@ -467,6 +467,22 @@ def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):
     assert all(torch.equal(o, ref) for lst in outs for o in lst)
     keys = {k for k in packing._WORKSPACES if k[0] == x.device.index}
     assert len(keys) >= 3                                          # default stream + two side streams
+    # the buffer captured launches use was created and zeroed eagerly (together with the first eager one): nothing
+    # but the GEMM is captured.  One that is BORN under capture gets a captured memset in front of every launch.
+    ckey = (x.device.index, "capture")
+    assert packing._WS_EAGER[ckey]
+    packing._WORKSPACES.pop(ckey)
+    packing._WS_EAGER.pop(ckey)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        packing.linear(x, p, out=out, path="gemm9")
+    assert not packing._WS_EAGER[ckey]
+    packing._WORKSPACES[ckey][:65536].fill_(7)                     # whatever the buffer holds before the first replay
+    for _ in range(2):
+        out.zero_()
+        g2.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
 
 
 def test_linear_empty_and_nonfinite_inputs(dev):
@@ -638,6 +654,28 @@ def test_skinny_integer_exact_and_nonfinite(dev):
     assert torch.isnan(y[3]).all() and torch.isfinite(y[[i for i in range(M) if i != 3]]).all()
     with pytest.raises(ValueError):
         packing.linear(torch.zeros(65, K, dtype=torch.float16, device=dev), pk, path="skinny")
+
+
+@pytest.mark.parametrize("M", [49, 64, 100, 128, 200, 256, 512, 1000])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008), (208, 2176), (4096, 192)])
+def test_midm_split_k_llama_shapes(dev, M, N, K):
+    """The mid-M split-K kernel (csrc/midm.hip; reference analogue: the split_k_iters launcher,
+    gemm_cuda_gen.cu:429-475) at the Llama shapes and token counts it serves -- one and two token tiles, ragged M,
+    K slices of equal and unequal length (172 chunks), a ragged last channel tile (N = 208), an odd chunk count
+    (K = 192: the second chunk of the last double-step lies beyond K) -- against the fp32 product on the bit-exact
+    dequant kernel's weight, and the automatic dispatch against the same."""
+    from mxq_amd import packing
+    g = torch.Generator(device="cpu").manual_seed(N + K + M)
+    p = packing.quantize_pack((torch.randn(N, K, generator=g) * 0.02).half().to(dev))
+    wd = packing.dequant(p).float()
+    x = torch.randn(M, K, generator=g).half().to(dev)
+    yref = x.float() @ wd.t()
+    for path in ("midm", "auto"):
+        y = packing.linear(x, p, path=path).float()
+        assert ((y - yref).abs().max() / yref.abs().max()).item() <= REL_TOL, path
+        assert ((y - yref).norm() / yref.norm()).item() <= REL_TOL, path
+    # deterministic: the slabs are summed in slice order, whatever the arrival order
+    assert torch.equal(packing.linear(x, p, path="midm"), packing.linear(x, p, path="midm"))
 
 
 @pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])

@@ -10,6 +10,7 @@ between launches), median of 5 replays.
     python tools/midm_bench.py [--ms 64,128,256,512,1024] [--paths auto,midm,gemm8,skinny] [--json out.json]
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -41,6 +42,24 @@ def timed(fn_for_copy, n_copies, reps=5):
     return sorted(ts)[len(ts) // 2]
 
 
+_LIBS = {}
+
+
+def lib_linear(path, x, p, out, variant=10):
+    """The quantised Linear through ANOTHER build of libmxq_hip.so (path "lib:<repo-relative .so>[:variant]"; variant
+    of mxq_gemm_f16_ws, default 10 = the mid-M kernel): same-process A/B of builds (tools/build_variant.sh)."""
+    lib = _LIBS.get(path)
+    if lib is None:
+        lib = _LIBS[path] = ctypes.CDLL(os.path.join(ROOT, path))
+        lib.mxq_gemm_f16_ws.restype = ctypes.c_int
+        lib.mxq_gemm_f16_ws.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_size_t,
+                                                                                    ctypes.c_void_p]
+    ws = packing.gemm_workspace(x.device, counters=variant != 10)
+    rc = lib.mxq_gemm_f16_ws(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), x.shape[0], p.N, p.K,
+                             variant, ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream)
+    assert rc == 0, rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ms", default="64,128,256,512,1024")
@@ -67,6 +86,14 @@ def main():
                 if path == "skinny" and M > 64:
                     continue
                 try:
+                    if path.startswith("lib:"):
+                        so, _, var = path[4:].partition(":")
+                        call = lambda i: lib_linear(so, x, ws[i], out, int(var or 10))
+                        call(0)
+                        err = ((out.float() - x.float() @ w16.float().t()).abs().max() / (x.float() @ w16.float().t()).abs().max()).item()
+                        assert err <= 1e-3 or "abl" in so, (path, err)          # (ablation builds are wrong by construction)
+                        row[path] = round(timed(call, nw), 2)
+                        continue
                     row[path] = round(timed(lambda i: packing.linear(x, ws[i], out=out, path=path), nw), 2)
                 except ValueError as e:       # a path this build does not have
                     row[path] = None
