@@ -57,18 +57,37 @@ def build_layers(layers, dev):
     return out
 
 
-def cpu_baseline(dev, budget_s=12.0):
-    """Config 1 of BASELINE.json on the host cores: one [4096, 4096] MXQ Linear, batch 1 x
-    seq 128 -> dequant (fp32 scale*(q-zero), fp16 cast) + F.linear per call."""
-    from oracle import cpu_linear
-    # Thread pool = the cores this process may actually run on (its affinity mask; the 1-GPU box gives the job a
-    # 16-core share of a 256-CPU host), capped at 16: more torch threads than cores only thrash, and a pool sized
-    # from os.cpu_count() made the round-1 number box-dependent.
+def host_cores():
+    """Cores this process may really use: its affinity mask, cut by the cgroup CPU quota where one is set (the 1-GPU
+    box gives the job a share of a 256-CPU host: the mask says 256, the quota what it gets), capped at 16."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(16, cores)))
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, q // period)
+        except (OSError, ValueError):
+            pass
+    return cores, quota, max(1, min(16, cores, quota or cores))
+
+
+def cpu_baseline(dev, budget_s=12.0):
+    """Config 1 of BASELINE.json on the host cores: one [4096, 4096] MXQ Linear, batch 1 x
+    seq 128 -> dequant (fp32 scale*(q-zero), fp16 cast) + F.linear per call; and, next to it, the GPU's own time
+    for the same call on the same inputs ("the CPU number next to the GPU kernel ... with
+    the speed-up"), measured with HIP events after the headline region."""
+    from oracle import cpu_linear
+    cores, quota, threads = host_cores()
+    torch.set_num_threads(threads)
     N = K = 4096
     M = 128
     g = torch.Generator(device=dev).manual_seed(0)
@@ -76,10 +95,25 @@ def cpu_baseline(dev, budget_s=12.0):
     p = packing.quantize_pack(W)
     params = {k: v.cpu() for k, v in packing.unpack(p).items()}
     x = torch.randn(M, K, generator=torch.Generator().manual_seed(7)).half()
-    y_gpu = packing.linear(x.to(dev), p, path="gemm").float().cpu()
+    xd = x.to(dev)
+    y_gpu = packing.linear(xd, p).float().cpu()               # the product dispatch for 128 tokens
     for _ in range(2):
         y = cpu_linear.dequant_linear(params, N, K, x)
     rel = ((y - y_gpu).abs().max() / y.abs().max()).item()
+    # GPU: 200 stream-ordered calls between two HIP events on the launch stream (weights re-read every call; 9.4 MB
+    # stay in the Infinity Cache between calls, as they would between the tokens of a real prefill chunk)
+    out = torch.empty(M, N, device=dev, dtype=torch.float16)
+    for _ in range(20):
+        packing.linear(xd, p, out=out)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 200
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        packing.linear(xd, p, out=out)
+    ev1.record()
+    torch.cuda.synchronize()
+    gpu_ms = ev0.elapsed_time(ev1) / reps
     times = []
     t_end = time.perf_counter() + budget_s
     while time.perf_counter() < t_end and len(times) < 200:
@@ -88,12 +122,17 @@ def cpu_baseline(dev, budget_s=12.0):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(2.0 * M * N * K / med / 1e12, 5), "unit": "TFLOP/s", "cores": torch.get_num_threads(),
-            "affinity_cpus": cores,
+    flop = 2.0 * M * N * K
+    return {"value": round(flop / med / 1e12, 5), "unit": "TFLOP/s", "cores": torch.get_num_threads(),
+            "affinity_cpus": cores, "cgroup_cpu_quota": quota,
             "kind": "port", "tokens_per_s": round(M / med, 1), "ms_per_call": round(med * 1e3, 3),
             "iters": len(times), "host_cpus": os.cpu_count(), "gpu_vs_cpu_max_rel_err": rel,
+            "gpu_ms_per_call": round(gpu_ms, 5), "gpu_TFLOPs": round(flop / (gpu_ms * 1e-3) / 1e12, 2),
+            "gpu_speedup": round(med * 1e3 / gpu_ms, 1),
+            "gpu_kernel": "mid-M split-K kernel + combine (mxq_linear_f16_ws dispatch at 128 tokens), stream-ordered "
+                          "launches, HIP events",
             "sample": "config 1: one 4096x4096 MXQ Linear, M=128 tokens, dequant(fp32)+F.linear per call "
-                      "(4.295 GFLOP), median of the calls that fit ~12 s"}
+                      "(4.295 GFLOP), median of the calls that fit ~12 s; the GPU runs the same call on the same inputs"}
 
 
 def main():
@@ -198,8 +237,9 @@ def main():
     achieved = flops_rank_step / (dev_ms / args.steps * 1e-3) / 1e12
 
     traffic = None       # HBM bytes per launch from rocprofv3 PMC counters (collected offline, see the file)
-    tpath = os.path.join(ROOT, "profiles", "r02_gemm8_traffic.json")
-    if world == 1 and os.path.exists(tpath):
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm8_traffic.json") for r in (3, 2))
+                  if os.path.exists(q)), "")
+    if world == 1 and tpath:
         traffic = json.load(open(tpath))["avg_hbm_bytes_per_launch"]
     if rank == 0:
         bpw = sum(p.nbytes() for lin in layers for _, p in lin) * 8.0 / (LS.PARAMS_PER_LAYER * len(my_layers))

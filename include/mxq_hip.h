@@ -107,7 +107,8 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * the Llama shapes, not for gate/up at M = 2048).
  * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 8 = the
  * 256x128-tile kernel (MFMA waves stream x, dedicated waves dequantise, persistent over tiles, stream-K tail;
- * csrc/gemm8.hip) at any M, 9 = the same but splitting its tail whenever that is structurally possible (tests);
+ * csrc/gemm8.hip) at any M, 9 = the same but splitting its tail whenever that is structurally possible (tests),
+ * 10 = the mid-M split-K kernel (csrc/midm.hip) at any M;
  * anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
  * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
  * used by tools/ alone: they are not part of this ABI.) */
@@ -116,6 +117,14 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
                       void* workspace, size_t workspace_bytes, void* stream);
 int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* workspace, size_t workspace_bytes, void* stream);
+/* mxq_linear_f16_ws for a weight in any layout (MXQ_LAYOUT_*: mixed with exact or compact metadata, W2G16, W4ROW).
+ * Dispatch by token count: <= 4 the streaming GEMV, 5..48 the skinny MFMA kernel and 49..192 the mid-M split-K
+ * kernel (csrc/midm.hip: K cut into slices over the workgroups, fp32 partial tiles in the workspace beyond its first
+ * 64 KiB, summed in slice order by a second launch -- the reference launcher's split_k_iters regime,
+ * gemm_cuda_gen.cu:429-475) for the mixed layouts, the prefill kernel otherwise.  The mid-M kernel does not touch
+ * the workspace's counters. */
+int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                             int layout, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Hoisted-dequant mode of the same Linear, for launches that cover many token tiles (batch x seq >= ~8k tokens, e.g.
  * BASELINE configs[4]): the fused kernel dequantises each 128 x 64 weight tile once per 256 tokens; here the bit-exact

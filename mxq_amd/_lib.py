@@ -46,6 +46,7 @@ SIGNATURES = {
     "mxq_hoist_scratch_bytes": (c_size_t, [c_int, c_int]),
     "mxq_linear_f16_hoisted": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "mxq_linear_f16_ws": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "mxq_linear_f16_layout_ws": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "mxq_gemm_f16_ws": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "mxq_gemv_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "mxq_skinny_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),

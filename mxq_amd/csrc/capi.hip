@@ -253,6 +253,24 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
     return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                             int layout, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    if (!layout_ok(layout)) return MXQ_E_SHAPE;
+    if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
+    if (layout == MXQ_LAYOUT_MIXED)
+        return mxq_linear_f16_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, stream);
+    if (M <= 4) return mxq_launch_gemv_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
+    if (layout == MXQ_LAYOUT_MIXEDC) {
+        if (M <= 48) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
+        if (M <= MIDM_MAX_TOKENS && workspace)
+            return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, 0, 0,
+                                       (hipStream_t)stream);
+    }
+    return mxq_launch_gemm8_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes,
+                                       (hipStream_t)stream);
+}
+
 int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* workspace, size_t workspace_bytes, void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;

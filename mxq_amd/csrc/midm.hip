@@ -188,7 +188,7 @@ __device__ __forceinline__ void midm_run(char* smem, const uint16_t* __restrict_
         }
     };
 
-    // ---- packed weights, raw: wave w copies row block w's two blocks of the double-step (36 lanes x 16 B each; a row
+    // ---- packed weights, raw: wave w copies row block w's two blocks of the double-step (BLK_B / 16 lanes x 16 B each; a row
     // block's chunks are contiguous, its row blocks NC blocks apart).  A row block beyond N lies beyond the buffer:
     // zeros.  A chunk beyond the slice's end delivers another chunk's (finite) weights, against activations that are zero.
     const uint32_t blk_stride = (uint32_t)NC * BLK_B;
@@ -197,7 +197,7 @@ __device__ __forceinline__ void midm_run(char* smem, const uint16_t* __restrict_
     auto load_p = [&](int t) __attribute__((always_inline)) {
         char* b = smem + G::OFF_R + (t % DP) * G::RS_BYTES + wave * BLK_B;
         const rsrc_t wr = make_rsrc(qweight, t < nd ? wbytes : 0u);      // past the slice: empty descriptor, as for x
-        if (lane < 36 && !(MIDM_ABL & 16)) {
+        if (lane < BLK_B / 16 && !(MIDM_ABL & 16)) {     // 36 lanes (exact metadata) / 30 (compact)
             dma16(wr, pvoff, (uint32_t)(c0 + 2 * t) * BLK_B, b);
             dma16(wr, pvoff, (uint32_t)(c0 + 2 * t + 1) * BLK_B, b + 8 * BLK_B);
         }

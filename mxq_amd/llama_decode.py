@@ -82,10 +82,14 @@ class DecodeStage:
         self.pos = torch.zeros(1, dtype=torch.int64, device=dev)      # device-resident position
         self.window = ContextWindow(max_ctx)                          # its host-side mirror (bounds check)
         self.ctx_ids = torch.arange(max_ctx, device=dev)
-        g = torch.Generator(device=dev).manual_seed(99)
+        # embedding and lm_head are seeded SEPARATELY: drawn one after the other from one generator, a stage that is
+        # last but not first got the embedding's draw as its lm_head, i.e. a pipeline whose tokens could never match
+        # the single-process run (found by the world-2 rehearsal of round 3, tools/decode_bench.py --verify)
         if first:
+            g = torch.Generator(device=dev).manual_seed(99)
             self.embed = (torch.randn(vocab, hidden, generator=g, device=dev) * 0.02).half()
         if last:
+            g = torch.Generator(device=dev).manual_seed(98)
             self.lm_head = (torch.randn(vocab, hidden, generator=g, device=dev) * 0.02).half()   # plain fp16 Linear
         self._graph = None
         self._head_ws = None

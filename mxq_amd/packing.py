@@ -314,8 +314,13 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         if path not in ("auto", "gemm", "gemv", "gemm8", "fused"):
             raise ValueError(f"path {path!r} is not available for compact metadata")
         with torch.cuda.device(x.device):
-            fn = lib.mxq_gemv_f16_layout if path == "gemv" or (path == "auto" and M <= 4) else lib.mxq_gemm_f16_layout
-            _lib.check(fn(*args, 3, _stream(x2)), f"mxq_linear_f16[{path}, compact]")
+            if path == "auto" and M > 48:       # mid-M split-K kernel up to MIDM_MAX_TOKENS, prefill kernel beyond
+                ws = gemm_workspace(x2.device, counters=M > MIDM_MAX_TOKENS)
+                _lib.check(lib.mxq_linear_f16_layout_ws(*args, 3, ws.data_ptr(), ws.numel(), _stream(x2)),
+                           "mxq_linear_f16_layout_ws[compact]")
+            else:
+                fn = lib.mxq_gemv_f16_layout if path == "gemv" or (path == "auto" and M <= 4) else lib.mxq_gemm_f16_layout
+                _lib.check(fn(*args, 3, _stream(x2)), f"mxq_linear_f16[{path}, compact]")
         return out.reshape(*x.shape[:-1], p.N)
     with torch.cuda.device(x.device):
         if path == "gemv":

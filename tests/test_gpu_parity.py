@@ -366,6 +366,25 @@ def test_gemm_vs_oracle(dev, M, N, K, path):
     _check_gemm(y, O.linear_ref(x.numpy(), w16), f"{path} {M}x{N}x{K}")
 
 
+def test_config1_workload_m128_4096_vs_oracle(dev):
+    """BASELINE configs[0] exactly: one 4096 x 4096 MXQ Linear, batch 1 x seq 128 (weights seed 0, activations seed 7, as
+    bench.py's cpu_baseline leg): every kernel that can run it, and the automatic dispatch, against the ORACLE's
+    weight (numpy restatement of fasterquant, pinned to the reference by the golden vectors) -- <= 1e-3 in both norms."""
+    from mxq_amd import packing
+    N = K = 4096
+    M = 128
+    W16 = (torch.randn(N, K, generator=torch.Generator().manual_seed(0)) * 0.02).half()
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(7)).half()
+    ref = O.mxq_quantize(W16.numpy())
+    p = packing.quantize_pack(W16.to(dev))
+    got = packing.unpack(p)
+    for k in KEYS:
+        assert np.array_equal(got[k].cpu().numpy(), ref[k]), k             # the integer unpack, bit for bit
+    yref = O.linear_ref(x.numpy(), ref["w_deq32"].astype(np.float16))
+    for path in ["auto"] + GEMM_KERNELS:
+        _check_gemm(packing.linear(x.to(dev), p, path=path).cpu().numpy(), yref, f"configs[0] {path}")
+
+
 def test_gemm_integer_exact_layout(dev):
     """Small-integer weights and activations make every partial sum exact in fp32/fp16, so
     any fragment / swizzle / k-ordering mistake shows up as an exact mismatch (asymmetric
@@ -676,6 +695,12 @@ def test_midm_split_k_llama_shapes(dev, M, N, K):
         assert ((y - yref).norm() / yref.norm()).item() <= REL_TOL, path
     # deterministic: the slabs are summed in slice order, whatever the arrival order
     assert torch.equal(packing.linear(x, p, path="midm"), packing.linear(x, p, path="midm"))
+    # compact metadata (fp16 zero-points): the same kernel behind mxq_linear_f16_layout_ws, against ITS dequantised weight
+    pc = packing.compact(p)
+    yc_ref = x.float() @ packing.dequant(pc).float().t()
+    yc = packing.linear(x, pc, path="auto").float()
+    assert ((yc - yc_ref).abs().max() / yc_ref.abs().max()).item() <= REL_TOL
+    assert ((yc - yc_ref).norm() / yc_ref.norm()).item() <= REL_TOL
 
 
 @pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])

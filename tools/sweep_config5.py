@@ -5,7 +5,7 @@
 and 32-layer totals; and PyTorch's fp16 GEMM (hipBLASLt) on the dequantised weight as reference.  Every
 quantised arm is checked at the full size (<= 1e-3 max-norm and Frobenius against the fp32 product on the
 kernel-dequantised weight, 4096 sampled token rows) before its time is reported.
-    python tools/sweep_config5.py [--m 32768] [--iters 3]"""
+    python tools/sweep_config5.py [--m 32768] [--iters 5] [--rounds 5]"""
 import argparse
 import json
 import os
@@ -20,10 +20,10 @@ SHAPES = [("q/k/v/o", 4096, 4096, 4), ("gate/up", 11008, 4096, 2), ("down", 4096
 PEAK = 2500.0
 
 
-def timed(fn, iters):
-    for _ in range(4):      # warm-up: the first launches of a process run at a different clock / cold caches
-        fn()
-    torch.cuda.synchronize()
+def burst(fn, iters):
+    """Seconds per launch over `iters` back-to-back launches (2 untimed ones first)."""
+    fn()
+    fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -37,44 +37,70 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--warm-s", type=float, default=2.5, help="seconds of back-to-back launches before anything is timed")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     M = args.m
-    report = {"config": f"W2A16 / W4A16 / mixed-2/4 sweep, M = {M} tokens (batch 8 x seq 4096)", "arms": {}}
-    for arm in ("mixed", "w2g16", "w4row", "fp16-hipblaslt"):
+    ARMS = ("mixed", "w2g16", "w4row", "fp16-hipblaslt")
+    # ---- every (shape, arm) case is built and verified FIRST; the timing then walks them in ROTATED order, round by
+    # round, after >= 2 s of warm-up: round 2's sweep timed "mixed, 4096^2" first, after 4 launches, and read a 14 %
+    # gap between arms that run the SAME dense kernel as a property of the data
+    cases = {}
+    for name, N, K, mult in SHAPES:
+        g = torch.Generator(device=dev).manual_seed(N * 7 + K)
+        W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
+        x = torch.randn(M, K, generator=g, device=dev).half()
+        out = torch.empty(M, N, device=dev, dtype=torch.float16)
+        rows_ = torch.randint(0, M, (4096,), generator=g, device=dev)
+        for arm in ARMS:
+            if arm == "fp16-hipblaslt":
+                cases[(name, arm)] = dict(fn=(lambda x=x, W=W, out=out: torch.matmul(x, W.t(), out=out)), bpw=16.0, err=None)
+                continue
+            p = packing.quantize_pack(W) if arm == "mixed" else packing.quantize_pack_uniform(W, arm)
+            fn = (lambda x=x, p=p, out=out: packing.linear_layout(x, p, out=out))
+            fn()
+            # parity at the full size: fp32 product on the kernel-dequantised weight (bit-exact against the oracle in
+            # tests/), 4096 sampled token rows; both error norms of SURVEY.md 8c
+            wd = packing.dequant(p) if arm == "mixed" else packing.expand_uniform(p, codes=False)[0]
+            ref = x[rows_].float() @ wd.float().t()
+            got = out[rows_].float()
+            err_max = ((got - ref).abs().max() / ref.abs().max()).item()
+            err_fro = ((got - ref).norm() / ref.norm()).item()
+            assert err_max <= 1e-3 and err_fro <= 1e-3, (arm, name, err_max, err_fro)
+            cases[(name, arm)] = dict(fn=fn, bpw=p.bits_per_weight(), err={"max_rel": err_max, "fro_rel": err_fro})
+            del wd, ref, got
+    import time
+    t_end = time.perf_counter() + args.warm_s
+    while time.perf_counter() < t_end:
+        for k in cases:
+            cases[k]["fn"]()
+        torch.cuda.synchronize()
+    order = list(cases)
+    samples = {k: [] for k in order}
+    for r in range(args.rounds):
+        rot = order[(r * 5) % len(order):] + order[:(r * 5) % len(order)]
+        if r % 2:
+            rot = rot[::-1]
+        for k in rot:
+            samples[k].append(burst(cases[k]["fn"], args.iters))
+    report = {"config": f"W2A16 / W4A16 / mixed-2/4 sweep, M = {M} tokens (batch 8 x seq 4096)",
+              "method": f"{args.rounds} rounds over all (shape, arm) cases in rotated / reversed order after {args.warm_s} s of "
+                        f"warm-up, {args.iters} launches per sample; ms = median, spread = (max - min) / median", "arms": {}}
+    for arm in ARMS:
         layer_t = layer_f = 0.0
         rows = []
         for name, N, K, mult in SHAPES:
-            g = torch.Generator(device=dev).manual_seed(N * 7 + K)
-            W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
-            x = torch.randn(M, K, generator=g, device=dev).half()
-            out = torch.empty(M, N, device=dev, dtype=torch.float16)
-            if arm == "fp16-hipblaslt":
-                t = timed(lambda: torch.matmul(x, W.t(), out=out), args.iters)
-                bpw = 16.0
-            else:
-                p = packing.quantize_pack(W) if arm == "mixed" else packing.quantize_pack_uniform(W, arm)
-                t = timed(lambda: packing.linear_layout(x, p, out=out), args.iters)
-                bpw = p.bits_per_weight()
-                # parity at the full size: fp32 product on the kernel-dequantised weight (bit-exact against the
-                # oracle in tests/), 4096 sampled token rows; both error norms of SURVEY.md 8c
-                wd = packing.dequant(p) if arm == "mixed" else packing.expand_uniform(p, codes=False)[0]
-                rows_ = torch.randint(0, M, (4096,), generator=g, device=dev)
-                ref = x[rows_].float() @ wd.float().t()
-                got = out[rows_].float()
-                err_max = ((got - ref).abs().max() / ref.abs().max()).item()
-                err_fro = ((got - ref).norm() / ref.norm()).item()
-                assert err_max <= 1e-3 and err_fro <= 1e-3, (arm, name, err_max, err_fro)
-                rows_err = {"max_rel": err_max, "fro_rel": err_fro}
-                del wd, ref, got
+            ts = sorted(samples[(name, arm)])
+            t = ts[len(ts) // 2]
             fl = 2.0 * M * N * K
-            rows.append({"linear": name, "N": N, "K": K, "ms": round(t * 1e3, 3), "TFLOPs": round(fl / t / 1e12, 1),
-                         "mfma_frac": round(fl / t / 1e12 / PEAK, 3), "bits_per_weight": round(bpw, 3)})
-            if arm != "fp16-hipblaslt":
-                rows[-1].update({k: float(f"{v:.3g}") for k, v in rows_err.items()})
+            rows.append({"linear": name, "N": N, "K": K, "ms": round(t * 1e3, 3), "spread": round((ts[-1] - ts[0]) / t, 3),
+                         "TFLOPs": round(fl / t / 1e12, 1), "mfma_frac": round(fl / t / 1e12 / PEAK, 3),
+                         "bits_per_weight": round(cases[(name, arm)]["bpw"], 3)})
+            if cases[(name, arm)]["err"]:
+                rows[-1].update({k: float(f"{v:.3g}") for k, v in cases[(name, arm)]["err"].items()})
             layer_t += mult * t
             layer_f += mult * fl
-            del W, x, out
         report["arms"][arm] = {"per_linear": rows, "layer_ms": round(layer_t * 1e3, 3),
                                "model_32_layers_ms": round(32 * layer_t * 1e3, 2),
                                "TFLOPs": round(layer_f / layer_t / 1e12, 1),
