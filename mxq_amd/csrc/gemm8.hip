@@ -62,13 +62,14 @@ constexpr int SMEM_BYTES = OFF_WD + WD_SLOTS * W_STAGE;
 static_assert(OFF_W + 2 * W_STAGE <= SMEM_BYTES && SMEM_BYTES <= 160 * 1024, "LDS budget");
 constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K] matrix (never part of the C ABI)
 
-// profiling-only switches (template parameter ABL; product build = 0)
-constexpr int ABL_NO_MFMA = 2, ABL_NO_DEQ = 4, ABL_NO_XDMA = 1, ABL_NO_STORE = 256;
+// profiling-only switches (template parameter ABL; the product library instantiates ABL = 0 only, and the stamp / ballast
+// code exists only under MXQ_PROFILING: libmxq_hip_prof.so)
+[[maybe_unused]] constexpr int ABL_NO_MFMA = 2, ABL_NO_DEQ = 4, ABL_NO_XDMA = 1, ABL_NO_STORE = 256;
 // 16: the dequant waves skip the 4-bit arm (its loads and its conversion); 32: the OLDER MFMA wave of each SIMD (waves 0-3)
 // carries 30 independent VALU ops per K-step -- what taking that arm over would cost it.  Timing only.
-constexpr int ABL_NO_Q4 = 16, ABL_MMA_VALU = 32;
+[[maybe_unused]] constexpr int ABL_NO_Q4 = 16, ABL_MMA_VALU = 32;
 // scheduling experiments (correct results): issue priorities of the two roles
-constexpr int EXP_NO_PRIO = 1024, EXP_MMA_PRIO = 2048, EXP_STAMPS = 4096;
+[[maybe_unused]] constexpr int EXP_NO_PRIO = 1024, EXP_MMA_PRIO = 2048, EXP_STAMPS = 4096;
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
@@ -174,9 +175,10 @@ __device__ __forceinline__ void issue_x(const XDma& d, char* smem, int wave, int
 
 #define MXQ_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// diagnostic builds only (EXP_STAMPS): cycle stamps around the phases of a K-step; sums leave through the workspace
+// diagnostic builds only (libmxq_hip_prof.so, EXP_STAMPS): cycle stamps around the phases of a K-step; sums leave through the workspace
 typedef unsigned long long u64t;
 struct Stamps { u64t work, wait, bar, n; };
+#ifdef MXQ_PROFILING
 __device__ __forceinline__ u64t stamp() {
     u64t t;
     __builtin_amdgcn_sched_barrier(0);
@@ -184,6 +186,11 @@ __device__ __forceinline__ u64t stamp() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
+#define MXQ_STAMPS(ABL) (((ABL) & EXP_STAMPS) != 0)
+#else
+__device__ __forceinline__ u64t stamp() { return 0; }
+#define MXQ_STAMPS(ABL) false      /* the product build carries no stamp code */
+#endif
 
 // One K-step t >= 1: MFMAs of (t-1, kk=1) and (t, kk=0), fragment reads of step t, and -- ISSUE -- the x DMAs of
 // step t+2 (slot (t+2) % 3 was last read in step t-1), spread behind groups of MFMAs.
@@ -192,7 +199,7 @@ __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, in
                                          f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1, Frag4& xf1,
                                          Stamps& st) {
     u64t t0 = 0, t1 = 0, t2 = 0;
-    if constexpr ((ABL & EXP_STAMPS) != 0) t0 = stamp();
+    if constexpr (MXQ_STAMPS(ABL)) t0 = stamp();
     mfma_rows<0, 1, ABL>(acc, wf1, xf1);
     MXQ_FENCE();
     load_frags<DENSE>(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
@@ -207,6 +214,7 @@ __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, in
     MXQ_FENCE();
     mfma_rows<0, 2, ABL>(acc, wf0, xf0);
     MXQ_FENCE();
+#ifdef MXQ_PROFILING
     if constexpr ((ABL & ABL_MMA_VALU) != 0) {
         if (wave < 4) {
             float b0 = (float)t, b1 = b0 + 1.f, b2 = b0 + 2.f, b3 = b0 + 3.f, b4 = b0 + 4.f;
@@ -217,17 +225,18 @@ __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, in
             asm volatile("" ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4));
         }
     }
+#endif
     MXQ_FENCE();
     if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) issue_x<2, 4>(xd, smem, wave, t + 2);
     MXQ_FENCE();
     mfma_rows<2, 4, ABL>(acc, wf0, xf0);
-    if constexpr ((ABL & EXP_STAMPS) != 0) t1 = stamp();
+    if constexpr (MXQ_STAMPS(ABL)) t1 = stamp();
     // this step's 4 DMAs stay in flight across the barrier; the previous step's (x of step t+1) have landed
     if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if constexpr ((ABL & EXP_STAMPS) != 0) t2 = stamp();
+    if constexpr (MXQ_STAMPS(ABL)) t2 = stamp();
     __builtin_amdgcn_s_barrier();
-    if constexpr ((ABL & EXP_STAMPS) != 0) {
+    if constexpr (MXQ_STAMPS(ABL)) {
         const u64t t3 = stamp();
         st.work += t1 - t0; st.wait += t2 - t1; st.bar += t3 - t2; st.n += 1;
     }
@@ -371,9 +380,9 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
     int t = 1;
     Stamps st = {0, 0, 0, 0};
     u64t rt0 = 0;
-    if constexpr ((ABL & EXP_STAMPS) != 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+    if constexpr (MXQ_STAMPS(ABL)) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
     for (; t + 2 < NT; ++t) mma_step<ABL, true, DENSE>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
-    if constexpr ((ABL & EXP_STAMPS) != 0) {   // this workgroup's wave: {work, wait, barrier, steps} cycle sums
+    if constexpr (MXQ_STAMPS(ABL)) {   // this workgroup's wave: {work, wait, barrier, steps} cycle sums
         u64t rt1;                              // + the same span on the constant 100 MHz clock (high half of word 3): the core clock held
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
         if (lane == 0 && sk.ws) {

@@ -1067,6 +1067,35 @@ def test_g3_fakequant_llama_width(dev, g3, K):
     assert np.array_equal(_bits(out), g3[f"bf16_K{K}_out"])
 
 
+@pytest.mark.parametrize("shape", [(4096, 4096), (11008, 4096), (4096, 11008)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+def test_ste_backward_full_size(dev, shape, dt):
+    """BASELINE configs[3] at the decoder block's real weight shapes: MXAsymQuantizer.backward (utils_quant.py:464-475) is
+    grad_in = grad_out except 0 where w >= 2 or w <= -2 -- checked EXACTLY over the whole tensor against the same
+    rule written with torch ops on the device (planted values at, just inside and beyond +-2.0, NaN / inf gradients pass
+    through untouched), through the autograd Function the trainer calls."""
+    from mxq_amd.utils_quant import MXAsymQuantizer
+    g = torch.Generator().manual_seed(shape[0] + shape[1])
+    w = (torch.randn(*shape, generator=g) * 0.9).to(dt)
+    flat = w.view(-1)
+    edge = torch.tensor([2.0, -2.0, 1.9921875, -1.9921875, 2.015625, -2.015625, 0.0, 65504.0 if dt != torch.bfloat16 else 3e38])
+    flat[:: flat.numel() // 64][: edge.numel()] = edge.to(dt)
+    flat[5] = 0.5
+    flat[7] = -0.5                                                    # inside the clip range: their gradients pass
+    go = torch.randn(*shape, generator=g).to(dt)
+    go.view(-1)[5] = float("nan")
+    go.view(-1)[7] = float("inf")
+    wd = w.to(dev).requires_grad_()
+    out = MXAsymQuantizer.apply(wd, torch.tensor([-2.0, 2.0]), 2, False)
+    out.backward(go.to(dev))
+    want = go.to(dev).clone()
+    want[(wd.detach() >= 2.0) | (wd.detach() <= -2.0)] = 0
+    got = wd.grad
+    same = (got.view(torch.int16 if dt != torch.float32 else torch.int32) == want.view(torch.int16 if dt != torch.float32 else torch.int32))
+    assert bool(same.all()), int((~same).sum())
+    assert int((want == 0).sum()) > 0 and torch.isnan(got.view(-1)[5]) and torch.isinf(got.view(-1)[7])
+
+
 @pytest.mark.parametrize("shape,dt", [((4096, 4096), "bf16"), ((1000, 11008), "bf16"), ((512, 4096), "fp32"),
                                       ((1001, 8192), "bf16"),      # row split over 2 waves, odd row count
                                       ((37, 16384), "bf16"),       # 4 waves per row at the register kernel's limit

@@ -1,0 +1,568 @@
+// Decode-path GEMV (M <= 4 tokens) on the packed formats:
+//   y[m, n] = sum_k x[m, k] * (scale * (q - zero))[n, k], fp32 accumulate, fp16 out.
+//
+// Native counterpart of the reference's fused unpack+dot kernel gemv_mxq_kernel_g16_v0
+// (mxq_quant/cuda_kernel/csrc/quantization/gemv_mxq_cuda.cu:39-208) -- same idea (never materialise fp16 weights in
+// memory), different everything else.  What round 2's measurements say bounds this kernel, and what the structure
+// does about each (tools/gemv_stamps.py, tools/ab_gemv.py, tools/probes/stream_probe.hip):
+//   * Not the HBM peak: a loads-only kernel in this access pattern streams 5.2-5.4 TB/s, weights served from the
+//     Infinity Cache instead of HBM made the round-1 kernel only ~15 % faster, and halving its VALU work only ~7 %.
+//   * Round trips: a wave that loads a tile, waits, computes, loads the next ... pays one loaded HBM latency
+//     (2.5-4 us with every workgroup's requests queued at once) per tile, and the workgroup's prologue (activation
+//     staging + barrier) waited for the first tile as well, because vector-memory loads retire in order (vmcnt).
+//     So: each wave keeps TWO tiles in flight while it computes a third (three register sets, rotated by unrolling
+//     -- no copies, a copy would wait for its load); the activation loads are issued BEFORE the first tiles, so the
+//     staging waits for them alone; and nothing on the hot path branches around a load -- a branch makes the
+//     compiler's wait counts conservative, i.e. a drain.  Instead: tiles are read through a buffer descriptor that
+//     spans exactly the row block's K range (a tile index past the end returns zeros and costs no memory traffic),
+//     and threads with nothing to stage write to a dummy LDS slot.
+//   * Fewer, longer waves: 2 / 4 / 8 waves per workgroup by row-block count (every workgroup resident, ~2-3 k waves
+//     on the chip, 2-8 tiles each) instead of 16 waves with one tile.
+//   * VALU: the integer CODES go into v_dot2_f32_f16 and the group's scale / zero-point are applied to the group's
+//     16-term sum,
+//         sum_k x_k s (q_k - z)  =  s * (sum_k q_k x_k)  -  s z * (sum_k x_k),
+//     with the per-group activation sums computed once per workgroup next to the staged activations.  A code becomes
+//     an fp16 operand without a conversion: OR-ed into the top mantissa bits of 1.0 it reads 1 + q/4 (2-bit) or
+//     1 + q/16 (4-bit), i.e. one shift and one v_and_or_b32 per TWO weights (the byte-spread code words put
+//     elements k and k + 2 sixteen bits apart; the staged activations are permuted to (x0, x2, x1, x3) per four to
+//     match).  ~120 VALU ops per 64 weights instead of ~230 for building the exact fp16 weights first (LUT +
+//     4 v_perm per 4 weights).  The result is the fp32 sum over the UNROUNDED weights s (q - z): it differs from
+//     the sum over the reference's fp16-rounded weights by the fp16 rounding of each weight (2^-11 relative,
+//     independent per weight), ~1e-5 of the output scale at K = 4096 -- far inside the path's 1e-3 tolerance.
+//   * Round 3 (tools/gemv_stamps.py): the per-lane dword loads of a tile are 15-16 vector-memory INSTRUCTIONS for 2304
+//     bytes, and the CU's address pipe takes ~16 cycles per instruction whatever its width: the ~1300 instructions per
+//     CU of a gate|up launch are ~20 k cycles -- the whole 8.7 us "weight loop" -- and the 30 instructions every wave
+//     issues before it may stage the activations kept the "stage x" phase at 2-4 us of every launch.  The mixed layouts
+//     therefore fetch a tile RAW by LDS-DMA (3 instructions of up to 1 KB: the tile is contiguous) into a per-wave ring
+//     of 3 slots and pick the dwords out of LDS (15 ds_read_b32, on an LDS that is otherwise idle); the wave that issued
+//     a DMA is the only reader of its slot, so a counted vmcnt is all the synchronisation there is.
+// One workgroup per 16-row block; lane -> (row r = lane & 15, chunk slot cs = lane >> 4); a wave consumes 4
+// consecutive 16x64 blocks (2304 contiguous bytes) per tile; waves split K by tiles.
+#include <hip/hip_runtime.h>
+
+#include "mxq_dequant.h"
+#include "mxq_format.h"
+#include "mxq_kernels.h"
+
+namespace {
+
+// cache policy of the WEIGHT loads (raw_buffer_load aux bits: 2 = nt).  The weights of a decode GEMV are read once,
+// by one CU each; x, rowmeta and everything re-read stay on the default policy.  A/B: profiles/r03_gemv_nt_ab.txt
+#ifndef MXQ_GEMV_WAUX
+#define MXQ_GEMV_WAUX 0
+#endif
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+
+__device__ __forceinline__ float dot2(uint32_t w, uint32_t x, float acc) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w), __builtin_bit_cast(half2v, x), acc, false);
+}
+
+// (a & m) | o in one op (the mask in an SGPR, the fp16 ones in a VGPR: gfx9 VOP3 takes no literals, and left to itself
+// the compiler emits v_and + v_or)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t o) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(o));
+    return r;
+}
+
+// sum_k (1 + q_k / 4) x_k over the 16 two-bit codes of byte-spread word d.  Element k sits at bit 8 (k & 3) +
+// 2 (k >> 2): field f of bytes (0, 2) = elements (4f, 4f + 2) lands in mantissa bits 9:8 of the two fp16 lanes
+// with one shift, bytes (1, 3) = elements (4f + 1, 4f + 3) likewise.  xa / xb: the group's 16 activations in the
+// staged order (x0, x2, x1, x3 | x4, x6, x5, x7 | ...).
+__device__ __forceinline__ float codedot2x16(uint32_t d, const uint4 xa, const uint4 xb, float acc) {
+    constexpr uint32_t M = 0x03000300u, ONE = 0x3C003C00u;
+    acc = dot2(and_or(d << 8, M, ONE), xa.x, acc);
+    acc = dot2(and_or(d, M, ONE), xa.y, acc);
+    acc = dot2(and_or(d << 6, M, ONE), xa.z, acc);
+    acc = dot2(and_or(d >> 2, M, ONE), xa.w, acc);
+    acc = dot2(and_or(d << 4, M, ONE), xb.x, acc);
+    acc = dot2(and_or(d >> 4, M, ONE), xb.y, acc);
+    acc = dot2(and_or(d << 2, M, ONE), xb.z, acc);
+    acc = dot2(and_or(d >> 6, M, ONE), xb.w, acc);
+    return acc;
+}
+
+// sum_k (1 + q_k / 16) x_k over the 8 four-bit codes of byte-spread word d (element k at bit 8 (k & 3) + 4 (k >> 2));
+// xa: the 8 activations in the staged order
+__device__ __forceinline__ float codedot4x8(uint32_t d, const uint4 xa, float acc) {
+    constexpr uint32_t M = 0x03C003C0u, ONE = 0x3C003C00u;
+    acc = dot2(and_or(d << 6, M, ONE), xa.x, acc);
+    acc = dot2(and_or(d >> 2, M, ONE), xa.y, acc);
+    acc = dot2(and_or(d << 2, M, ONE), xa.z, acc);
+    acc = dot2(and_or(d >> 6, M, ONE), xa.w, acc);
+    return acc;
+}
+
+// 8 fp16 activations (x0 .. x7) -> the staged order (x0, x2, x1, x3, x4, x6, x5, x7) and their fp32 sum
+__device__ __forceinline__ uint4 stage8(const uint4 v, float& sum) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 h = __builtin_bit_cast(h8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += (float)h[j];
+    uint4 o;
+    o.x = __builtin_amdgcn_perm(v.y, v.x, 0x05040100u);
+    o.y = __builtin_amdgcn_perm(v.y, v.x, 0x07060302u);
+    o.z = __builtin_amdgcn_perm(v.w, v.z, 0x05040100u);
+    o.w = __builtin_amdgcn_perm(v.w, v.z, 0x07060302u);
+    return o;
+}
+
+#ifdef MXQ_PROFILING
+// phase stamps of every workgroup (tools/gemv_stamps.py): [workgroup][4] = start, activations staged, weight loop
+// done, result stored; 100 MHz wall clock (comparable across CUs)
+__device__ unsigned long long* g_gemv_stamps = nullptr;
+#define GEMV_STAMP(i)                                                                            \
+    if (g_gemv_stamps != nullptr && threadIdx.x == 0) g_gemv_stamps[blockIdx.x * 4 + (i)] = wall_clock64();
+#else
+#define GEMV_STAMP(i)
+#endif
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// PRO: prologue fused into the activation staging (decode, M = 1 only):
+//   0 = none; 1 = RMSNorm: x <- fp16(x * norm_w), and the row's scalar rsqrt(mean(x^2) + eps) -- linear in the
+//   output -- multiplies the 16 results at the end (so the staging does not wait for the reduction);
+//   2 = SwiGLU gate: the input row is [2K] = (gate, up) and x <- fp16(silu(gate)) * up.
+// residual (nullable): y <- residual + W.x (the decoder layer's skip connection).
+// LAYOUT: MXQ_LAYOUT_MIXED / MIXEDC (3 two-bit groups + the 4-bit quarter per chunk; exact / compact metadata),
+// MXQ_LAYOUT_W2G16 (4 two-bit groups) or MXQ_LAYOUT_W4ROW (4 four-bit quarters, scale / zero per row from rowmeta).
+template <int MB, int GEMV_THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED>
+__global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16_t* __restrict__ x,
+                                                                     const uint32_t* __restrict__ qweight,
+                                                                     const float4* __restrict__ rowmeta,
+                                                                     uint16_t* __restrict__ y, int M, int N, int K,
+                                                                     const uint16_t* __restrict__ norm_w, float eps,
+                                                                     const uint16_t* __restrict__ residual) {
+    constexpr int W = GEMV_THREADS / 64;
+    constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC;   // exact / compact metadata
+    constexpr bool COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
+    constexpr int NG2 = MIXED ? 3 : LAYOUT == MXQ_LAYOUT_W2G16 ? 4 : 0;   // two-bit groups per chunk
+    constexpr int NW4 = MIXED ? 2 : LAYOUT == MXQ_LAYOUT_W4ROW ? 8 : 0;   // four-bit code words per chunk
+    constexpr int BLK_DW = LAYOUT == MXQ_LAYOUT_W4ROW ? 128 : COMPACT ? MXQC_BLK_DW : MXQ_BLK_DW;
+    // LDS: x [MB][K] fp16 (code-dot order) | xsum [MB][K/16] f32 | red [W][MB][16] f32 | wsum [W] f32 | dummy slots
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, cs = lane >> 4;
+    const int rb = blockIdx.x;
+    const int NC = K / 64, NC4 = (NC + 3) / 4, NG = K / 16;
+    GEMV_STAMP(0)
+
+    float* xsum = (float*)(smem + (size_t)MB * K * 2);
+    float* red = xsum + MB * NG;
+    float* wsum = red + W * MB * 16;
+    // [64 lanes][32 B] + [64] f32: where idle threads "stage" (16-byte aligned, as the launcher sizes it)
+    char* dummy = smem + ((((char*)(wsum + W) - smem) + 15) & ~(ptrdiff_t)15);
+    constexpr bool DMA = MIXED && MB == 1;              // mixed layouts, one token: raw tiles by LDS-DMA (header); else registers
+    constexpr int TILE_B = 4 * BLK_DW * 4;              // 2304 (exact) / 1920 (compact) bytes
+    char* ring = dummy + 64 * 32 + 64 * 4 + wave * (3 * TILE_B);   // this wave's 3 tile slots (16-byte aligned: launcher)
+
+    // ---- activation loads first (L2-resident, small), 2 staging steps hoisted; branch-free (clamped addresses)
+    struct Act {
+        h8 a0, a1;     // 16 activations (one scale group)
+        h8 b0, b1;     // PRO 1: their RMSNorm weights; PRO 2: the up projection (a = gate)
+    };
+    // DMA path: the tile DMAs are inline asm (the compiler orders every LDS access behind a builtin LDS-DMA with
+    // s_waitcnt vmcnt(0): the activation staging would wait for the first tiles again, and the tile reads of the loop
+    // for the tiles just requested).  An asm memory operation is invisible to the compiler's wait counts, so every
+    // vector-memory operation between the first DMA and the end of the K loop must be counted BY HAND -- which is why
+    // the activation loads are asm too (form (ii) of the cdna guide, 5.7: "=v" loads, then ONE wait statement that
+    // names every destination "+v") and the row metadata is consumed only after the loop.
+    auto ld16 = [&](const uint16_t* ptr) {
+        h8 v;
+        if constexpr (DMA) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+        else v = *(const h8*)ptr;
+        return v;
+    };
+    auto load_act = [&](int i) {
+        Act t;
+        const int ic = min(i, MB * NG - 1);
+        const int m = ic / NG, g = ic % NG;
+        const uint16_t* xr = x + (int64_t)min(m, M - 1) * K + g * 16;      // PRO != 0: one token, m == 0
+        t.a0 = ld16(xr);
+        t.a1 = ld16(xr + 8);
+        if constexpr (PRO == 1) {
+            t.b0 = ld16(norm_w + g * 16);
+            t.b1 = ld16(norm_w + g * 16 + 8);
+        }
+        if constexpr (PRO == 2) {
+            t.b0 = ld16(xr + K);
+            t.b1 = ld16(xr + K + 8);
+        }
+        return t;                                       // (nothing here may USE a loaded value: that would be a wait)
+    };
+    Act act0 = load_act(tid), act1 = load_act(tid + GEMV_THREADS);
+
+    // ---- the first two weight tiles right behind them.  A tile = 4 consecutive blocks (one per chunk slot).
+    struct Tile {
+        uint32_t c2w[NG2 ? NG2 : 1], z2w[NG2 ? NG2 : 1], c4w[NW4 ? NW4 : 1], scw;
+        uint2 qq[NG2 ? NG2 : 1];
+    };
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(qweight + (int64_t)rb * NC * BLK_DW), 0, NC * BLK_DW * 4, 0x00020000);
+    const int lane_off = (cs * BLK_DW) * 4;             // byte offset of the lane's block inside a tile
+    auto load_tile = [&](int c4) {                      // c4 >= NC4 or a chunk >= NC: out of range = zeros, no traffic
+        Tile t = {};
+        const int so = c4 * (4 * BLK_DW * 4);           // wave-uniform
+        auto dw = [&](int idx) { return __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off + idx * 4, so, MXQ_GEMV_WAUX); };
+        if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t.c4w[i] = dw(mxq_w4_c4(i >> 1, i & 1, r));
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG2; ++g) {
+                t.c2w[g] = dw(MIXED ? mxq_c2(g, r) : mxq_w2_c2(g, r));
+                if constexpr (COMPACT)                  // fp16 zero-point (widened where it is used)
+                    t.z2w[g] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane_off + mxqc_z2_u16(g, r) * 2, so, MXQ_GEMV_WAUX);
+                else
+                    t.z2w[g] = dw(MIXED ? mxq_z2(g, r) : mxq_w2_z2(g, r));
+                const int q = COMPACT ? mxqc_qq(g) : mxq_qq(g);     // SC / QQ: same offsets in v1 and W2G16
+                t.qq[g] = make_uint2(dw(q), dw(q + 1));
+            }
+            if constexpr (MIXED) {
+                t.c4w[0] = dw(mxq_c4(0, r));
+                t.c4w[1] = dw(mxq_c4(1, r));
+            }
+            t.scw = __builtin_amdgcn_raw_buffer_load_b16(rs, lane_off + (COMPACT ? mxqc_sc_u16(r) : mxq_sc_u16(r)) * 2, so, MXQ_GEMV_WAUX);
+        }
+        return t;
+    };
+    // ---- DMA path: tile c4 -> ring slot `slot`; whole instructions of 64 lanes x 16 B, the last one partial
+    constexpr int DMA_N = (TILE_B + 1023) / 1024;       // 3 (exact) / 2 (compact) instructions per tile
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    const uint64_t rbase = (uint64_t)(qweight + (int64_t)rb * NC * BLK_DW);
+    const u32x4v rs4 = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rbase),
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(rbase >> 32) & 0xFFFFu)),
+                        (uint32_t)__builtin_amdgcn_readfirstlane(NC * BLK_DW * 4), 0x00020000u};   // = rs, as 4 dwords
+    auto dma_tile = [&](int c4, int slot) {
+        const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)c4 * TILE_B);   // past the row block's K range: zeros land
+        const uint32_t la = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(ring + slot * TILE_B));
+#pragma unroll
+        for (int i = 0; i < DMA_N; ++i) {
+            const int lanes = TILE_B - i * 1024 >= 1024 ? 64 : (TILE_B - i * 1024) / 16;
+            // M0 = LDS destination of lane 0 (written in the statement that reads it: the compiler owns M0 elsewhere);
+            // s_nop 4: an SGPR written by v_readfirstlane needs 5 wait states before a buffer instruction reads it
+            if (lanes == 64 || lane < lanes) {
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\t"
+                             "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "s"(la + (uint32_t)i * 1024u), "v"((uint32_t)(i * 1024 + lane * 16)), "s"(rs4), "s"(so)
+                             : "memory");
+            }
+        }
+    };
+    auto read_tile = [&](int slot) {                    // the lane's dwords of its block (cs) out of the slot
+        Tile t = {};
+        const uint32_t* b = (const uint32_t*)(ring + slot * TILE_B) + cs * BLK_DW;
+        const uint16_t* bh = (const uint16_t*)b;
+#pragma unroll
+        for (int g = 0; g < NG2; ++g) {
+            t.c2w[g] = b[mxq_c2(g, r)];
+            if constexpr (COMPACT) t.z2w[g] = bh[mxqc_z2_u16(g, r)];
+            else t.z2w[g] = b[mxq_z2(g, r)];
+            const int q = COMPACT ? mxqc_qq(g) : mxq_qq(g);
+            t.qq[g] = make_uint2(b[q], b[q + 1]);
+        }
+        t.c4w[0] = b[mxq_c4(0, r)];
+        t.c4w[1] = b[mxq_c4(1, r)];
+        t.scw = bh[COMPACT ? mxqc_sc_u16(r) : mxq_sc_u16(r)];
+        return t;
+    };
+    // (the sched_barriers pin the issue order the wait counts are computed from: activations, row metadata, all of
+    // tile 0, all of tile 1, and only then the staging arithmetic -- left alone, the scheduler sinks a tile-0 load
+    // behind tile 1, and the loop's first wait then covers most of tile 1 in EVERY iteration)
+    const float4 rm = rowmeta[rb * 16 + r];
+    __builtin_amdgcn_sched_barrier(0);
+    Tile T0, T1, T2;
+    if constexpr (DMA) {
+        dma_tile(wave, 0);
+        dma_tile(wave + W, 1);
+        // the activations have arrived once only the two tiles' DMA instructions are outstanding (in-order counter)
+        if constexpr (PRO == 0)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(act0.a0), "+v"(act0.a1), "+v"(act1.a0), "+v"(act1.a1) : "n"(2 * DMA_N) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%8)"
+                         : "+v"(act0.a0), "+v"(act0.a1), "+v"(act0.b0), "+v"(act0.b1), "+v"(act1.a0), "+v"(act1.a1), "+v"(act1.b0), "+v"(act1.b1)
+                         : "n"(2 * DMA_N) : "memory");
+    } else {
+        T0 = load_tile(wave);
+        __builtin_amdgcn_sched_barrier(0);
+        T1 = load_tile(wave + W);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- stage the activations: code-dot order + per-group fp32 sums; idle threads write to their dummy slot
+    float ss = 0.f;
+    auto stage_act = [&](int i, Act t) {
+        const bool live = i < MB * NG;                  // i = m * NG + g: rows are K * 2 = NG * 32 bytes
+        if (MB > 1 && min(i, MB * NG - 1) / NG >= M) {  // rows beyond M are staged as zeros (select, not branch)
+            const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            t.a0 = zero;
+            t.a1 = zero;
+        }
+        if constexpr (PRO == 1) {
+            float sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sq += (float)t.a0[j] * (float)t.a0[j] + (float)t.a1[j] * (float)t.a1[j];
+            ss += live ? sq : 0.f;                      // (an idle thread holds a clamped copy of the last group)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                t.a0[j] = t.a0[j] * t.b0[j];
+                t.a1[j] = t.a1[j] * t.b1[j];
+            }
+        }
+        if constexpr (PRO == 2) {                      // SwiGLU: x <- fp16(silu(gate)) * up
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g0 = (float)t.a0[j], g1 = (float)t.a1[j];
+                t.a0[j] = (_Float16)(g0 / (1.0f + __expf(-g0))) * t.b0[j];
+                t.a1[j] = (_Float16)(g1 / (1.0f + __expf(-g1))) * t.b1[j];
+            }
+        }
+        float sum = 0.f;
+        const uint4 o0 = stage8(__builtin_bit_cast(uint4, t.a0), sum);
+        const uint4 o1 = stage8(__builtin_bit_cast(uint4, t.a1), sum);
+        char* dst = live ? smem + (size_t)i * 32 : dummy + lane * 32;
+        float* sdst = live ? xsum + i : (float*)(dummy + 64 * 32) + lane;
+        *(uint4*)dst = o0;
+        *(uint4*)(dst + 16) = o1;
+        *sdst = sum;
+    };
+    stage_act(tid, act0);
+    stage_act(tid + GEMV_THREADS, act1);
+    for (int i = tid + 2 * GEMV_THREADS; i < MB * NG; i += GEMV_THREADS) {   // M > 1 / odd shapes (K > 32 x threads)
+        Act t = load_act(i);
+        if constexpr (DMA)   // asm loads: wait by hand (rare path: a full drain, the first tiles included)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(t.a0), "+v"(t.a1), "+v"(t.b0), "+v"(t.b1)::"memory");
+        stage_act(i, t);
+    }
+    if constexpr (PRO == 1) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (lane == 0) wsum[wave] = ss;
+    }
+    __syncthreads();
+    GEMV_STAMP(1)
+
+    // P: sum_g s_g * D'_g,  Q: sum_g s_g (1 + z_g / 4) X_g   (two-bit groups; y = 4 (P - Q))
+    // R: sum D'4 over every four-bit quarter of the row, X4: sum of their activation sums (y += 16 s4 (R - (1 + z4 / 16) X4))
+    float P[MB], Q[MB], R[MB], X4[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) P[m] = Q[m] = R[m] = X4[m] = 0.f;
+    auto compute = [&](int c4, const Tile& t) {
+        const int chunk = c4 * 4 + cs;
+        if (chunk < NC) {                               // no memory ops inside: the wait counts stay exact
+            const char* xk = smem + (size_t)chunk * 128;
+            const float* xg = xsum + chunk * 4;
+#pragma unroll
+            for (int g = 0; g < NG2; ++g) {
+                const float s = mxq_scale(__uint_as_float(t.qq[g].x), __uint_as_float(t.qq[g].y),
+                                          (t.scw >> (4 * g)) & 15u);
+                float z;
+                if constexpr (COMPACT) z = (float)__builtin_bit_cast(_Float16, (uint16_t)t.z2w[g]);
+                else z = __uint_as_float(t.z2w[g]);
+                const float sz = s * __builtin_fmaf(z, 0.25f, 1.0f);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + g * 32);
+                    const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + g * 32 + 16);
+                    P[m] = __builtin_fmaf(s, codedot2x16(t.c2w[g], xa, xb, 0.f), P[m]);
+                    Q[m] = __builtin_fmaf(sz, xg[m * NG + g], Q[m]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NW4 / 2; ++q) {      // 16 four-bit weights per pair of code words
+                constexpr int G0 = MIXED ? 3 : 0;    // the mixed layout's quarter is the chunk's last
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const uint4 xa = *(const uint4*)(xk + (size_t)m * K * 2 + (G0 + q) * 32);
+                    const uint4 xb = *(const uint4*)(xk + (size_t)m * K * 2 + (G0 + q) * 32 + 16);
+                    R[m] = codedot4x8(t.c4w[2 * q], xa, R[m]);
+                    R[m] = codedot4x8(t.c4w[2 * q + 1], xb, R[m]);
+                    X4[m] += xg[m * NG + G0 + q];
+                }
+            }
+        }
+    };
+    if constexpr (DMA) {
+        // two tiles in flight while a third is computed: tile c4 + 2 W is requested into the slot that tile c4 - W
+        // was read out of one iteration ago (its ds_reads have returned: their values were consumed), then the wave
+        // waits until only the two younger tiles' DMA instructions are outstanding -- tile c4 has landed -- and reads
+        // its own slot (no other wave touches it: no barrier)
+        int slot = 0;
+        for (int c4 = wave; c4 < NC4; c4 += W) {
+            const int nslot = slot == 0 ? 2 : slot - 1;      // (slot + 2) % 3
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_tile(c4 + 2 * W, nslot);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_N) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            compute(c4, read_tile(slot));
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two run-ahead DMAs (zero fills past the end) land before LDS is reused
+    } else {
+    // two tiles in flight while a third is computed; the register sets rotate by unrolling (no copies)
+    for (int c4 = wave; c4 < NC4; c4 += 3 * W) {
+        T2 = load_tile(c4 + 2 * W);
+        compute(c4, T0);
+        T0 = load_tile(c4 + 3 * W);
+        compute(c4 + W, T1);
+        T1 = load_tile(c4 + 4 * W);
+        compute(c4 + 2 * W, T2);
+    }
+    }
+    GEMV_STAMP(2)
+    // (the row's 4-bit-arm parameters are consumed here, behind the loop: a compiler wait for this plain load in front
+    // of the loop would also wait for the DMAs it cannot see)
+    const float s4 = mxq_scale(rm.z, rm.w, (uint32_t)rm.y), z4 = rm.x;
+    float acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        acc[m] = 0.f;
+        if constexpr (NG2 > 0) acc[m] = 4.0f * (P[m] - Q[m]);
+        if constexpr (NW4 > 0) acc[m] += 16.0f * s4 * (R[m] - __builtin_fmaf(z4, 0.0625f, 1.0f) * X4[m]);
+    }
+
+    // reduce over the 4 chunk slots of the wave, then over waves
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        float v = acc[m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (cs == 0) red[(wave * MB + m) * 16 + r] = v;
+    }
+    __syncthreads();
+    if (tid < MB * 16) {
+        const int m = tid >> 4, rr = tid & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) v += red[(w * MB + m) * 16 + rr];
+        if constexpr (PRO == 1) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < W; ++w) tot += wsum[w];
+            v *= rsqrtf(tot / (float)K + eps);
+        }
+        if (m < M) {
+            _Float16 h = (_Float16)v;
+            if (residual) h = __builtin_bit_cast(_Float16, residual[(int64_t)m * N + rb * 16 + rr]) + h;
+            y[(int64_t)m * N + rb * 16 + rr] = __builtin_bit_cast(uint16_t, h);
+        }
+    }
+    GEMV_STAMP(3)
+}
+
+template <int MB, int THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED>
+int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+             const void* norm_w, float eps, const void* residual, hipStream_t stream) {
+    constexpr int W = THREADS / 64;
+    constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC;
+    constexpr int TILE_B = 4 * (LAYOUT == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_DW : MXQ_BLK_DW) * 4;
+    // x | group sums | reduction | dummy staging slots | (mixed layouts) 3 raw tile slots per wave; every part a multiple of 16 B
+    // except W * (MB * 16 + 1) floats: rounded up
+    const size_t head = (size_t)MB * K * 2 + (size_t)MB * (K / 16) * 4 + (((size_t)W * (MB * 16 + 1) * 4 + 15) & ~(size_t)15) + 64 * 32 + 64 * 4;
+    const size_t smem = head + (MIXED ? (size_t)W * 3 * TILE_B : 0);
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT><<<N / 16, THREADS, smem, stream>>>(
+        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K,
+        (const uint16_t*)norm_w, eps, (const uint16_t*)residual);
+    return (int)hipGetLastError();
+}
+
+// Waves per workgroup by row-block count: every workgroup resident at once (~5 waves per SIMD at ~90 VGPRs), some
+// 2-3 thousand waves on the chip, each with several tiles to pipeline.  <= 384 row blocks (N = 4096): 8 waves (K = 4096:
+// 2 tiles each, all in flight from the start; K = 11008: 5-6 each); <= 768 (q|k|v): 4 waves; more (gate|up: 1376): 2.
+__host__ inline int gemv_threads(int N, int forced) {
+    if (forced) return forced;
+    const int rbs = N / 16;
+    return rbs <= 384 ? 512 : rbs <= 768 ? 256 : 128;
+}
+
+#define MXQ_GEMV_DISPATCH(MB, PRO, LAYOUT, TH)                                                                          \
+    ((TH) == 512   ? launch_t<MB, 512, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
+     : (TH) == 256 ? launch_t<MB, 256, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
+     : (TH) == 128 ? launch_t<MB, 128, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
+                   : (int)hipErrorInvalidValue)
+
+template <int MB, int LAYOUT = MXQ_LAYOUT_MIXED>
+int launch(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream,
+           int threads = 0) {
+    const void *norm_w = nullptr, *residual = nullptr;
+    const float eps = 0.f;
+    const int th = gemv_threads(N, threads);
+    return MXQ_GEMV_DISPATCH(MB, 0, LAYOUT, th);
+}
+
+template <int LAYOUT>
+int launch_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                  hipStream_t stream) {
+    if (M == 1) return launch<1, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream);
+    if (M == 2) return launch<2, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream);
+    if (M <= 4) return launch<4, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream);
+    return (int)hipErrorInvalidValue;
+}
+
+}   // namespace
+
+int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                        hipStream_t stream) {
+    return launch_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, stream);
+}
+
+int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                               int layout, hipStream_t stream) {
+    switch (layout) {
+        case MXQ_LAYOUT_MIXED: return launch_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_W2G16: return launch_layout<MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_W4ROW: return launch_layout<MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_MIXEDC: return launch_layout<MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, stream);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+template <int LAYOUT>
+static int fused_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K, int prologue,
+                        const void* norm_w, float eps, const void* residual, hipStream_t stream, int threads = 0) {
+    const int th = gemv_threads(N, threads), M = 1;
+    switch (prologue) {
+        case 0: return MXQ_GEMV_DISPATCH(1, 0, LAYOUT, th);
+        case 1: return MXQ_GEMV_DISPATCH(1, 1, LAYOUT, th);
+        case 2: return MXQ_GEMV_DISPATCH(1, 2, LAYOUT, th);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                              int prologue, const void* norm_w, float eps, const void* residual, int compact,
+                              hipStream_t stream) {
+    return compact ? fused_layout<MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual, stream)
+                   : fused_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual, stream);
+}
+
+#ifdef MXQ_PROFILING
+// tools/gemv_stamps.py: point the kernels of THIS library at a device buffer of 4 stamps per workgroup (NULL: off),
+// and a fused one-token launch (prologue 0 / 1 / 2, explicit workgroup size or 0) through this library's kernels
+extern "C" int mxq_prof_gemv_set_stamps(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemv_stamps), &p, sizeof(p));
+}
+extern "C" int mxq_prof_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                                       int prologue, const void* norm_w, float eps, const void* residual, int threads,
+                                       void* stream) {
+    return fused_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual,
+                                          (hipStream_t)stream, threads);
+}
+// A/B entry for tools/ (correct results): explicit workgroup size (128 / 256 / 512 threads), M = 1
+extern "C" int mxq_prof_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                 int threads, void* stream) {
+    if (M != 1) return -1;
+    return launch<1>(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream, threads);
+}
+#endif
