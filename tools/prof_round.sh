@@ -22,6 +22,14 @@ done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_sq1 -- python3 $R/tools/gemm_prof.py gemm 2048 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $OUT/${TAG}_pmc_sq2 -- python3 $R/tools/gemm_prof.py gemm 2048 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
 echo "sq counters done"
+# mid-M split-K kernel (csrc/midm.hip) at BASELINE configs[0]'s shape: kernel trace of the dispatch over a few token counts,
+# traffic and SQ counters at 128 tokens x 4096^2
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_midm_trace -- python3 $R/tools/midm_bench.py --ms 64,128,192 --paths auto --no-torch > $OUT/${TAG}_midm_trace.txt 2>> $OUT/${TAG}_pmc.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_midm_${c} -- python3 $R/tools/gemm_prof.py midm 128 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
+done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${TAG}_midm_sq -- python3 $R/tools/gemm_prof.py midm 128 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
+echo "midm done"
 # BASELINE configs[4] arms at M = 32768: FETCH / WRITE / MFMA-busy per weight layout (4096^2 Linear)
 for lay in mixed w2g16 w4row; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_c5_${lay}_FETCH -- python3 $R/tools/gemm_prof.py gemm 32768 4096 4096 4 $lay > /dev/null 2>> $OUT/${TAG}_pmc.err
