@@ -512,7 +512,7 @@ def test_linear_empty_and_nonfinite_inputs(dev):
     p, w16, g = _packed_case(dev, 256, 4096, 11)
     assert packing.linear(torch.empty(0, 4096, dtype=torch.float16, device=dev), p).shape == (0, 256)
     assert packing.linear(torch.empty(2, 0, 4096, dtype=torch.float16, device=dev), p).shape == (2, 0, 256)
-    for M, path in ((3, "gemv"), (100, "gemm1"), (300, "gemm9"), (700, "gemm8")):
+    for M, path in ((3, "gemv"), (100, "gemm1"), (300, "gemm9"), (700, "gemm8"), (100, "midm"), (150, "auto"), (600, "midm")):
         x = torch.randn(M, 4096, generator=g).half()
         clean = packing.linear(x.to(dev), p, path=path)
         x[1, 7] = float("nan")

@@ -71,6 +71,14 @@ def main():
         print(f"{name:13s}: median {pct(d, .5):.2f}  p10 {pct(d, .1):.2f}  p90 {pct(d, .9):.2f}  max {d.max():.2f} us")
     print(f"finish       : median {pct(rel[:, 3], .5):.2f}  p10 {pct(rel[:, 3], .1):.2f}  p90 {pct(rel[:, 3], .9):.2f}  "
           f"max {rel[:, 3].max():.2f} us after the first start")
+    # who finishes late?  blocks b and b + 8 share an XCD (label b % 8); blocks are dealt to CUs in order
+    fin = rel[:, 3]
+    by_xcd = [fin[e::8] for e in range(8)]
+    print("finish by XCD label (median / max us): " + "  ".join(f"{e}: {pct(v, .5):.1f}/{v.max():.1f}" for e, v in enumerate(by_xcd)))
+    q = max(1, nwg // 8)
+    print("finish by launch-order octile (median us): " + "  ".join(f"{pct(fin[i * q:(i + 1) * q], .5):.1f}" for i in range(8)))
+    st = rel[:, 1] - rel[:, 0]
+    print("stage-x by XCD label (median / max us):  " + "  ".join(f"{e}: {pct(st[e::8], .5):.1f}/{st[e::8].max():.1f}" for e in range(8)))
     late = (rel[:, 0] > pct(rel[:, 3], .1)).sum().item()
     print(f"workgroups that start after the first 10 % have finished (a second round): {late}")
 
