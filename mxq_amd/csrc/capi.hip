@@ -216,9 +216,9 @@ int mxq_linear_f16_hoisted(const void* x, const void* qweight, const void* rowme
 }
 
 // Token counts served by the mid-M split-K kernel (midm.hip): above the skinny kernel's range, below the point
-// where the prefill kernel's 256 x 128 tiles win again -- from 256 tokens on at every Llama shape
+// where the prefill kernel's 256 x 128 tiles win again -- beyond 256 tokens at every Llama shape
 // (tools/midm_bench.py, profiles/r03_midM.txt)
-static const int MIDM_MAX_TOKENS = 192;
+static const int MIDM_MAX_TOKENS = 256;
 
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream) {

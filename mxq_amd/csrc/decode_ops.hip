@@ -262,10 +262,21 @@ __global__ __launch_bounds__(64) void lmhead_final_kernel(const float* __restric
     const int lane = threadIdx.x;
     float best = -INFINITY;
     int besti = 0x7FFFFFFF;
-    for (int i = lane; i < n; i += 64) {
-        const float v = part_val[i];
-        const int ix = part_idx[i];
-        if (v > best || (v == best && ix < besti)) { best = v; besti = ix; }
+    // n <= 1024 partials (launcher): all of a lane's 16 loads go out together (clamped, never branched around) instead
+    // of one dependent round trip per iteration (7.3 -> ~2 us of every token)
+    float pv[16];
+    int pi[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = lane + 64 * k;
+        const int ic = i < n ? i : n - 1;
+        pv[k] = part_val[ic];
+        pi[k] = part_idx[ic];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const bool live = lane + 64 * k < n;
+        if (live && (pv[k] > best || (pv[k] == best && pi[k] < besti))) { best = pv[k]; besti = pi[k]; }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {

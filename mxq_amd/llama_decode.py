@@ -113,20 +113,23 @@ class DecodeStage:
     def embed_token(self, tok):
         return self.embed.index_select(0, tok)
 
-    def head(self, h):
+    def head(self, h, out: Optional[torch.Tensor] = None):
         """Final RMSNorm + lm_head + greedy argmax -> token id tensor [1] (int64).  Fused stages of Llama width run it
-        as one native launch pair (csrc/decode_ops.hip, mxq_lmhead_argmax_f16); otherwise plain torch ops."""
+        as one native launch pair (csrc/decode_ops.hip, mxq_lmhead_argmax_f16); otherwise plain torch ops.
+        ``out`` (int64 [1], device): where the native pair writes the id -- the token loop passes its token buffer and
+        saves a copy launch per token."""
         if self.fused and self.hidden == 4096 and h.shape[0] == 1:
             if self._head_ws is None:
                 self._head_ws = torch.empty(2 * 1024, dtype=torch.float32, device=self.dev)
                 self._head_tok = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            tok = out if out is not None and out.dtype == torch.int64 and out.numel() == 1 and out.is_contiguous() else self._head_tok
             hc = h.contiguous()
             lib = _lib.load()
             _lib.check(lib.mxq_lmhead_argmax_f16(hc.data_ptr(), self.norm_w.data_ptr(), 1e-5, self.lm_head.data_ptr(),
                                                  self.lm_head.shape[0], self.hidden, self._head_ws.data_ptr(), 1024,
-                                                 self._head_tok.data_ptr(),
+                                                 tok.data_ptr(),
                                                  torch.cuda.current_stream(self.dev).cuda_stream), "mxq_lmhead_argmax_f16")
-            return self._head_tok
+            return tok
         logits = torch.nn.functional.linear(self._rms(h), self.lm_head)
         return logits.argmax(dim=-1)
 
@@ -203,7 +206,9 @@ class DecodeStage:
             raise ValueError("capture_token_loop needs the first and the last stage in one process")
 
         def one():
-            token_buf.copy_(self.head(self.step(self.embed_token(token_buf))).reshape(-1)[:1])
+            t = self.head(self.step(self.embed_token(token_buf)), out=token_buf)
+            if t is not token_buf:
+                token_buf.copy_(t.reshape(-1)[:1])
         for _ in range(2):
             one()
         self.pos.zero_()

@@ -32,7 +32,7 @@ def _stream(t: torch.Tensor) -> int:
 _WORKSPACES: Dict[tuple, torch.Tensor] = {}
 _WS_EAGER: Dict[tuple, bool] = {}    # key -> the buffer was created AND zeroed outside any graph capture
 _WS_HEAD = 65536      # bytes of K-step counters at the head of a workspace (include/mxq_hip.h)
-MIDM_MAX_TOKENS = 192     # capi.hip: token counts that mxq_linear_f16_ws hands to the mid-M split-K kernel (no counters)
+MIDM_MAX_TOKENS = 256     # capi.hip: token counts that mxq_linear_f16_ws hands to the mid-M split-K kernel (no counters)
 
 
 def gemm_workspace(device: torch.device, counters: bool = True) -> torch.Tensor:
