@@ -1,0 +1,1115 @@
+// W2/4 x A16 dequant-GEMM for prefill (any token count > 8): MFMA waves own the activation stream, dedicated waves
+// own ALL of the dequant; persistent over tiles, hybrid stream-K tail.
+//
+// Counterpart of the reference's (never built) AWQ tensor-core GEMM
+// mxq_quant/cuda_kernel/csrc/quantization/gemm_cuda_gen.cu:28-218 and of the implicit nn.Linear on the
+// fake-quant weight (mxq_quant/main.py:85); arithmetic contract x16 . fp16(scale * (q - zero))^T of
+// lib/quantizer.py:19-20 + mxqgpt.py:448, fp32 accumulation.
+//
+// Tile 256 tokens x 128 channels x K-step 64 (= one MXQ chunk); 12 waves with fixed roles:
+//   * waves 0-7  "MFMA waves" (one 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_f16 each): fragment reads + 32 MFMAs
+//     per K-step, and the x tile's LDS-DMA (4 x 1 KiB buffer_load ... lds each per K-step, addressed by one
+//     per-lane offset VGPR each + a scalar K offset; rows beyond M read as zeros through the buffer descriptor's
+//     range check) -- no VALU work in the loop at all.  (Round 1's kernel put the 2-bit dequant, ~48 VALU ops per
+//     K-step, INSIDE the MFMA waves' instruction streams: an in-order wave that carries VALU chains between its
+//     MFMAs stalls its MFMAs on them, and both MFMA waves of a SIMD do so in lockstep.)
+//   * waves 8-11 "dequant waves" (one per SIMD): the whole dequant (2-bit LUT / v_perm groups and the 4-bit arm)
+//     into the fp16 W16 tile.  The packed words come straight from global memory into registers (6-7 dword loads
+//     per thread and chunk through the tile's buffer descriptor), a GROUP of 3 chunks at a time; a burst converts the
+//     whole group into result registers and issues the next group's loads, the 3 K-steps after it only write one
+//     chunk each into the W16 double buffer (deq_segment_h: why bursts).  Raised issue priority, scalar fp32 ops
+//     (no SLP packing: Makefile).
+//   * one raw s_barrier per K-step; x ring 3 slots (DMA two steps ahead, counted vmcnt), W16 double buffer
+//     (hoisted-dequant mode: a 3-slot ring of fp16 weight tiles instead): 144 KiB of LDS.  D^T = W . x^T: a lane
+//     owns 4 consecutive channels of a token.
+//   * the output leaves without an LDS round trip (store_tile_xpose), so a workgroup that runs several tiles issues
+//     the next tile's first DMAs behind the last barrier of this one and they fly under its epilogue.
+//
+// Grid = min(tiles, CUs) persistent workgroups dealing whole tiles round-robin + (with a workspace) one stream-K
+// workgroup per CU for the tiles beyond the last full round ("tail"): their K-steps are dealt evenly, XCD by XCD
+// (tail tile t belongs to XCD t & 7; an XCD's 32 units share its tail tiles so the operands stay in that L2).  A
+// unit's K range covers the end of one tile and the start of the next; each piece ("segment") runs the same pipeline
+// on a shifted K window.  A segment that does not cover its tile's whole K leaves its fp32 accumulators in a
+// workspace slot and, after the unit's last segment, bumps a per-(tile, wave) K-step counter; the wave whose bump
+// completes the count sums the slots in unit order (its own re-read from the slot) -- a fixed order, so the
+// result does not depend on which wave finishes -- writes fp16 y and re-zeroes the counter.  Nobody ever waits on
+// another workgroup.  Slots and counters cross XCDs (one L2 each): slot traffic is agent-scope relaxed atomics
+// (global_store / load ... sc1), ordered against the counter bump by s_waitcnt vmcnt(0).
+#include <hip/hip_runtime.h>
+
+#include "mxq_dequant.h"
+#include "mxq_format.h"
+#include "mxq_kernels.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 256, BN = 128, BK = 64;
+constexpr int N_MMA = 8, N_DEQ = 4, THREADS = (N_MMA + N_DEQ) * 64;
+constexpr int A_STAGE = BM * BK * 2, A_SLOTS = 3;
+constexpr int W_STAGE = BN * BK * 2;
+constexpr int OFF_A = 0;
+constexpr int OFF_W = OFF_A + A_SLOTS * A_STAGE;
+// hoisted-dequant mode: a 3-slot ring of fp16 weight tiles in the place of the W16 double buffer
+constexpr int OFF_WD = OFF_W, WD_SLOTS = 3;
+constexpr int OFF_FLAGS = OFF_WD + WD_SLOTS * W_STAGE;      // progress words of the flag-synchronised steps (below)
+constexpr int SMEM_BYTES = OFF_FLAGS + 128;
+static_assert(OFF_W + 2 * W_STAGE <= OFF_FLAGS && SMEM_BYTES <= 160 * 1024, "LDS budget");
+constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K] matrix (never part of the C ABI)
+
+// profiling-only switches (template parameter ABL; the product library instantiates ABL = 0 only, and the stamp / ballast
+// code exists only under MXQ_PROFILING: libmxq_hip_prof.so)
+[[maybe_unused]] constexpr int ABL_NO_MFMA = 2, ABL_NO_DEQ = 4, ABL_NO_XDMA = 1, ABL_NO_STORE = 256;
+// 16: the dequant waves skip the 4-bit arm (its loads and its conversion); 32: the OLDER MFMA wave of each SIMD (waves 0-3)
+// carries 30 independent VALU ops per K-step -- what taking that arm over would cost it.  Timing only.
+[[maybe_unused]] constexpr int ABL_NO_Q4 = 16, ABL_MMA_VALU = 32;
+// scheduling experiments (correct results): issue priorities of the two roles
+[[maybe_unused]] constexpr int EXP_NO_PRIO = 1024, EXP_MMA_PRIO = 2048, EXP_STAMPS = 4096;
+// EXP_BARRIER: every K-step ends in the workgroup barrier (the round-2 kernel); default: progress flags (below)
+[[maybe_unused]] constexpr int EXP_BARRIER = 8192;
+
+// ------------------------------------------------------------------------------------------------
+// K-steps without a workgroup barrier (round 3)
+// ------------------------------------------------------------------------------------------------
+// With one s_barrier per K-step every wave waits for the slowest of twelve in every step: the stamps of round 2 show the
+// older MFMA wave of a SIMD done after 857-940 cycles of a 1617-cycle step and parked ~700 at the barrier, while its
+// partner and the dequant wave are still working.  What the waves really depend on is narrower:
+//   an MFMA wave, before it reads step t:   the fp16 weight stage of step t published by all 4 dequant / DMA waves, and the
+//                                           x rows of step t landed -- its own DMAs and those of the ONE other wave that
+//                                           fills rows of the same 64-token band (wave ^ 1);
+//   before it refills x slot (t + 2) % 3:   that same partner done reading step t - 1;
+//   a dequant wave, before it overwrites weight stage (t + 1) & 1: all 8 MFMA waves done reading step t - 1.
+// So inside a segment the steps 1 .. NT - 2 synchronise through monotonic progress words in LDS, one per wave, written by
+// lane 0 after the wave's own counted wait and polled (one ds_read_b128 / b32, s_sleep) by the waves that depend on it:
+//   dq[d] = 1 + last weight stage published by dequant / DMA wave d,   mm[w] = 1 + last step MFMA wave w has read completely,
+//   xd[w] = 1 + last x step whose rows wave w's DMAs have landed.
+// LDS accesses of a wave execute in order, so data written before the progress word is visible to whoever has seen the
+// word.  Step 0, the last step of a segment and the prologue keep their barriers (the ring is handed over to the next
+// tile / segment there), and every wave (re)initialises its words before step 0's barrier.  Nobody can wait in a cycle:
+// every wait is for an EARLIER step of another wave.
+constexpr int FLG_DQ = 0, FLG_MM = 4, FLG_XD = 12;       // word offsets inside the flag block
+__device__ __forceinline__ void flag_set(char* smem, int word, uint32_t v, int lane) {
+    if (lane == 0) *(volatile uint32_t*)(smem + OFF_FLAGS + word * 4) = v;
+}
+__device__ __forceinline__ void flag_wait1(const char* smem, int word, uint32_t need) {
+    for (;;) {
+        const uint32_t v = *(const volatile uint32_t*)(smem + OFF_FLAGS + word * 4);
+        if (__builtin_amdgcn_readfirstlane(v) >= need) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+template <int WORDS>   // 4 or 8 consecutive words starting at a 16-byte aligned one: all of them >= need
+__device__ __forceinline__ void flag_wait_all(const char* smem, int word, uint32_t need) {
+    for (;;) {
+        u32x4 v = *(const volatile u32x4*)(smem + OFF_FLAGS + word * 4);
+        uint32_t m = min(min(v[0], v[1]), min(v[2], v[3]));
+        if constexpr (WORDS == 8) {
+            v = *(const volatile u32x4*)(smem + OFF_FLAGS + word * 4 + 16);
+            m = min(m, min(min(v[0], v[1]), min(v[2], v[3])));
+        }
+        if (__builtin_amdgcn_readfirstlane(m) >= need) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+
+// LDS-DMA through a buffer descriptor: 16 B per lane, LDS destination = wave-uniform base + 16 * lane;
+// global source = descriptor base + voff (per lane) + soff (scalar); out-of-range sources deliver zeros
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ void bufdma16(rsrc_t rsrc, uint32_t voff, uint32_t soff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+
+// XCD-aware tile order (speed only): tiles are dealt to the 8 XCDs as compact 2-D blocks (4 x 2 regions)
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0) {
+        const int e = bid & 7, l = bid >> 3;
+        const int rm = tiles_m >> 2, rn = tiles_n >> 1;
+        const int full = rm * 16;
+        const int p = l / full;
+        const int j = l - p * full;
+        const int left = rn - p * 16;
+        const int pw = left < 16 ? left : 16;
+        tm = (e & 3) * rm + j / pw;
+        tn = (e >> 2) * rn + p * 16 + j % pw;
+        return;
+    }
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tm = lin % tiles_m;
+    tn = lin / tiles_m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream-K bookkeeping (protocol: header)
+// ------------------------------------------------------------------------------------------------
+struct SkSeg {
+    float* ws;        // partial slots: [unit = 8u+e][2][BM*BN] fp32
+    int* cnt;         // K-step counters: [tail tile = 8j+e][N_MMA waves]
+    int u, e, units;  // this unit, its XCD, units per XCD
+    int S;            // K-steps in one XCD's tail = tail tiles per XCD * NT
+    int j;            // tile index inside the XCD's tail
+    int first;        // 1: the segment starts at the unit's range start (slot 0), else slot 1
+};
+// A wave's 16 KB slot, 16 bytes per lane and fragment: ONE sc1 (write-through / L1-bypassing) 16-byte access per fragment,
+// 1 KB contiguous per instruction.  (Round 2 began with two 8-byte agent-scope atomics per fragment: 8-byte accesses run at
+// 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md; nothing here needs atomicity -- a slot is read only after the
+// K-step count that its writer bumped behind s_waitcnt vmcnt(0) is complete.)
+__device__ __forceinline__ void st_agent(float* slot, int f, int lane, f32x4 v) {
+    const rsrc_t r = make_rsrc(slot, 16384u);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (uint32_t)(f * 64 + lane) * 16u, 0u, 16);
+}
+__device__ __forceinline__ f32x4 ld_agent(const float* slot, int f, int lane) {
+    const rsrc_t r = make_rsrc(slot, 16384u);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (uint32_t)(f * 64 + lane) * 16u, 0u, 16));
+}
+__device__ __forceinline__ int sk_bound(int u, int S, int units) { return (int)((uint32_t)u * (uint32_t)S / (uint32_t)units); }
+
+// ------------------------------------------------------------------------------------------------
+// MFMA waves
+// ------------------------------------------------------------------------------------------------
+typedef half8 Frag4[4];
+
+// DENSE: the weight tile is a 3-slot ring of fp16 tiles filled by LDS-DMA (hoisted-dequant mode, below) instead of the
+// double buffer the dequant waves write
+template <bool DENSE>
+__device__ __forceinline__ void load_frags(const char* smem, int t, int kk, int wm, int wn, int fr, int fq, Frag4& wf,
+                                           Frag4& xf) {
+    const char* a_base = smem + OFF_A + (t % A_SLOTS) * A_STAGE;
+    const char* w_base = DENSE ? smem + OFF_WD + (t % WD_SLOTS) * W_STAGE : smem + OFF_W + (t & 1) * W_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(w_base + swz(wn * 64 + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz(wm * 64 + j * 16 + fr, kk * 4 + fq));
+}
+
+template <int I0, int I1, int ABL>
+__device__ __forceinline__ void mfma_rows(f32x4 (&acc)[4][4], const Frag4& wf, const Frag4& xf) {
+#pragma unroll
+    for (int i = I0; i < I1; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (ABL & ABL_NO_MFMA) asm volatile("" ::"v"(wf[i]), "v"(xf[j]));
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+}
+
+// the x tile of K-step t: wave w fills rows 32w .. 32w+31 of slot t % 3 with 4 DMAs of 8 full 128-B rows;
+// lane -> (row 8i + lane / 8, 16-B chunk lane % 8), source chunk XOR-swizzled so that the fragment reads are
+// conflict-poor (swz above).  voff[i] = that row's byte offset from the tile's first row + the chunk.
+struct XDma {
+    rsrc_t rsrc;         // x rows m0 .. of this tile (range-checked: rows beyond M read as zeros)
+    uint32_t voff[4];
+    uint32_t k0;         // byte offset of the segment's first K-step inside a row
+};
+template <int I0, int I1>
+__device__ __forceinline__ void issue_x(const XDma& d, char* smem, int wave, int t) {
+    char* dst = smem + OFF_A + (t % A_SLOTS) * A_STAGE + wave * 4096;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) bufdma16(d.rsrc, d.voff[i], d.k0 + (uint32_t)t * (BK * 2), dst + i * 1024);
+}
+
+#define MXQ_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// diagnostic builds only (libmxq_hip_prof.so, EXP_STAMPS): cycle stamps around the phases of a K-step; sums leave through the workspace
+typedef unsigned long long u64t;
+struct Stamps { u64t work, wait, bar, n; };
+#ifdef MXQ_PROFILING
+__device__ __forceinline__ u64t stamp() {
+    u64t t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MXQ_STAMPS(ABL) (((ABL) & EXP_STAMPS) != 0)
+#else
+__device__ __forceinline__ u64t stamp() { return 0; }
+#define MXQ_STAMPS(ABL) false      /* the product build carries no stamp code */
+#endif
+
+// One K-step t >= 1: MFMAs of (t-1, kk=1) and (t, kk=0), fragment reads of step t, and -- ISSUE -- the x DMAs of
+// step t+2 (slot (t+2) % 3 was last read in step t-1), spread behind groups of MFMAs.
+// WAITF: the step's inputs are awaited through the progress words (every step >= 1 of a flag build: the step before it
+// may have ended without a barrier); FLAGS: it also ENDS by publishing its progress instead of the barrier (steps 1 .. NT - 2)
+template <int ABL, bool ISSUE, bool DENSE, bool FLAGS, bool WAITF = FLAGS>
+__device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, int wn, int fr, int fq, const XDma& xd,
+                                         f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1, Frag4& xf1,
+                                         Stamps& st, int lane) {
+    u64t t0 = 0, t1 = 0, t2 = 0;
+    if constexpr (WAITF) {
+        flag_wait_all<4>(smem, FLG_DQ, (uint32_t)t + 1);          // weight stage of step t published
+        flag_wait1(smem, FLG_XD + (wave ^ 1), (uint32_t)t + 1);   // the band partner's x rows of step t landed
+    }
+    if constexpr (MXQ_STAMPS(ABL)) t0 = stamp();
+    mfma_rows<0, 1, ABL>(acc, wf1, xf1);
+    MXQ_FENCE();
+    load_frags<DENSE>(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
+    MXQ_FENCE();
+    mfma_rows<1, 2, ABL>(acc, wf1, xf1);
+    MXQ_FENCE();
+    if constexpr (ISSUE && FLAGS) flag_wait1(smem, FLG_MM + (wave ^ 1), (uint32_t)t);   // slot (t+2)%3: the partner has read step t-1
+    if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) issue_x<0, 2>(xd, smem, wave, t + 2);
+    MXQ_FENCE();
+    mfma_rows<2, 4, ABL>(acc, wf1, xf1);
+    MXQ_FENCE();
+    load_frags<DENSE>(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
+    MXQ_FENCE();
+    mfma_rows<0, 2, ABL>(acc, wf0, xf0);
+    MXQ_FENCE();
+#ifdef MXQ_PROFILING
+    if constexpr ((ABL & ABL_MMA_VALU) != 0) {
+        if (wave < 4) {
+            float b0 = (float)t, b1 = b0 + 1.f, b2 = b0 + 2.f, b3 = b0 + 3.f, b4 = b0 + 4.f;
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1\n\tv_add_f32 %2, %2, %2\n\tv_add_f32 %3, %3, %3\n\tv_add_f32 %4, %4, %4"
+                             : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4));
+            asm volatile("" ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4));
+        }
+    }
+#endif
+    MXQ_FENCE();
+    if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) issue_x<2, 4>(xd, smem, wave, t + 2);
+    MXQ_FENCE();
+    mfma_rows<2, 4, ABL>(acc, wf0, xf0);
+    if constexpr (MXQ_STAMPS(ABL)) t1 = stamp();
+    // this step's 4 DMAs stay in flight across the barrier; the previous step's (x of step t+1) have landed
+    if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if constexpr (MXQ_STAMPS(ABL)) t2 = stamp();
+    if constexpr (FLAGS) {
+        flag_set(smem, FLG_XD + wave, (uint32_t)t + 2, lane);   // x(t + 1) rows of this wave have landed (vmcnt above)
+        flag_set(smem, FLG_MM + wave, (uint32_t)t + 1, lane);   // step t read completely (lgkmcnt above)
+    } else {
+        __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (MXQ_STAMPS(ABL)) {
+        const u64t t3 = stamp();
+        st.work += t1 - t0; st.wait += t2 - t1; st.bar += t3 - t2; st.n += 1;
+    }
+}
+
+__device__ __forceinline__ void store_tile(const f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N, int m0,
+                                           int n0, int wm, int wn, int fr, int fq) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fq * 4;
+            if (n >= N) continue;
+            half4 h = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2],
+                       (_Float16)acc[i][j][3]};
+            *(half4*)(y + (int64_t)m * N + n) = h;
+        }
+    }
+}
+
+// The tile WITHOUT an LDS round trip: a lane's accumulators are 4 channels (8 B as fp16) of W-fragment block i for
+// each of 4 token blocks j; the 4 lanes {fr, fr+16, fr+32, fr+48} hold one token's 64 channels as a 4 x 4 grid of
+// 8-byte cells (block i, quarter fq).  Two butterfly stages of lane swaps (v_permlane32_swap: lanes +-32 <-> blocks
+// +-2; v_permlane16_swap: lanes +-16 <-> blocks +-1) transpose the grid, after which lane fq owns block fq whole:
+// 32 contiguous bytes = two 16-byte stores, and the 4 lanes together write the token's full 128-B line.  Needs no
+// LDS, so the x ring can be refilled for the NEXT tile while this one is still being written (persistent loop).
+__device__ __forceinline__ void store_tile_xpose(const f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N,
+                                                 int m0, int n0, int wm, int wn, int fr, int fq) {
+    typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+    const int n = n0 + wn * 64 + fq * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t c[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            c[i][0] = mxq_pack_f16(acc[i][j][0], acc[i][j][1]);
+            c[i][1] = mxq_pack_f16(acc[i][j][2], acc[i][j][3]);
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            u32x2v r;
+            r = __builtin_amdgcn_permlane32_swap(c[0][d], c[2][d], false, false); c[0][d] = r[0]; c[2][d] = r[1];
+            r = __builtin_amdgcn_permlane32_swap(c[1][d], c[3][d], false, false); c[1][d] = r[0]; c[3][d] = r[1];
+            r = __builtin_amdgcn_permlane16_swap(c[0][d], c[1][d], false, false); c[0][d] = r[0]; c[1][d] = r[1];
+            r = __builtin_amdgcn_permlane16_swap(c[2][d], c[3][d], false, false); c[2][d] = r[0]; c[3][d] = r[1];
+        }
+        const int m = m0 + wm * 64 + j * 16 + fr;
+        if (m < M && n < N) {
+            uint16_t* dst = y + (int64_t)m * N + n;
+            *(u32x4*)dst = (u32x4){c[0][0], c[0][1], c[1][0], c[1][1]};
+            *(u32x4*)(dst + 8) = (u32x4){c[2][0], c[2][1], c[3][0], c[3][1]};
+        }
+    }
+}
+
+// The tile through LDS (the wave's own 9 KB of the idle x ring) so that it leaves as full 128-B lines, 16 B per
+// lane; only for workgroups that run a single whole tile (a stream-K unit's next segment may already be
+// refilling the ring).
+__device__ __forceinline__ void store_tile_staged(const f32x4 (&acc)[4][4], char* smem, uint16_t* __restrict__ y, int M,
+                                                  int N, int m0, int n0, int wave, int lane) {
+    constexpr int ROW = 144;   // 128 B of channels + 16 B: keeps the b128 reads aligned and spreads the banks
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    char* st = smem + OFF_A + wave * (64 * ROW);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            half4 h = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2],
+                       (_Float16)acc[i][j][3]};
+            *(half4*)(st + (j * 16 + fr) * ROW + (i * 16 + fq * 4) * 2) = h;
+        }
+    const int n = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const u32x4 v = *(const u32x4*)(st + row * ROW + (lane & 7) * 16);
+        const int m = m0 + wm * 64 + row;
+        if (m < M && n < N) *(u32x4*)(y + (int64_t)m * N + n) = v;
+    }
+}
+
+__device__ __forceinline__ void xdma_setup(XDma& xd, const uint16_t* __restrict__ x, int M, int K, int m0, int kt0,
+                                           int wave, int lane) {
+    const int rows = M - m0 < BM ? M - m0 : BM;                       // live rows of this tile
+    xd.rsrc = make_rsrc(x + (int64_t)m0 * K, (uint32_t)rows * (uint32_t)K * 2u);
+    xd.k0 = (uint32_t)kt0 * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        xd.voff[i] = (uint32_t)row * (uint32_t)K * 2u + ((((uint32_t)lane & 7u) ^ ((uint32_t)row & 7u)) << 4);
+    }
+}
+// a segment's prologue DMAs: x of its steps 0 and 1 (needs the whole x ring idle: every read of the previous
+// segment's slots lies before that segment's last barrier)
+template <int ABL>
+__device__ __forceinline__ void mma_prologue_issue(const XDma& xd, char* smem, int wave, int NT) {
+    if constexpr (!(ABL & ABL_NO_XDMA)) {
+        issue_x<0, 4>(xd, smem, wave, 0);
+        if (NT > 1) issue_x<0, 4>(xd, smem, wave, 1);
+    }
+}
+
+// One segment = NT K-steps of one tile.  pre: its prologue DMAs are already in flight (issued by the caller behind
+// the previous segment's last barrier; other VMEM traffic of this wave -- the previous tile's output stores -- may
+// sit in between, so the first wait is a full one).  After the last barrier, BEFORE the final 16 MFMAs and the
+// output, `next(...)` runs: the persistent loop issues the next tile's prologue DMAs there, which then fly under
+// this tile's epilogue.
+template <int ABL, bool DENSE, class Next>
+__device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int NT, const XDma& xd, bool pre,
+                                            uint16_t* __restrict__ y, int M, int N, int m0, int n0, int NT_tile,
+                                            const SkSeg& sk, Next&& next) {
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag4 wf0, xf0, wf1, xf1;
+
+    if (!pre) mma_prologue_issue<ABL>(xd, smem, wave, NT);
+    if (NT > 1 && !pre) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // prologue barrier 1: x tile 0 and packed blocks 0..3 landed
+    __builtin_amdgcn_s_barrier();   // prologue barrier 2: W16(0) written by the dequant waves
+
+    // step 0: no previous half
+    load_frags<DENSE>(smem, 0, 0, wm, wn, fr, fq, wf0, xf0);
+    load_frags<DENSE>(smem, 0, 1, wm, wn, fr, fq, wf1, xf1);
+    if (NT > 2) {
+        if constexpr (!(ABL & ABL_NO_XDMA)) issue_x<0, 4>(xd, smem, wave, 2);
+        mfma_rows<0, 4, ABL>(acc, wf0, xf0);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    } else {
+        mfma_rows<0, 4, ABL>(acc, wf0, xf0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    constexpr bool FLG = !(ABL & EXP_BARRIER);
+    if constexpr (FLG) {   // the state behind step 0's barrier: x(1) landed, step 0 read
+        flag_set(smem, FLG_XD + wave, 2u, lane);
+        flag_set(smem, FLG_MM + wave, 1u, lane);
+    }
+    __builtin_amdgcn_s_barrier();
+
+    int t = 1;
+    Stamps st = {0, 0, 0, 0};
+    u64t rt0 = 0;
+    if constexpr (MXQ_STAMPS(ABL)) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+    for (; t + 2 < NT; ++t) mma_step<ABL, true, DENSE, FLG>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st, lane);
+    if constexpr (MXQ_STAMPS(ABL)) {   // this workgroup's wave: {work, wait, barrier, steps} cycle sums
+        u64t rt1;                              // + the same span on the constant 100 MHz clock (high half of word 3): the core clock held
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+        if (lane == 0 && sk.ws) {
+            u64t* d = (u64t*)sk.ws + ((int64_t)blockIdx.x * (N_MMA + N_DEQ) + wave) * 4;
+            d[0] = st.work; d[1] = st.wait; d[2] = st.bar; d[3] = st.n | ((rt1 - rt0) << 32);
+        }
+    }
+    // the last two steps request nothing; the very last one ends in the barrier that hands the ring over
+    if (t + 1 < NT) { mma_step<ABL, false, DENSE, FLG>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st, lane); ++t; }
+    if (t < NT) mma_step<ABL, false, DENSE, false, FLG>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st, lane);
+    next();                                  // the ring is idle from here on
+    mfma_rows<0, 4, ABL>(acc, wf1, xf1);     // (NT-1, kk=1)
+
+    if (NT != NT_tile) {
+        // partial segment: park the accumulators in this unit's slot; counted in after the unit's last segment
+        float* mine = sk.ws + ((int64_t)((sk.u * 8 + sk.e) * 2 + (sk.first ? 0 : 1)) * (BM * BN)) + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st_agent(mine, i * 4 + j, lane, acc[i][j]);
+        return;
+    }
+    if constexpr (!(ABL & ABL_NO_STORE)) {
+        store_tile_xpose(acc, y, M, N, m0, n0, wm, wn, fr, fq);
+    } else {   // keep every accumulator alive without writing the tile
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_ += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (s_ == 123.456f) y[0] = 1;
+    }
+}
+
+// The wave that completed a tile's K-step count: sum every contributor's slot in unit order and write y.
+__device__ __forceinline__ void sk_finish(const SkSeg& sk, int j, int NT_tile, int wave, int lane, char* smem,
+                                          uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
+    const int lo = j * NT_tile, hi = lo + NT_tile;
+    int uf = 0;
+    while (uf + 1 < sk.units && sk_bound(uf + 1, sk.S, sk.units) <= lo) ++uf;
+    f32x4 acc[4][4];
+    bool any = false;
+    for (int v = uf; v < sk.units && sk_bound(v, sk.S, sk.units) < hi; ++v) {
+        const int vb = sk_bound(v, sk.S, sk.units);
+        if (sk_bound(v + 1, sk.S, sk.units) <= (vb > lo ? vb : lo)) continue;   // empty range: no slot was written
+        const float* src = sk.ws + ((int64_t)((v * 8 + sk.e) * 2 + (vb >= lo ? 0 : 1)) * (BM * BN)) + wave * 4096;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // 8 fragments (16 loads) in flight at a time
+            f32x4 p[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) p[i][jj] = ld_agent(src, (h * 2 + i) * 4 + jj, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[h * 2 + i][jj] = any ? acc[h * 2 + i][jj] + p[i][jj] : p[i][jj];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        any = true;
+    }
+    if (lane == 0)   // ready for the next launch
+        __hip_atomic_store(sk.cnt + (j * 8 + sk.e) * N_MMA + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    store_tile_xpose(acc, y, M, N, m0, n0, wave >> 1, wave & 1, lane & 15, lane >> 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dequant waves
+// ------------------------------------------------------------------------------------------------
+struct Deq {
+    char* smem;
+    rsrc_t rsrc;          // the WHOLE packed weight (one descriptor per launch: a per-tile one would have to be
+                          // selected between tiles, and a selected descriptor lives in VGPRs -- a waterfall loop around
+                          // every load).  Row-blocks are the outermost dimension, so a row-block beyond the weight's
+                          // last one lies beyond the buffer: zeros, whatever the K offset
+    uint32_t voff_blk;    // byte offset of the thread's row-block inside the packed weight; 0x80000000 = nothing to
+                          // load (the range check is on this offset; launcher: the weight is smaller than 2^31 bytes)
+    uint32_t k0;          // byte offset of the segment's first K-step inside a row-block's run
+    int d, lane, NT;
+    int row, r, h;        // W row of this thread (0..127), its row inside the block, column half (wave-uniform)
+    float s4, z4;
+    float4 rm;            // the row's 4-bit-arm parameters as loaded (rowmeta)
+};
+
+__device__ __forceinline__ void put8(char* wt, int row, int slot, const uint32_t* o) {
+    *(u32x4*)(wt + swz(row, slot)) = (u32x4){o[0], o[1], o[2], o[3]};
+}
+
+// The packed words one thread needs for one chunk.  h = 0: 2-bit groups 0, 1 (columns 0..31); h = 1: group 2 and the
+// 4-bit quarter (columns 32..63).  W2G16: h = 0 groups 0, 1; h = 1 groups 2, 3.  W4ROW: 4 code words each.
+struct Pk {
+    uint32_t c[4];    // code words
+    uint32_t z[2];    // 2-bit zero-points (fp32 bits; compact metadata: the fp16 halfword until widen_pk)
+    uint32_t scw;     // the row's scale codes
+    f32x2 qq[2];      // (qs, qz) of the thread's 2-bit groups
+};
+struct Pk4 {          // W4ROW: code words only (scale / zero come from rowmeta)
+    uint32_t c[4];
+};
+template <int LAYOUT>
+struct PkOf { typedef Pk type; };
+template <>
+struct PkOf<MXQ_LAYOUT_W4ROW> { typedef Pk4 type; };
+
+// They come STRAIGHT from global memory into registers, three K-steps before they are used (6-7 dword loads per
+// thread and chunk through the tile's buffer descriptor; 16 lanes of a row-block read 64 consecutive bytes).  Round 2
+// first had them copied into a 4-slot LDS ring by LDS-DMA and read back from there: the two DMA pieces per wave and
+// step cost their issuer 100-185 cycles apiece next to MFMAs, on the one wave per SIMD whose ~90-op chain is the
+// critical path of a K-step (-2..4 % per launch without them; bit-identical results).
+template <int LAYOUT, int H, bool NOQ4 = false>
+__device__ __forceinline__ void load_pk(const Deq& c, int t, typename PkOf<LAYOUT>::type& k) {
+    constexpr int BYTES = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : LAYOUT == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
+    // wave-uniform by construction; said explicitly, or a K offset selected between two tiles' descriptors counts as
+    // divergent and every load below gets a waterfall loop around it
+    const uint32_t so = __builtin_amdgcn_readfirstlane(c.k0 + (uint32_t)t * BYTES);
+    auto dw = [&](int idx) { return __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, c.voff_blk + (uint32_t)idx * 4u, so, 0); };
+    auto hw = [&](int idx) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(c.rsrc, c.voff_blk + (uint32_t)idx * 2u, so, 0); };
+    if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k.c[i] = dw(mxq_w4_c4(H * 2 + (i >> 1), i & 1, c.r));
+    } else {
+    constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC, COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
+    k.scw = hw(COMPACT ? mxqc_sc_u16(c.r) : mxq_sc_u16(c.r));
+    const int g0 = H * 2;   // first 2-bit group of this thread
+    auto zero_of = [&](int g) -> uint32_t {
+        if constexpr (COMPACT) return hw(mxqc_z2_u16(0, c.r) + g * 16);
+        else return dw((MIXED ? mxq_z2(0, c.r) : mxq_w2_z2(0, c.r)) + g * 16);
+    };
+    constexpr int QQ0 = COMPACT ? MXQC_OFF_QQ : MXQ_OFF_QQ;
+    k.c[0] = dw((MIXED ? mxq_c2(0, c.r) : mxq_w2_c2(0, c.r)) + g0 * 16);
+    k.z[0] = zero_of(g0);
+    k.qq[0] = (f32x2){__uint_as_float(dw(QQ0 + g0 * 2)), __uint_as_float(dw(QQ0 + g0 * 2 + 1))};
+    if (LAYOUT == MXQ_LAYOUT_W2G16 || H == 0) {
+        k.c[1] = dw((MIXED ? mxq_c2(1, c.r) : mxq_w2_c2(1, c.r)) + g0 * 16);
+        k.z[1] = zero_of(g0 + 1);
+        k.qq[1] = (f32x2){__uint_as_float(dw(QQ0 + g0 * 2 + 2)), __uint_as_float(dw(QQ0 + g0 * 2 + 3))};
+    } else if constexpr (!NOQ4) {
+        k.c[2] = dw(mxq_c4(0, c.r));
+        k.c[3] = dw(mxq_c4(1, c.r));
+    }
+    }
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void widen_pk(typename PkOf<LAYOUT>::type& k) {   // compact zero-points arrive as fp16 halfwords
+    if constexpr (LAYOUT == MXQ_LAYOUT_MIXEDC) {
+        k.z[0] = __float_as_uint((float)__builtin_bit_cast(_Float16, (uint16_t)k.z[0]));
+        k.z[1] = __float_as_uint((float)__builtin_bit_cast(_Float16, (uint16_t)k.z[1]));
+    }
+}
+
+// chunk t: preloaded packed words -> fp16 W16[t & 1]
+// chunk's packed words -> the thread's 32 fp16 weights (4 x 16 bytes: W16 slots s0 .. s0+3 of its row)
+template <int LAYOUT, int H, bool NOQ4 = false>
+__device__ __forceinline__ void convert_pk(const Deq& c, const typename PkOf<LAYOUT>::type& k, u32x4 (&res)[4]) {
+    uint32_t o[8];
+    if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            mxq_deq4x8(k.c[2 * q], c.s4, c.z4, o);
+            mxq_deq4x8(k.c[2 * q + 1], c.s4, c.z4, o + 4);
+            res[2 * q] = (u32x4){o[0], o[1], o[2], o[3]};
+            res[2 * q + 1] = (u32x4){o[4], o[5], o[6], o[7]};
+        }
+    } else {
+        const int g0 = H * 2;
+        mxq_deq2x16(k.c[0], mxq_scale(k.qq[0][0], k.qq[0][1], (k.scw >> (4 * g0)) & 15u), __uint_as_float(k.z[0]), o);
+        res[0] = (u32x4){o[0], o[1], o[2], o[3]};
+        res[1] = (u32x4){o[4], o[5], o[6], o[7]};
+        if (LAYOUT == MXQ_LAYOUT_W2G16 || H == 0) {
+            mxq_deq2x16(k.c[1], mxq_scale(k.qq[1][0], k.qq[1][1], (k.scw >> (4 * g0 + 4)) & 15u), __uint_as_float(k.z[1]), o);
+        } else if constexpr (!NOQ4) {
+            mxq_deq4x8(k.c[2], c.s4, c.z4, o);
+            mxq_deq4x8(k.c[3], c.s4, c.z4, o + 4);
+        }
+        res[2] = (u32x4){o[0], o[1], o[2], o[3]};
+        res[3] = (u32x4){o[4], o[5], o[6], o[7]};
+    }
+}
+// ... into W16[t & 1]: the thread's column half H = slots 4 H .. 4 H + 3
+template <int H>
+__device__ __forceinline__ void store_pk(const Deq& c, int t, const u32x4 (&res)[4]) {
+    char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(wt + swz(c.row, H * 4 + i)) = res[i];
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void deq_setup(Deq& c, char* smem, int wave, int lane, const uint32_t* __restrict__ qweight,
+                                          int N, int K, int n0, int kt0, int nsteps) {
+    constexpr int BLK_B = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : LAYOUT == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
+    const int NT_tile = K / BK;
+    c.smem = smem;
+    c.d = wave - N_MMA;
+    c.lane = lane;
+    c.NT = nsteps;
+    const uint32_t blk_stride = (uint32_t)NT_tile * BLK_B;   // bytes between consecutive row-blocks
+    c.rsrc = make_rsrc(qweight, (uint32_t)(N >> 4) * blk_stride);
+    c.k0 = (uint32_t)kt0 * BLK_B;
+    const int dt = c.d * 64 + lane;   // 0..255
+    c.row = dt & 127;
+    c.h = __builtin_amdgcn_readfirstlane(dt >> 7);   // wave-uniform: dequant waves 0,1 -> 0; 2,3 -> 1
+    c.r = c.row & 15;
+    c.voff_blk = (uint32_t)((n0 >> 4) + (c.row >> 4)) * blk_stride;
+}
+__device__ __forceinline__ void deq_none(Deq& c, const Deq& like) {   // a descriptor whose every load is out of range
+    c = like;
+    c.voff_blk = 0x80000000u;
+    c.k0 = 0;
+}
+
+// One segment on the dequant waves, R chunks at a time ("group").  A BURST waits for the group's R register sets
+// (loaded during the previous group's steps), converts all of them into result registers, and at once issues the loads
+// of the next group -- of this segment, or, after its last group, group 0 of `nxt` (the next tile of the persistent
+// loop, or nothing).  The following R K-steps only write one chunk's results into the W16 double buffer and meet the
+// barrier.  Why bursts instead of ~90 VALU ops in every step: next to MFMAs a VALU op of this wave issues at ~8-10
+// cycles, and the same ops interleaved into the MFMA waves' issue slots slow those down; in a burst step the MFMA
+// waves finish their step and wait at the barrier while the rest of the burst runs at full rate, and the R-1 steps
+// after it carry no VALU work at all (measured +3 % over the same work spread evenly, R = 3).
+// pre: the sets already hold / are loading chunks 0 .. R-1 (issued by the previous tile's last burst).
+template <int ABL, int LAYOUT, int H, int R>
+__device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const float4* __restrict__ rowmeta, int N, int n0,
+                                              bool pre, typename PkOf<LAYOUT>::type (&S)[R]) {
+    const int NT = c.NT;
+    u32x4 res[R][4];
+    auto load_group = [&](int base) {          // chunks base .. base+R-1 of this segment, or group 0 of nxt past its end
+        if constexpr (ABL & ABL_NO_DEQ) return;
+        const bool over = base >= NT;
+        Deq d = c;
+        d.voff_blk = over ? nxt.voff_blk : c.voff_blk;
+        d.k0 = over ? nxt.k0 : c.k0;
+        const int b0 = over ? 0 : base;
+#pragma unroll
+        for (int i = 0; i < R; ++i) load_pk<LAYOUT, H, (ABL & ABL_NO_Q4) != 0>(d, b0 + i, S[i]);
+    };
+    auto burst = [&](int base) {               // convert the loaded group, then fetch the one after it
+        if constexpr (!(ABL & ABL_NO_DEQ)) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                widen_pk<LAYOUT>(S[i]);
+                convert_pk<LAYOUT, H, (ABL & ABL_NO_Q4) != 0>(c, S[i], res[i]);
+            }
+        }
+        load_group(base + R);
+    };
+    constexpr bool FLG = !(ABL & EXP_BARRIER);
+    // chunk q -> W16[q & 1] during step q - 1.  Steps 1 .. NT - 2 (chunks 2 .. NT - 1) synchronise through the progress
+    // words: the stage is free once all 8 MFMA waves have read step q - 2, and chunk q is announced behind its stores
+    auto put = [&](int q, const u32x4 (&r4)[4]) {
+        const bool flags = FLG && q >= 2;
+        if (flags) flag_wait_all<8>(c.smem, FLG_MM, (uint32_t)q - 1);
+        if constexpr (!(ABL & ABL_NO_DEQ)) store_pk<H>(c, q, r4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (flags) {
+            flag_set(c.smem, FLG_DQ + c.d, (uint32_t)q + 1, c.lane);
+        } else {
+            if (FLG && q == 1) flag_set(c.smem, FLG_DQ + c.d, 2u, c.lane);   // behind step 0's barrier chunk 1 is published
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    if (!pre) load_group(0);
+    int gn = n0 + c.row;
+    gn = gn < N ? gn : N - 1;
+    c.rm = rowmeta[gn];
+    __builtin_amdgcn_s_barrier();              // prologue barrier 1 (the MFMA waves' x tile 0 has landed)
+    c.s4 = mxq_scale(c.rm.z, c.rm.w, (uint32_t)c.rm.y);
+    c.z4 = c.rm.x;
+    burst(0);
+    put(0, res[0]);                            // prologue barrier 2: W16(0) written
+    // step t = q - 1 writes chunk q; the segment's last step (t = NT - 1) writes nothing
+    for (int base = 0; base < NT; base += R) {
+#pragma unroll
+        for (int i = 1; i < R; ++i)
+            if (base + i < NT) put(base + i, res[i]);
+        if (base + R < NT) {
+            burst(base + R);
+            put(base + R, res[0]);
+        }
+    }
+    __builtin_amdgcn_s_barrier();              // step NT - 1
+}
+
+// the column half a dequant wave works on is wave-uniform but not a constant: dispatch once, outside the loops
+constexpr int DEQ_R = 3;    // measured: R = 2 -5 %, 3 and 4 +2 % over per-step dequant; R = 4 spills at the 168-VGPR cap
+template <int ABL, int LAYOUT>
+__device__ __forceinline__ void deq_segment(Deq& c, const Deq& nxt, int wave, int lane, const float4* __restrict__ rowmeta,
+                                            int N, int n0, bool pre, typename PkOf<LAYOUT>::type (&S)[DEQ_R]) {
+    if (c.h == 0) deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+    else deq_segment_h<ABL, LAYOUT, 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// hoisted-dequant mode: waves 8-11 are plain DMA waves for an fp16 weight tile
+// ------------------------------------------------------------------------------------------------
+// When a launch covers many token tiles (M >= 8192), dequantising the same 128 x 64 weight tile once per 256 tokens
+// is the dominant avoidable cost: the dequant is then HOISTED out of the token loop -- the bit-exact dequant kernel
+// (pack.hip) writes fp16 weights into a scratch buffer once, and this kernel's waves 8-11 stream its tiles into a
+// 3-slot LDS ring (4 DMAs of 8 full 128-B rows per wave and K-step, source chunks XOR-swizzled like the x tile) two
+// steps ahead, exactly as the MFMA waves stream x.  Same MFMA loop, same barriers, same epilogue; the products and
+// their summation order are those of the fused mode, so the two modes agree bit for bit.
+struct WDma {
+    rsrc_t rsrc;         // weight rows n0 .. of this tile (range-checked: rows beyond N read as zeros)
+    uint32_t voff[4];
+    uint32_t k0;
+    int d, NT;
+};
+__device__ __forceinline__ void wdma_setup(WDma& w, const uint16_t* __restrict__ w16, int N, int K, int n0, int kt0,
+                                           int nsteps, int wave, int lane) {
+    const int rows = N - n0 < BN ? N - n0 : BN;
+    w.rsrc = make_rsrc(w16 + (int64_t)n0 * K, (uint32_t)rows * (uint32_t)K * 2u);
+    w.k0 = (uint32_t)kt0 * (BK * 2);
+    w.d = wave - N_MMA;
+    w.NT = nsteps;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = w.d * 32 + i * 8 + (lane >> 3);
+        w.voff[i] = (uint32_t)row * (uint32_t)K * 2u + ((((uint32_t)lane & 7u) ^ ((uint32_t)row & 7u)) << 4);
+    }
+}
+__device__ __forceinline__ void issue_w(const WDma& w, char* smem, int t) {
+    char* dst = smem + OFF_WD + (t % WD_SLOTS) * W_STAGE + w.d * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bufdma16(w.rsrc, w.voff[i], w.k0 + (uint32_t)t * (BK * 2), dst + i * 1024);
+}
+__device__ __forceinline__ void wdma_prologue_issue(const WDma& w, char* smem) {
+    issue_w(w, smem, 0);
+    if (w.NT > 1) issue_w(w, smem, 1);
+}
+// barrier-for-barrier the twin of deq_segment (prologue barriers 1, 2, step 0, the last step; the steps between
+// through the progress words: dq[d] = 1 + last weight step whose pieces of this wave have landed)
+template <int ABL, class Next>
+__device__ __forceinline__ void wdma_segment(const WDma& w, char* smem, bool pre, int lane, Next&& next) {
+    constexpr bool FLG = !(ABL & EXP_BARRIER);
+    if (!pre) wdma_prologue_issue(w, smem);
+    if (w.NT > 1 && !pre) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < w.NT; ++t) {
+        const bool flags = FLG && t >= 1 && t + 1 < w.NT;
+        if (t + 2 < w.NT) {
+            if (flags) flag_wait_all<8>(smem, FLG_MM, (uint32_t)t);    // slot (t+2) % 3: every MFMA wave has read step t-1
+            issue_w(w, smem, t + 2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // this step's 4 DMAs stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (flags) {
+            flag_set(smem, FLG_DQ + w.d, (uint32_t)t + 2, lane);       // W(t + 1) has landed
+        } else {
+            if (FLG && t == 0) flag_set(smem, FLG_DQ + w.d, 2u, lane);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    next();
+}
+
+#define MXQ_LANE_ID(ln) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln))
+
+// grid = dp_grid persistent workgroups, which deal the first dp_tiles tiles round-robin (tile = block + k * dp_grid:
+// blocks b and b + 8 share an XCD and dp_grid is a multiple of 8 or the tile count itself, so a workgroup's tiles
+// keep its XCD's label) and overlap one tile's output with the next one's first DMAs, + 8 * units stream-K
+// workgroups for the `tail` tiles beyond them.
+template <int ABL, int LAYOUT>
+__global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* __restrict__ x,
+                                                               const uint32_t* __restrict__ qweight,
+                                                               const float4* __restrict__ rowmeta,
+                                                               uint16_t* __restrict__ y, int M, int N, int K,
+                                                               int tiles_m, int tiles_n, int dp_tiles, int dp_grid,
+                                                               int tail, int units, float* __restrict__ ws,
+                                                               int* __restrict__ cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NT = K / BK;
+    const int bid = blockIdx.x;
+    SkSeg sk;
+    sk.ws = ws;
+    sk.cnt = cnt;
+    sk.units = units;
+    sk.S = 0;
+    sk.u = sk.e = sk.j = sk.first = 0;
+    auto nothing = [] {};
+    if (wave < N_MMA) {
+        if constexpr ((ABL & EXP_MMA_PRIO) != 0) __builtin_amdgcn_s_setprio(3);   // experiment: MFMA waves first
+    } else {
+        // the dequant chain is the longer one of a K-step: its VALU ops go first whenever they are ready (the MFMAs
+        // lose a 4-cycle issue slot each time, the chain would lose up to 16)
+        if constexpr (!(ABL & (EXP_NO_PRIO | EXP_MMA_PRIO))) __builtin_amdgcn_s_setprio(3);
+    }
+
+    if (bid < dp_grid) {
+        // ---- persistent data-parallel workgroup: whole tiles bid, bid + dp_grid, ...
+        int tm, tn;
+        tile_of_block(bid, tiles_m, tiles_n, tm, tn);
+        if (wave < N_MMA) {
+            int ln;
+            MXQ_LANE_ID(ln);
+            XDma cur, nxt;
+            xdma_setup(cur, x, M, K, tm * BM, 0, wave, ln);
+            mma_prologue_issue<ABL>(cur, smem, wave, NT);
+            for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
+                MXQ_LANE_ID(ln);   // recomputed per tile and opaque: nothing lane-derived is hoisted (and spilled) across the loop
+                const int m0 = tm * BM, n0 = tn * BN;
+                const bool more = tile + dp_grid < dp_tiles;
+                if (more) tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
+                mma_segment<ABL, LAYOUT == LAYOUT_DENSE16>(smem, wave, ln, NT, cur, true, y, M, N, m0, n0, NT, sk, [&] {
+                    if (more) {
+                        xdma_setup(nxt, x, M, K, tm * BM, 0, wave, ln);
+                        mma_prologue_issue<ABL>(nxt, smem, wave, NT);
+                    }
+                });
+                cur = nxt;
+            }
+        } else if constexpr (LAYOUT == LAYOUT_DENSE16) {
+            int ln;
+            MXQ_LANE_ID(ln);
+            WDma cur, nxt;
+            wdma_setup(cur, (const uint16_t*)qweight, N, K, tn * BN, 0, NT, wave, ln);
+            wdma_prologue_issue(cur, smem);
+            for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
+                MXQ_LANE_ID(ln);
+                const bool more = tile + dp_grid < dp_tiles;
+                if (more) tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
+                wdma_segment<ABL>(cur, smem, true, ln, [&] {
+                    if (more) {
+                        wdma_setup(nxt, (const uint16_t*)qweight, N, K, tn * BN, 0, NT, wave, ln);
+                        wdma_prologue_issue(nxt, smem);
+                    }
+                });
+                cur = nxt;
+            }
+        } else {
+            int ln;
+            MXQ_LANE_ID(ln);
+            Deq cur, nxt;
+            typename PkOf<LAYOUT>::type S[DEQ_R] = {};
+            deq_setup<LAYOUT>(cur, smem, wave, ln, qweight, N, K, tn * BN, 0, NT);
+            bool pre = false;                  // a tile's last burst loads the next tile's first group
+            for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
+                MXQ_LANE_ID(ln);
+                const int n0 = tn * BN;
+                const bool more = tile + dp_grid < dp_tiles;
+                if (more) {
+                    tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
+                    deq_setup<LAYOUT>(nxt, smem, wave, ln, qweight, N, K, tn * BN, 0, NT);
+                } else {
+                    deq_none(nxt, cur);
+                }
+                deq_segment<ABL, LAYOUT>(cur, nxt, wave, ln, rowmeta, N, n0, pre, S);
+                pre = true;
+                cur = nxt;
+            }
+        }
+        return;
+    }
+
+    // ---- stream-K unit u of XCD e: K-steps [b0, b1) of that XCD's tail tiles laid end to end
+    const int su = bid - dp_grid;
+    sk.e = su & 7;
+    sk.u = su >> 3;
+    const int base = dp_tiles + sk.e;
+    sk.S = ((tail + 7 - sk.e) >> 3) * NT;   // tail tile t belongs to XCD t & 7: the first tail % 8 XCDs hold one more
+    const int b0 = sk_bound(sk.u, sk.S, units), b1 = sk_bound(sk.u + 1, sk.S, units);
+    // every wave walks the same segment list, so the barrier counts of the two roles stay matched
+    if (wave < N_MMA) {
+        int pj0 = -1, pn0 = 0, pj1 = -1, pn1 = 0;
+        for (int pos = b0; pos < b1;) {
+            sk.j = pos / NT;
+            const int end = b1 < (sk.j + 1) * NT ? b1 : (sk.j + 1) * NT;
+            sk.first = pos == b0;
+            int tm, tn;
+            tile_of_block(base + sk.j * 8, tiles_m, tiles_n, tm, tn);
+            int ln;
+            MXQ_LANE_ID(ln);
+            XDma xd;
+            xdma_setup(xd, x, M, K, tm * BM, pos - sk.j * NT, wave, ln);
+            mma_segment<ABL, LAYOUT == LAYOUT_DENSE16>(smem, wave, ln, end - pos, xd, false, y, M, N, tm * BM, tn * BN, NT, sk, nothing);
+            if (end - pos != NT) {
+                if (sk.first) { pj0 = sk.j; pn0 = end - pos; }
+                else { pj1 = sk.j; pn1 = end - pos; }
+            }
+            pos = end;
+        }
+        if (pj0 >= 0 || pj1 >= 0) {
+            int ln;
+            MXQ_LANE_ID(ln);
+            // every slot store of this wave has reached the coherence point before any count moves
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int old0 = 0, old1 = 0;
+            if (ln == 0) {   // both bumps in flight together
+                if (pj0 >= 0) old0 = __hip_atomic_fetch_add(cnt + (pj0 * 8 + sk.e) * N_MMA + wave, pn0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pj1 >= 0) old1 = __hip_atomic_fetch_add(cnt + (pj1 * 8 + sk.e) * N_MMA + wave, pn1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            old0 = __builtin_amdgcn_readfirstlane(old0);
+            old1 = __builtin_amdgcn_readfirstlane(old1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler ordering only: the slot loads are agent-scope themselves
+            if (pj0 >= 0 && old0 + pn0 == NT) {
+                int tm, tn;
+                tile_of_block(base + pj0 * 8, tiles_m, tiles_n, tm, tn);
+                sk_finish(sk, pj0, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
+            }
+            if (pj1 >= 0 && old1 + pn1 == NT) {
+                int tm, tn;
+                tile_of_block(base + pj1 * 8, tiles_m, tiles_n, tm, tn);
+                sk_finish(sk, pj1, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
+            }
+        }
+    } else {
+        for (int pos = b0; pos < b1;) {
+            const int j = pos / NT;
+            const int end = b1 < (j + 1) * NT ? b1 : (j + 1) * NT;
+            int tm, tn;
+            tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
+            int ln;
+            MXQ_LANE_ID(ln);
+            if constexpr (LAYOUT == LAYOUT_DENSE16) {
+                WDma w;
+                wdma_setup(w, (const uint16_t*)qweight, N, K, tn * BN, pos - j * NT, end - pos, wave, ln);
+                wdma_segment<ABL>(w, smem, false, ln, nothing);
+            } else {
+                Deq c, none;
+                typename PkOf<LAYOUT>::type S[DEQ_R] = {};
+                deq_setup<LAYOUT>(c, smem, wave, ln, qweight, N, K, tn * BN, pos - j * NT, end - pos);
+                deq_none(none, c);
+                deq_segment<ABL, LAYOUT>(c, none, wave, ln, rowmeta, N, tn * BN, false, S);
+            }
+            pos = end;
+        }
+    }
+}
+
+int cu_count() {
+    static int cus = 0;   // one device model per process on this platform
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
+constexpr size_t CNT_BYTES = 64 * 1024;   // K-step counters at the head of the workspace (>= 8*units*N_MMA ints)
+
+template <int ABL, int LAYOUT = MXQ_LAYOUT_MIXED>
+static int launch8(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                   void* workspace, size_t ws_bytes, bool force, hipStream_t stream) {
+    // the DMA descriptors address one tile's rows with 32-bit offsets: 256 rows of x, 8 row-blocks of packed weights
+    // 32-bit offsets: 256 rows of x per DMA descriptor; the whole packed weight behind one (offsets < 2^31)
+    if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(N / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 31))
+        return -1;   // MXQ_E_SHAPE
+    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm8_f16_kernel<ABL, LAYOUT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
+    const int NT = K / BK;
+    const int cus = cu_count() / 8 * 8, units = cus / 8;
+    int dp_tiles = tiles, tail = 0;
+    if (workspace && tiles % cus != 0 && units * 8 * N_MMA * sizeof(int) <= CNT_BYTES &&
+        ws_bytes >= CNT_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
+        const int t8 = (tiles % cus) / 8;   // tail tiles per XCD (the first tail % 8 XCDs hold one more)
+        // Splitting the tail costs ~20 us (every unit parks 128 KB of fp32 partials, the finishers read them back)
+        // and saves the idle share of one tile time, (1 - tail/CUs) * NT K-steps of ~1 us: worth it from ~24 idle
+        // K-steps per CU (M = 512: 60 -> 37 us at 4096^2; NOT Llama's gate/up at M = 2048, tail 176 / 256, NT = 64)
+        const bool pays = (int64_t)(cus - tiles % cus) * NT >= (int64_t)24 * cus;
+        if ((force || pays) && (int64_t)t8 * NT >= (int64_t)units * 4) {
+            tail = tiles % cus;
+            dp_tiles = tiles - tail;
+        }
+    }
+    const int dp_grid = dp_tiles < cus ? dp_tiles : cus;   // persistent: at most one data-parallel workgroup per CU
+    const int grid = dp_grid + (tail ? cus : 0);
+    mxq_gemm8_f16_kernel<ABL, LAYOUT><<<grid, THREADS, SMEM_BYTES, stream>>>(
+        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
+        dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace);
+    return (int)hipGetLastError();
+}
+
+}   // namespace
+
+size_t mxq_gemm8_workspace_bytes() { return CNT_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
+
+int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                         void* workspace, size_t ws_bytes, int force, hipStream_t stream) {
+    return launch8<0>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, force != 0, stream);
+}
+
+int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                int layout, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    switch (layout) {
+        case MXQ_LAYOUT_MIXED: return launch8<0, MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
+        case MXQ_LAYOUT_W2G16: return launch8<0, MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
+        case MXQ_LAYOUT_W4ROW: return launch8<0, MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
+        case MXQ_LAYOUT_MIXEDC: return launch8<0, MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
+    }
+    return -1;
+}
+
+// hoisted-dequant mode: w16 = dense fp16 [N, K] weight (the dequant kernel's output); same tiles, no stream-K tail
+int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, hipStream_t stream) {
+    return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, false, stream);
+}
+
+#ifdef MXQ_PROFILING
+// Built only into libmxq_hip_prof.so (make prof; tools/): parts of the kernel removed to time the rest.
+// WRONG RESULTS by construction -- never part of libmxq_hip.so or of include/mxq_hip.h.
+// 1 = no x DMAs, 2 = no MFMA, 4 = no dequant, 256 = no output stores (sums)
+extern "C" int mxq_prof_gemm8_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+                                         int K, int abl, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (abl) {
+        case 0: return launch8<0>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 1: return launch8<1>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 2: return launch8<2>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 4: return launch8<4>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 5: return launch8<5>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 6: return launch8<6>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 256: return launch8<256>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 260: return launch8<260>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 1024: return launch8<1024>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // correct results
+        case 2048: return launch8<2048>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);   // correct results
+        case 2050: return launch8<2050>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 16: return launch8<16>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 32: return launch8<32>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 48: return launch8<48>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+    }
+    return -1;   // MXQ_E_SHAPE: not an ablation this build carries
+}
+
+// the hoisted mode's MFMA kernel alone on an already dequantised fp16 weight (the dense yardstick of tools/ab_gemm.py)
+extern "C" int mxq_prof_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, void* stream_) {
+    return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, false, (hipStream_t)stream_);
+}
+
+// Diagnostic build with cycle stamps (cdna guide section 7, "In-kernel stamps"): dbg receives, per workgroup and wave,
+// {work, wait, barrier, steps} cycle sums over the steady-state K-steps (u64 x 4 x 12 waves x grid).  Never timed.
+template <int ABL>
+static int launch8_stamps(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                          void* dbg, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm8_f16_kernel<ABL, MXQ_LAYOUT_MIXED>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    mxq_gemm8_f16_kernel<ABL, MXQ_LAYOUT_MIXED><<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
+        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
+        tiles_m * tiles_n, tiles_m * tiles_n, 0, 32, (float*)dbg, nullptr);
+    return (int)hipGetLastError();
+}
+extern "C" int mxq_prof_gemm8_stamps_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+                                         int K, int abl, void* dbg, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (abl) {
+        case 0: return launch8_stamps<4096>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
+        case 2048: return launch8_stamps<4096 + 2048>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
+        case 1024: return launch8_stamps<4096 + 1024>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
+        case 4: return launch8_stamps<4096 + 4>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
+        case 2: return launch8_stamps<4096 + 2>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
+    }
+    return -1;
+}
+#endif   // MXQ_PROFILING
