@@ -118,7 +118,8 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
 int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* workspace, size_t workspace_bytes, void* stream);
 /* mxq_linear_f16_ws for a weight in any layout (MXQ_LAYOUT_*: mixed with exact or compact metadata, W2G16, W4ROW).
- * Dispatch by token count: <= 4 the streaming GEMV, 5..48 the skinny MFMA kernel and 49..256 the mid-M split-K
+ * Dispatch by token count: <= 4 the streaming GEMV, then the skinny MFMA kernel (up to 40 tokens, 20 for weights of more
+ * than 24 M elements, where its time has overtaken the split-K kernel's) and up to 256 tokens the mid-M split-K
  * kernel (csrc/midm.hip: K cut into slices over the workgroups, fp32 partial tiles in the workspace beyond its first
  * 64 KiB, summed in slice order by a second launch -- the reference launcher's split_k_iters regime,
  * gemm_cuda_gen.cu:429-475) for the mixed layouts, the prefill kernel otherwise.  The mid-M kernel does not touch

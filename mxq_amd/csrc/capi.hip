@@ -219,6 +219,10 @@ int mxq_linear_f16_hoisted(const void* x, const void* qweight, const void* rowme
 // where the prefill kernel's 256 x 128 tiles win again -- beyond 256 tokens at every Llama shape
 // (tools/midm_bench.py, profiles/r03_midM.txt)
 static const int MIDM_MAX_TOKENS = 256;
+// ... and the token count up to which the skinny kernel (one workgroup per 16-row block, every wave reads all of x from
+// L2) still beats it: its time grows with tokens x weight size, the split-K kernel's is flat up to 64 tokens.  Measured
+// crossovers (profiles/r03_midM.txt): ~44 tokens at 4096^2, ~22 at 11008 x 4096 and 4096 x 11008.
+static int skinny_max_tokens(int N, int K) { return (int64_t)N * K > ((int64_t)24 << 20) ? 20 : 40; }
 
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream) {
@@ -246,7 +250,8 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-    if (M <= 48) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
+    if (M <= (workspace ? skinny_max_tokens(N, K) : 48))
+        return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
     if (M <= MIDM_MAX_TOKENS && workspace)
         return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
                                    (hipStream_t)stream);
@@ -262,7 +267,8 @@ int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* row
         return mxq_linear_f16_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, stream);
     if (M <= 4) return mxq_launch_gemv_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
     if (layout == MXQ_LAYOUT_MIXEDC) {
-        if (M <= 48) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
+        if (M <= (workspace ? skinny_max_tokens(N, K) : 48))
+            return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
         if (M <= MIDM_MAX_TOKENS && workspace)
             return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, 0, 0,
                                        (hipStream_t)stream);

@@ -282,7 +282,8 @@ GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm":
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
     """y = x @ dequant(p).T for x [..., K] fp16 -> [..., N] fp16 (fp32 accumulation).
 
-    path: "auto" (GEMV kernel for <= 4 tokens, skinny MFMA kernel for 5..48, prefill GEMM beyond), "gemm", "gemv",
+    path: "auto" (GEMV kernel for <= 4 tokens, skinny MFMA kernel up to 40 -- 20 for weights beyond 24 M elements --,
+    mid-M split-K kernel up to 256, prefill GEMM beyond: the C dispatch of mxq_linear_f16_ws), "gemm", "gemv", "midm",
     "skinny" (1..64 tokens), "hoist" (dequant hoisted out of the token loop; "auto" / "gemm" take it from
     HOIST_MIN_TOKENS tokens on), "fused" (never hoist), or an explicit GEMM
     kernel: "gemm1" (128x128 tile), "gemm8" (256x128 tile, wave-specialised, persistent, stream-K tail), "gemm9"
@@ -306,7 +307,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         return linear_hoisted(x, p, out=out)
     lib = _lib.load()
     args = (x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K)
-    if path == "skinny" or (p.compact and path == "auto" and 4 < M <= 48):
+    if path == "skinny":
         with torch.cuda.device(x.device):
             _lib.check(lib.mxq_skinny_f16(*args, 3 if p.compact else 0, _stream(x2)), "mxq_skinny_f16")
         return out.reshape(*x.shape[:-1], p.N)
@@ -314,7 +315,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         if path not in ("auto", "gemm", "gemv", "gemm8", "fused"):
             raise ValueError(f"path {path!r} is not available for compact metadata")
         with torch.cuda.device(x.device):
-            if path == "auto" and M > 48:       # mid-M split-K kernel up to MIDM_MAX_TOKENS, prefill kernel beyond
+            if path == "auto" and M > 4:        # skinny / mid-M split-K / prefill kernel by token count and weight size (capi.hip)
                 ws = gemm_workspace(x2.device, counters=M > MIDM_MAX_TOKENS)
                 _lib.check(lib.mxq_linear_f16_layout_ws(*args, 3, ws.data_ptr(), ws.numel(), _stream(x2)),
                            "mxq_linear_f16_layout_ws[compact]")

@@ -1,0 +1,26 @@
+"""BASELINE configs[2] end to end on ONE GPU box: the layer pipeline's greedy decode (LayerPipeline.decode +
+DecodeStage.step_graph + embed_token / head) at world 2 over gloo with both ranks sharing cuda:0, against the
+single-process decode of the same model -- token ids must be identical (tools/decode_bench.py --verify).  The launcher
+(torch.distributed.run) never touches the GPU; two worker processes do (well inside the box's process guard)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compact", [False, True])
+def test_decode_pipeline_world2_tokens_equal_single_process(compact):
+    env = dict(os.environ, MXQ_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533" if compact else "29532", os.path.join(ROOT, "tools", "decode_bench.py"), "--tokens", "12",
+           "--layers", "4", "--ctx", "64", "--verify"] + (["--compact"] if compact else [])
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["tokens_equal_single_process"] == 12 and d["backend"] == "gloo"
