@@ -83,12 +83,14 @@ int mxq_dequant_f16(const void* qweight, const void* rowmeta, void* w16, int N, 
  * The fused unpack + per-group scale/zero + W2/4 x A16 product behind a quantised
  * nn.Linear.  Counterpart of gemm_forward_cuda (gemm_cuda.h:3-4, MFMA path, any M) and of
  * gemv_mxq_forward_cuda (gemv_mxq_cuda.h:4-12, streaming path, chosen for M <= 4).
- * x, y, qweight must be 16-byte aligned; y must not alias x. */
+ * Without a workspace the K range is never split: streaming GEMV (M <= 4), skinny MFMA kernel (<= 64), mid-M kernel
+ * with one slice per tile (<= 256), prefill kernel with whole tiles beyond; mxq_linear_f16_ws is the fast entry for
+ * 20 < M <= 1024.  x, y, qweight must be 16-byte aligned; y must not alias x. */
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream);
 /* The code paths of mxq_linear_f16, exposed for benchmarking / testing: streaming GEMV (M <= 4), skinny MFMA kernel
- * (4 < M <= 48: every packed byte read once, a lane dequantises the MFMA operand it owns; the reference re-reads the
- * weights once per batch row, gemv_mxq_cuda.cu:261-262), prefill GEMM (M > 48).  mxq_skinny_f16 accepts 1 <= M <= 64
+ * (5..40 tokens in the dispatch: every packed byte read once, a lane dequantises the MFMA operand it owns; the reference
+ * re-reads the weights once per batch row, gemv_mxq_cuda.cu:261-262), prefill GEMM.  mxq_skinny_f16 accepts 1 <= M <= 64
  * and layout MXQ_LAYOUT_MIXED (0) or MXQ_LAYOUT_MIXEDC (3, compact metadata, below). */
 int mxq_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
                    void* stream);

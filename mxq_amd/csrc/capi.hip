@@ -228,8 +228,10 @@ int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void
                    void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-    if (M <= 48) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
-    if (M <= 256)   // no workspace: the mid-M kernel without its K split (one slice per tile)
+    // no workspace, no K split: the skinny kernel as far as it goes (64 tokens x 4096^2: 19.5 us; the 128 x 128-tile
+    // kernel took 57), then the mid-M kernel with one slice per tile (44-54 us at 4096^2: use the _ws entry where it matters)
+    if (M <= 64) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
+    if (M <= MIDM_MAX_TOKENS)
         return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, nullptr, 0, 0, 0, (hipStream_t)stream);
     return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
 }
