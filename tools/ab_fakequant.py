@@ -21,11 +21,14 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--libs", default="mxq_amd/libmxq_hip.so,abtmp/libmxq_hip_before.so")
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--shape", default=None, help="N,K: four weights of this one shape instead of the decoder block")
     args = ap.parse_args()
     dt = {"bf16": (torch.bfloat16, 2), "f16": (torch.float16, 1), "f32": (torch.float32, 0)}[args.dtype]
     dev = torch.device("cuda:0")
     H, I = LS.HIDDEN, LS.INTERMEDIATE
     shapes = [(H, H)] * 4 + [(I, H)] * 2 + [(H, I)]
+    if args.shape:
+        shapes = [tuple(int(v) for v in args.shape.split(","))] * 4
     g = torch.Generator(device=dev).manual_seed(0)
     ws = [(torch.randn(n, k, generator=g, device=dev) * 0.02).to(dt[0]) for n, k in shapes]
     outs = [torch.empty_like(w) for w in ws]
@@ -67,7 +70,7 @@ def main():
     for n in names:
         t = sorted(ts[n])
         med = t[len(t) // 2]
-        print(f"{n:40s}: {med:7.1f} us per decoder block ({nbytes / med / 1e6:.2f} TB/s of read + write), min {t[0]:.1f}")
+        print(f"{n:40s}: {med:7.1f} us per pass ({nbytes / med / 1e6:.2f} TB/s of read + write), min {t[0]:.1f}")
 
 
 if __name__ == "__main__":
