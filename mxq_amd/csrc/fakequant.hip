@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void mxq_fakequant_fwd_reg_kernel(const void* 
     for (int i = 0; i < NI; ++i) {
         const int e0 = (i * 64 + lane) * VEC;
         raw[i] = make_uint4(0, 0, 0, 0);
-        if (active && e0 < part) raw[i] = T::load_raw(w, base + e0);
+        if (active && e0 < part) raw[i] = T::load_raw_nt(w, base + e0);
     }
     // min / max of every 16-column group (kept for the quantisation below); the 4-bit arm's row-wide min / max is the
     // min / max over the groups of the is4 lanes -- no separate pass over the row
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void mxq_fakequant_fwd_reg_kernel(const void* 
             const float mn = gmn[i], mx = gmx[i];
             float o[VEC];
             quant_vec<T, FASTQ>(vi, is4 ? alpha4 : T::rnd(mx - mn), is4 ? mn4 : mn, is4 ? 15.0f : L2, o);
-            T::store(out, base + e0, o);
+            T::store_nt(out, base + e0, o);
         }
     }
 }
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void mxq_fakequant_fwd_kernel(const void* __re
         const float beta = is4 ? mn4 : mn;
         float o[VEC];
         quant_vec<T, FASTQ>(v, alpha, beta, is4 ? 15.0f : L2, o);
-        T::store(out, base + e0, o);
+        T::store_nt(out, base + e0, o);
     }
 }
 
@@ -216,12 +216,12 @@ __global__ __launch_bounds__(256) void mxq_fakequant_bwd_kernel(const void* __re
     constexpr int VEC = T::VEC;
     float g[VEC], x[VEC];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        T::load(gout, i * VEC, g);
-        T::load(w, i * VEC, x);
+        T::load_nt(gout, i * VEC, g);
+        T::load_nt(w, i * VEC, x);
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
             if (x[j] >= hi || x[j] <= lo) g[j] = 0.0f;
-        T::store(gin, i * VEC, g);
+        T::store_nt(gin, i * VEC, g);
     }
 }
 

@@ -16,11 +16,25 @@ sys.path.insert(0, ROOT)
 from mxq_amd import llama_shapes as LS  # noqa: E402
 
 
+_HIP = None
+
+
+def _memcpy(dst, src):
+    global _HIP
+    if _HIP is None:
+        _HIP = ctypes.CDLL("libamdhip64.so")
+        _HIP.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    rc = _HIP.hipMemcpyAsync(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size(), 3,
+                             torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--libs", default="mxq_amd/libmxq_hip.so,abtmp/libmxq_hip_before.so")
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--bwd", action="store_true", help="time the straight-through backward (3 tensors per element) instead")
     ap.add_argument("--shape", default=None, help="N,K: four weights of this one shape instead of the decoder block")
     args = ap.parse_args()
     dt = {"bf16": (torch.bfloat16, 2), "f16": (torch.float16, 1), "f32": (torch.float32, 0)}[args.dtype]
@@ -32,7 +46,8 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     ws = [(torch.randn(n, k, generator=g, device=dev) * 0.02).to(dt[0]) for n, k in shapes]
     outs = [torch.empty_like(w) for w in ws]
-    nbytes = sum(2 * w.numel() * w.element_size() for w in ws)
+    nbytes = sum((3 if args.bwd else 2) * w.numel() * w.element_size() for w in ws)
+    gos = [torch.randn(w.shape, generator=g, device=dev).to(dt[0]) for w in ws] if args.bwd else None
     names = args.libs.split(",")
     graphs, ref = {}, None
     for name in names:
@@ -41,10 +56,17 @@ def main():
         fwd.restype = ctypes.c_int
         fwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 
-        def run(fwd=fwd):
+        bwd = lib.mxq_fakequant_bwd
+        bwd.restype = ctypes.c_int
+        bwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+
+        def run(fwd=fwd, bwd=bwd):
             st = torch.cuda.current_stream().cuda_stream
-            for w, o in zip(ws, outs):
-                rc = fwd(w.data_ptr(), o.data_ptr(), w.shape[0], w.shape[1], 2, dt[1], st)
+            for i, (w, o) in enumerate(zip(ws, outs)):
+                if args.bwd:
+                    rc = bwd(gos[i].data_ptr(), w.data_ptr(), o.data_ptr(), w.numel(), -0.03, 0.03, dt[1], st)
+                else:
+                    rc = fwd(w.data_ptr(), o.data_ptr(), w.shape[0], w.shape[1], 2, dt[1], st)
                 assert rc == 0, rc
         run()
         torch.cuda.synchronize()
@@ -57,6 +79,19 @@ def main():
         with torch.cuda.graph(cg):
             run()
         graphs[name] = cg
+    # the transfer floor of the same pass: a plain device copy of the same seven tensors (torch's elementwise copy kernel
+    # and hipMemcpyAsync device-to-device) -- what "one read + one write per element" costs with no arithmetic at all
+    for name, fn in (("copy: torch out.copy_(w)", lambda w, o: o.copy_(w)),
+                     ("copy: hipMemcpyAsync D2D", lambda w, o: _memcpy(o, w))):
+        for w, o in zip(ws, outs):
+            fn(w, o)
+        torch.cuda.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            for w, o in zip(ws, outs):
+                fn(w, o)
+        graphs[name] = cg
+        names.append(name)
     ts = {n: [] for n in names}
     for _ in range(args.rounds):
         for n in names:
@@ -70,7 +105,7 @@ def main():
     for n in names:
         t = sorted(ts[n])
         med = t[len(t) // 2]
-        print(f"{n:40s}: {med:7.1f} us per pass ({nbytes / med / 1e6:.2f} TB/s of read + write), min {t[0]:.1f}")
+        print(f"{n:40s}: {med:7.1f} us per pass ({nbytes / med / 1e6:.2f} TB/s of algorithmic bytes), min {t[0]:.1f}")
 
 
 if __name__ == "__main__":
