@@ -58,6 +58,29 @@ def make_call(v, x, p, wd, out):
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (v, rc)
         return call
+    if v.startswith("hlib:") or v.startswith("lib:"):      # another build of libmxq_hip.so (tools/build_variant.sh)
+        kind, so, *var = v.split(":")
+        lib = prof_lib(so)
+        M = x.shape[0]
+        if kind == "hlib":                                  # hlib:PATH -- its mxq_linear_f16_hoisted
+            fn = lib.mxq_linear_f16_hoisted
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+            scratch = packing.hoist_scratch(x.device, packing._lib.load().mxq_hoist_scratch_bytes(p.N, p.K))
+            a = (x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K, 0,
+                 scratch.data_ptr(), scratch.numel())
+        else:                                               # lib:PATH[:variant] -- its mxq_gemm_f16_ws (default gemm8)
+            fn = lib.mxq_gemm_f16_ws
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+            ws = packing.gemm_workspace(x.device)
+            a = (x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K,
+                 int(var[0]) if var else 8, ws.data_ptr(), ws.numel())
+
+        def call():
+            rc = fn(*a, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, (v, rc)
+        return call
     if v == "hoist":
         return lambda: packing.linear_hoisted(x, p, out=out)
     if v == "fused":
