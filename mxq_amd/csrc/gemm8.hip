@@ -429,19 +429,19 @@ __device__ __forceinline__ void sk_finish(const SkSeg& sk, int j, int NT_tile, i
         const int vb = sk_bound(v, sk.S, sk.units);
         if (sk_bound(v + 1, sk.S, sk.units) <= (vb > lo ? vb : lo)) continue;   // empty range: no slot was written
         const float* src = sk.ws + ((int64_t)((v * 8 + sk.e) * 2 + (vb >= lo ? 0 : 1)) * (BM * BN)) + wave * 4096;
+        // all 16 fragments of the slot in flight together: a slot costs the finisher ONE loaded-memory round trip (two
+        // batches of 8 were two; the same change on the mid-M combine kernel was worth 1.2 us)
+        f32x4 p[4][4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {   // 8 fragments (16 loads) in flight at a time
-            f32x4 p[2][4];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int jj = 0; jj < 4; ++jj) p[i][jj] = ld_agent(src, i * 4 + jj, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) p[i][jj] = ld_agent(src, (h * 2 + i) * 4 + jj, lane);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[h * 2 + i][jj] = any ? acc[h * 2 + i][jj] + p[i][jj] : p[i][jj];
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = any ? acc[i][jj] + p[i][jj] : p[i][jj];
+        __builtin_amdgcn_sched_barrier(0);
         any = true;
     }
     if (lane == 0)   // ready for the next launch
@@ -924,7 +924,8 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     if (e != hipSuccess) return (int)e;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
     const int NT = K / BK;
-    const int cus = cu_count() / 8 * 8, units = cus / 8;
+    const int cus = cu_count() / 8 * 8;
+    int units = cus / 8;
     int dp_tiles = tiles, tail = 0;
     if (workspace && tiles % cus != 0 && units * 8 * N_MMA * sizeof(int) <= CNT_BYTES &&
         ws_bytes >= CNT_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
@@ -936,10 +937,22 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
         if ((force || pays) && (int64_t)t8 * NT >= (int64_t)units * 4) {
             tail = tiles % cus;
             dp_tiles = tiles - tail;
+        } else if (pays && tiles > cus && (int64_t)t8 * NT < (int64_t)units * 4) {
+            // A tail of a few tiles (258 tiles on 256 CUs: Llama's gate/up at 640-768 tokens; 516 at 1536) used to run
+            // as a whole extra round of 2-4 workgroups.  Split it over FEWER units per XCD instead: >= 8 K-steps per
+            // unit and at most 8 contributors per tile (the finisher reads them all back).
+            const int tmax = (tiles % cus + 7) / 8;
+            int u = tmax * NT / 8;
+            if (u > 8 * tmax) u = 8 * tmax;
+            if (u >= 2) {
+                units = u < units ? u : units;
+                tail = tiles % cus;
+                dp_tiles = tiles - tail;
+            }
         }
     }
     const int dp_grid = dp_tiles < cus ? dp_tiles : cus;   // persistent: at most one data-parallel workgroup per CU
-    const int grid = dp_grid + (tail ? cus : 0);
+    const int grid = dp_grid + (tail ? 8 * units : 0);
     mxq_gemm8_f16_kernel<ABL, LAYOUT><<<grid, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
         dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace);
