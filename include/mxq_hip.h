@@ -139,6 +139,13 @@ size_t mxq_hoist_scratch_bytes(int N, int K);
 int mxq_linear_f16_hoisted(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                            int layout, void* w16_scratch, size_t scratch_bytes, void* stream);
 
+/* The second half of the hoisted mode on its own = the reference's implicit nn.Linear on the fake-quant fp16 weight
+ * (mxq_quant/main.py:85 -> lib/eval.py:54): y[M, N] = x[M, K] . w16[N, K]^T, fp16 operands, fp32
+ * accumulation in K order, fp16 result; w16 e.g. from mxq_dequant_f16.  variant 0: kernel by shape (the 256 x 256-tile
+ * kernel for launches of >= 2 tiles per CU with an even number of 64-deep K-tiles, else the 256 x 128 one), 1 / 2: that
+ * kernel explicitly (2 -> MXQ_E_SHAPE if K % 128 != 0).  Both kernels give bit-identical results. */
+int mxq_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, int variant, void* stream);
+
 /* Uniform-bit-width layouts for the W2A16 / W4A16 / mixed sweep (BASELINE config 5); the mixed
  * layout is layout 0.  1 = W2G16: Quantizer(bits=2, qq_scale_bits=4) on every 16-column group
  * (quantizer.py:61-147), 4.5 bit/weight; 2 = W4ROW: Quantizer(bits=4, qq_scale_bits=4) per row

@@ -196,6 +196,17 @@ int mxq_gemm_f16_layout(const void* x, const void* qweight, const void* rowmeta,
     return mxq_launch_gemm8_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, nullptr, 0, (hipStream_t)stream);
 }
 
+// y = x . w16^T on a dense fp16 weight: variant 0 = by shape, 1 = the 256 x 128 kernel (gemm8.hip, dense instantiation),
+// 2 = the 256 x 256 kernel (dense256.hip; MXQ_E_SHAPE when the K-tile count is odd)
+static int dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, int variant, hipStream_t stream) {
+    if (variant != 1) {
+        const int e = mxq_launch_dense256_f16(x, w16, y, M, N, K, variant == 2, stream);
+        if (e != -2) return e;
+        if (variant == 2) return MXQ_E_SHAPE;
+    }
+    return mxq_launch_gemm8_dense_f16(x, w16, y, M, N, K, stream);
+}
+
 size_t mxq_hoist_scratch_bytes(int N, int K) { return shape_ok(N, K) ? (size_t)N * K * 2 : 0; }
 
 int mxq_linear_f16_hoisted(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -212,7 +223,16 @@ int mxq_linear_f16_hoisted(const void* x, const void* qweight, const void* rowme
         e = mxq_launch_uniform_expand(qweight, rowmeta, w16_scratch, nullptr, nullptr, nullptr, nullptr, nullptr, N, K,
                                       layout, (hipStream_t)stream);
     if (e) return e;
-    return mxq_launch_gemm8_dense_f16(x, w16_scratch, y, M, N, K, (hipStream_t)stream);
+    return dense_f16(x, w16_scratch, y, M, N, K, 0, (hipStream_t)stream);
+}
+
+int mxq_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, int variant, void* stream) {
+    if (!x || !w16 || !y) return MXQ_E_NULL;
+    if (M < 0 || !shape_ok(N, K)) return MXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(w16) || !aligned16(y)) return MXQ_E_ALIGN;
+    if (variant < 0 || variant > 2) return MXQ_E_SHAPE;
+    if (M == 0) return 0;
+    return dense_f16(x, w16, y, M, N, K, variant, (hipStream_t)stream);
 }
 
 // Token counts served by the mid-M split-K kernel (midm.hip): above the skinny kernel's range, below the point

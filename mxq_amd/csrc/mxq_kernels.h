@@ -31,6 +31,9 @@ int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta
                          hipStream_t stream);   // 256x128 tile: MFMA waves stream x, dedicated waves dequantise; stream-K tail with a workspace (gemm8.hip); force: split even when it does not pay
 int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K,
                                hipStream_t stream);   // hoisted-dequant mode: w16 = dense fp16 [N, K] weight
+// the same product with a 256 x 256 tile and a quadrant-phase ping-pong schedule (dense256.hip); -2: not this kernel's
+// shape (odd K-tile count, or -- unless force -- too few tiles to fill the chip twice): take the kernel above
+int mxq_launch_dense256_f16(const void* x, const void* w16, void* y, int M, int N, int K, int force, hipStream_t stream);
 int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,

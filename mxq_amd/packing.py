@@ -276,6 +276,35 @@ def dequant(p: PackedMXQ) -> torch.Tensor:
     return out
 
 
+DENSE_VARIANTS = {"auto": 0, "dense128": 1, "dense256": 2}   # include/mxq_hip.h: mxq_dense_f16 variants
+
+
+def linear_dense(x: torch.Tensor, w16: torch.Tensor, out: Optional[torch.Tensor] = None, variant: str = "auto") -> torch.Tensor:
+    """y = x @ w16.T on a dense fp16 [N, K] weight (e.g. ``dequant(p)``): the reference's ``nn.Linear`` on the fake-quant
+    weight (mxq_quant/main.py:85) and the second half of the hoisted mode; fp32 accumulation, fp16 result.
+    variant: "auto", "dense128" (256 x 128-tile kernel), "dense256" (256 x 256-tile kernel; K % 128 == 0)."""
+    _need_gpu(x, w16)
+    if x.dtype != torch.float16 or w16.dtype != torch.float16 or w16.dim() != 2 or x.shape[-1] != w16.shape[1]:
+        raise ValueError("expected fp16 x [..., K] and fp16 w16 [N, K]")
+    if not w16.is_contiguous():
+        raise ValueError("w16 must be contiguous")
+    if variant not in DENSE_VARIANTS:
+        raise ValueError(f"unknown variant {variant!r}")
+    N, K = w16.shape
+    check_shape(N, K)
+    x2 = x.reshape(-1, K).contiguous()
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    elif out.shape != (M, N) or out.dtype != torch.float16 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float16 [tokens, out_features] tensor")
+    if M:
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().mxq_dense_f16(x2.data_ptr(), w16.data_ptr(), out.data_ptr(), M, N, K,
+                                                 DENSE_VARIANTS[variant], _stream(x2)), f"mxq_dense_f16[{variant}]")
+    return out.reshape(*x.shape[:-1], N)
+
+
 GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
 
 

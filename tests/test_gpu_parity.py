@@ -801,6 +801,37 @@ def test_hoisted_dequant_mode_is_bit_identical_to_the_fused_gemm(dev, layout, M,
         assert torch.equal(packing.linear_layout(x, p, path="auto"), hoisted)
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (300, 272, 256), (1000, 784, 4096), (8192, 4096, 256),
+                                   (515, 512, 11008), (2304, 11008, 512), (12288, 1024, 384)])
+def test_dense256_kernel_is_bit_identical_to_the_256x128_one(dev, M, N, K):
+    """mxq_dense_f16 (the reference's nn.Linear on the fake-quant fp16 weight, mxq_quant/main.py:85): the 256 x 256-tile
+    quadrant-phase kernel (csrc/dense256.hip) multiplies the same fp16 operands in the same K order as the 256 x 128
+    kernel's dense instantiation -- identical bits -- on one tile, ragged M / N edges, Llama's K-tile counts (64, 172),
+    several tiles per persistent workgroup (512-688 tiles on 256 CUs: the unit pipeline runs across tile boundaries),
+    twice in a row (no state left behind)."""
+    from mxq_amd import packing
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    w16 = (torch.randn(N, K, generator=g) * 0.02).half().to(dev)
+    x = torch.randn(M, K, generator=g).half().to(dev)
+    a = packing.linear_dense(x, w16, variant="dense128")
+    b = packing.linear_dense(x, w16, variant="dense256")
+    rows = torch.arange(0, M, max(1, M // 512), device=dev)
+    ref = x[rows].float() @ w16.float().t()
+    assert ((b[rows].float() - ref).abs().max() / ref.abs().max()).item() <= REL_TOL
+    assert torch.equal(a, b)
+    assert torch.equal(packing.linear_dense(x, w16, variant="dense256"), b)
+    assert torch.equal(packing.linear_dense(x, w16), b)                       # "auto": whichever kernel, the same bits
+
+
+def test_dense256_rejects_an_odd_k_tile_count(dev):
+    from mxq_amd import packing
+    x = torch.zeros(256, 192, dtype=torch.float16, device=dev)
+    w16 = torch.zeros(256, 192, dtype=torch.float16, device=dev)
+    with pytest.raises(ValueError):
+        packing.linear_dense(x, w16, variant="dense256")
+    assert packing.linear_dense(x, w16).abs().max().item() == 0.0               # auto falls back to the 256 x 128 kernel
+
+
 # ----------------------------------------------------------------------------------------
 # compact metadata mode (format v2: fp16 zero-points, 3.75 bit/weight)
 # ----------------------------------------------------------------------------------------

@@ -81,6 +81,8 @@ def make_call(v, x, p, wd, out):
             rc = fn(*a, torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (v, rc)
         return call
+    if v in packing.DENSE_VARIANTS and v != "auto":        # the plain GEMM on the dequantised weight: dense128 / dense256
+        return lambda: packing.linear_dense(x, wd, out=out, variant=v)
     if v == "hoist":
         return lambda: packing.linear_hoisted(x, p, out=out)
     if v == "fused":
