@@ -59,6 +59,22 @@ MXQ_HD void mxq_deq2x16(uint32_t d, float s, float z, uint32_t out[8]) {
     }
 }
 
+// ... and one half of them: elements 8h .. 8h+7 -> 4 x packed fp16 pairs (the same LUT, the same selections)
+MXQ_HD void mxq_deq2x8(uint32_t d, int h, float s, float z, uint32_t out[4]) {
+    const uint32_t p01 = mxq_pack_f16(s * (0.0f - z), s * (1.0f - z));
+    const uint32_t p23 = mxq_pack_f16(s * (2.0f - z), s * (3.0f - z));
+    const uint32_t lut_lo = MXQ_PERM(p23, p01, 0x06040200u);
+    const uint32_t lut_hi = MXQ_PERM(p23, p01, 0x07050301u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t m = (d >> (2 * (2 * h + j))) & 0x03030303u;   // codes of elements 4(2h+j) .. +3
+        const uint32_t lo = MXQ_PERM(0u, lut_lo, m);
+        const uint32_t hi = MXQ_PERM(0u, lut_hi, m);
+        out[2 * j] = MXQ_PERM(hi, lo, 0x05010400u);
+        out[2 * j + 1] = MXQ_PERM(hi, lo, 0x07030602u);
+    }
+}
+
 // byte N of a word as float (one v_cvt_f32_ubyteN; spelled as asm on the device because the optimiser folds the
 // nibble masks of the caller into per-element shift+and+convert sequences otherwise: 3 ops instead of 1)
 #if defined(__HIP_DEVICE_COMPILE__)

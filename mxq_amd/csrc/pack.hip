@@ -86,9 +86,12 @@ __global__ void mxq_unpack_kernel(const uint32_t* __restrict__ qweight, const fl
 }
 
 // ------------------------------------------------------------------------------------ //
-// dequant to a dense fp16 [N, K] matrix (bit-exact fake-quant weight, mxqgpt.py:448).
-// One thread per (row, chunk quarter): 16 weights = 32 B.  Block = 256 threads covers
-// 16 rows x 4 chunks: thread -> (quarter, chunk slot, r).
+// dequant to a dense fp16 [N, K] matrix (bit-exact fake-quant weight, mxqgpt.py:448): the first half of the
+// hoisted mode.  Write-bound (2 B out per 0.56 B in), so the layout follows the STORES: a lane owns one 16-byte
+// slot (8 weights = half a 16-column quarter) of a row's 128-byte chunk line, 8 lanes cover the line and a wave
+// instruction writes 8 rows x 128 B in full lines.  (Round 2's thread -> (row, quarter) mapping wrote 32-byte
+// pieces of 16 different rows per instruction: 13.0 -> 9.6 us at 4096^2, profiles/r03_dense256.txt.)
+// Block = 4 waves = the 4 chunks of a chunk quad x one 16-row block; a wave does its chunk's rows 0-7, then 8-15.
 // ------------------------------------------------------------------------------------ //
 template <bool COMPACT>
 __global__ __launch_bounds__(256) void mxq_dequant_f16_kernel(const uint32_t* __restrict__ qweight,
@@ -96,28 +99,28 @@ __global__ __launch_bounds__(256) void mxq_dequant_f16_kernel(const uint32_t* __
                                                               uint16_t* __restrict__ out, int N, int K) {
     const int NC = K / 64, NC4 = (NC + 3) / 4;
     const int rb = blockIdx.x / NC4, c4 = blockIdx.x % NC4;
-    const int t = threadIdx.x;
-    const int r = t & 15, cs = (t >> 4) & 3, qt = t >> 6;   // qt wave-uniform
-    const int n = rb * 16 + r, c = c4 * 4 + cs;
+    const int lane = threadIdx.x & 63;
+    const int c = c4 * 4 + (threadIdx.x >> 6);          // wave-uniform
     if (c >= NC) return;
+    const int slot = lane & 7, qt = slot >> 1, h = slot & 1;
     typedef MxqMixed<COMPACT> F;
     const uint32_t* tile = qweight + ((int64_t)rb * NC + c) * F::BLK_DW;
-    uint32_t o[8];
-    if (qt < 3) {
-        const uint32_t d = tile[mxq_c2(qt, r)];
-        const float z = F::z2(tile, qt, r);
-        const uint32_t scw = F::scw(tile, r);
-        const float qs = __uint_as_float(tile[F::qq(qt)]), qz = __uint_as_float(tile[F::qq(qt) + 1]);
-        mxq_deq2x16(d, mxq_scale(qs, qz, (scw >> (4 * qt)) & 15u), z, o);
-    } else {
-        const float4 m = rowmeta[n];
-        const float s = mxq_scale(m.z, m.w, (uint32_t)m.y);
-        mxq_deq4x8(tile[mxq_c4(0, r)], s, m.x, o);
-        mxq_deq4x8(tile[mxq_c4(1, r)], s, m.x, o + 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = i * 8 + (lane >> 3), n = rb * 16 + r;
+        uint32_t o[4];
+        if (qt < 3) {
+            const uint32_t d = tile[mxq_c2(qt, r)];
+            const float z = F::z2(tile, qt, r);
+            const uint32_t scw = F::scw(tile, r);
+            const float qs = __uint_as_float(tile[F::qq(qt)]), qz = __uint_as_float(tile[F::qq(qt) + 1]);
+            mxq_deq2x8(d, h, mxq_scale(qs, qz, (scw >> (4 * qt)) & 15u), z, o);
+        } else {
+            const float4 m = rowmeta[n];
+            mxq_deq4x8(tile[mxq_c4(h, r)], mxq_scale(m.z, m.w, (uint32_t)m.y), m.x, o);
+        }
+        *(uint4*)(out + (int64_t)n * K + c * 64 + slot * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    uint4* dst = (uint4*)(out + (int64_t)n * K + c * 64 + qt * 16);
-    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 // ------------------------------------------------------------------------------------ //

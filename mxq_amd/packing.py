@@ -74,7 +74,7 @@ def gemm_workspace(device: torch.device, counters: bool = True) -> torch.Tensor:
 
 
 _HOIST: Dict[tuple, torch.Tensor] = {}
-HOIST_MIN_TOKENS = 8192     # "auto" hoists the dequant out of the token loop from this many tokens on (tools/ab_gemm.py)
+HOIST_MIN_TOKENS = 4096     # "auto" hoists the dequant out of the token loop from this many tokens on (tools/ab_gemm.py)
 
 
 def hoist_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
