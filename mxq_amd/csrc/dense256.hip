@@ -12,15 +12,16 @@
 // reads / stages -- at the grain of 16 MFMAs (256 cycles), not of a whole K-tile.  (Round 2's 256 x 256 experiments,
 // tools/experiments/dense256.hip, alternated whole K-tiles or interleaved everything in one stream: +5 % at best.)
 //
-// LDS: 8 slots of 16 KB = two K-tiles x four UNITS.  A unit is what one phase reads first:
-//     A = the first 64 tokens of both token halves     (read in phase 1)      B = the first 32 channels of all four
-//     D = the last 64 tokens of both                   (phase 3)                  channel quarters (phase 1)
-//                                                                             C = the last 32 channels (phase 2)
-// Phase P (counted over the whole persistent loop, 4 per K-tile) stages unit P + 6 into slot (P + 6) % 8 -- the slot's
-// previous unit P - 2 was last read in phase P - 2 or earlier -- and waits vmcnt(8): everything up to unit P + 2 has
-// landed, which is exactly what phase P + 1 reads after this phase's barriers.  Every unit has four phases (>= 2000
-// cycles) between issue and wait; the wait is the same in every phase, and the unit sequence runs on across tile
-// boundaries (the last phases of a tile stage the next tile's first units), so the pipeline never drains.
+// LDS: 8 slots of 16 KB = two K-tiles x four UNITS, one per phase, in the order the phases read them:
+//     A(t) = the first 64 tokens of both token halves  (phase 1)      C(t) = the last 32 channels of all four channel
+//     D(t) = the last 64 tokens of both                (phase 3)             quarters (phase 2)
+//     B(t+1) = the first 32 channels of the NEXT K-tile, read in phase 4 into a second register set (so every phase
+//     reads 8 or 4 fragments; reading it in the next phase 1 makes that phase's read segment 12 long: 0.1-1.1 % slower)
+// Phase P (counted over the whole persistent loop, 4 per K-tile) reads unit P, stages unit P + 6 into slot (P + 6) % 8 --
+// the slot's previous unit P - 2 was read two phases ago -- and waits vmcnt(10): everything up to unit P + 1 has
+// landed, which is what phase P + 1 reads after this phase's barriers.  Every unit has five phases (>= 2500 cycles)
+// between issue and wait; the wait is the same in every phase, and the unit sequence runs on across tile boundaries
+// (the last phases of a tile stage the next tile's first units), so the pipeline never drains.
 #include <hip/hip_runtime.h>
 
 #include "mxq_dequant.h"
@@ -39,6 +40,7 @@ constexpr int SMEM = 8 * UNIT;          // 128 KB
 enum { UA = 0, UB = 1, UC = 2, UD = 3 };
 
 #define D256_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 #define D256_LANE_ID(v) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(v))
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
@@ -93,18 +95,22 @@ __device__ __forceinline__ void src_of(Src& s, const uint16_t* __restrict__ x, c
 typedef half8 XFrag[2][4];   // [k half][token block]
 typedef half8 WFrag[2][2];   // [k half][channel block]
 
-// the wave's x sub-tile xs (64 tokens) / weight sub-tile ws (32 channels) of the K-tile in slot parity `par`
+// LDS slot of a unit: (K-tile parity) * 4 + position in the staging sequence A(t), C(t), D(t), B(t+1) -- the order in
+// which the phases read them (B(t+1), the next K-tile's first weight sub-tile, is read one phase early into a second
+// register set: 8 / 4 / 8 / 4 fragment reads per phase instead of 12 / 4 / 8 / 0)
+constexpr int SEQ_A = 0, SEQ_C = 1, SEQ_D = 2, SEQ_B = 3;
 template <int XS>
 __device__ __forceinline__ void load_x(const char* smem, int par, int wr, int fr, int fq, XFrag& f) {
-    const char* u = smem + (par * 4 + (XS ? UD : UA)) * UNIT;
+    const char* u = smem + (par * 4 + (XS ? SEQ_D : SEQ_A)) * UNIT;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int j = 0; j < 4; ++j) f[kk][j] = *(const half8*)(u + swz(wr * 64 + j * 16 + fr, kk * 4 + fq));
 }
-template <int WS>
+// weight sub-tile from the unit in sequence position SEQ of parity `par`
+template <int SEQ>
 __device__ __forceinline__ void load_w(const char* smem, int par, int wc, int fr, int fq, WFrag& f) {
-    const char* u = smem + (par * 4 + (WS ? UC : UB)) * UNIT;
+    const char* u = smem + (par * 4 + SEQ) * UNIT;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -165,42 +171,39 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[4][8], uint16_t* _
 struct Regs {
     f32x4 acc[4][8];
     XFrag x0, x1;
-    WFrag w0, w1;
+    WFrag w0[2], w1;   // w0: by K-tile parity (the next K-tile's is read while this one's is still in use)
 };
 
-// Phase p (0..7) of a K-tile PAIR (K-tiles kt0, kt0 + 1 -> slot parities 0, 1).  It stages unit (p + 6): kind (p + 2) % 4
-// of K-tile kt0 + (p + 6) / 4, into slot (p + 6) % 8.  LAST: the pair is the tile's last one, so K-tiles kt0 + 2 and
-// kt0 + 3 are the NEXT tile's K-tiles 0 and 1 (`nxt`; an empty descriptor when there is none: zeros, no traffic).
+// Phase p (0..7) of a K-tile PAIR (K-tiles kt0, kt0 + 1 -> slot parities 0, 1).  It reads sequence unit p and stages
+// sequence unit p + 6 (into slot (p + 6) % 8; the slot's previous unit p - 2 was read two phases ago), then waits until
+// unit p + 1 -- what the next phase reads -- has landed.  LAST: the pair is the tile's last one: K-tiles kt0 + 2, kt0 + 3
+// are the NEXT tile's K-tiles 0, 1 (`nxt`; an empty descriptor when there is none: zeros, no traffic).
 template <int P, bool LAST>
 __device__ __forceinline__ void phase(Regs& R, char* smem, const Src& cur, const Src& nxt, const uint32_t (&voff)[4][2], int kt0,
                                       int wave, int wr, int wc, int fr, int fq) {
     constexpr int PAR = P >> 2, PH = P & 3;
-    // ---- reads of the quadrant's new sub-tile (the other one is still in registers)
-    if constexpr (PH == 0) {
-        load_w<0>(smem, PAR, wc, fr, fq, R.w0);
-        D256_FENCE();
-        load_x<0>(smem, PAR, wr, fr, fq, R.x0);
-    } else if constexpr (PH == 1) {
-        load_w<1>(smem, PAR, wc, fr, fq, R.w1);
-    } else if constexpr (PH == 2) {
-        load_x<1>(smem, PAR, wr, fr, fq, R.x1);
-    }
+    // ---- fragment reads: the quadrant's new sub-tile (phase 4: the NEXT K-tile's first weight sub-tile)
+    constexpr int SEQ = (P + 6) & 3, SLOT = (P + 6) & 7;
+    constexpr int DK = ((P + 6) >> 2) + (SEQ == SEQ_B ? 1 : 0);              // its K-tile, relative to kt0
+    constexpr int KIND = SEQ == SEQ_A ? UA : SEQ == SEQ_C ? UC : SEQ == SEQ_D ? UD : UB;
+    if constexpr (PH == 0) load_x<0>(smem, PAR, wr, fr, fq, R.x0);
+    else if constexpr (PH == 1) load_w<SEQ_C>(smem, PAR, wc, fr, fq, R.w1);
+    else if constexpr (PH == 2) load_x<1>(smem, PAR, wr, fr, fq, R.x1);
+    else load_w<SEQ_B>(smem, PAR, wc, fr, fq, R.w0[PAR ^ 1]);
     D256_FENCE();
-    // ---- stage unit P + 6
-    constexpr int KIND = (P + 2) & 3, DK = (P + 6) >> 2, SLOT = (P + 6) & 7;
+    // ---- stage sequence unit P + 6
     if constexpr (LAST && DK >= 2) stage<KIND>(nxt, voff, smem, SLOT, wave, DK - 2);
     else stage<KIND>(cur, voff, smem, SLOT, wave, kt0 + DK);
     D256_FENCE();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // units <= P + 2 have landed (this wave's pieces)
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // units <= P + 1 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     D256_FENCE();
-    __builtin_amdgcn_s_setprio(1);
-    if constexpr (PH == 0) mfma_quadrant<0, 0>(R.acc, R.w0, R.x0);
+    // (s_setprio 1 / 3 around the MFMA cluster: 0.5-1 % slower than none; the staging before the reads: 0.5 % slower)
+    if constexpr (PH == 0) mfma_quadrant<0, 0>(R.acc, R.w0[PAR], R.x0);
     else if constexpr (PH == 1) mfma_quadrant<0, 1>(R.acc, R.w1, R.x0);
     else if constexpr (PH == 2) mfma_quadrant<1, 1>(R.acc, R.w1, R.x1);
-    else mfma_quadrant<1, 0>(R.acc, R.w0, R.x1);
-    __builtin_amdgcn_s_setprio(0);
+    else mfma_quadrant<1, 0>(R.acc, R.w0[PAR], R.x1);
     D256_FENCE();
     __builtin_amdgcn_s_barrier();
 }
@@ -246,17 +249,22 @@ __global__ __launch_bounds__(THREADS) void mxq_dense256_f16_kernel(const uint16_
     tile_of(blockIdx.x, tiles_m, tiles_n, tm, tn);
     Src cur, nxt;
     src_of(cur, x, w, M, N, K, tm, tn, true);
-    // prologue: units 0..5 = K-tile 0 whole and A, B of K-tile 1
+    // prologue: B(0) (sequence unit -1, slot 7) and sequence units 0..5 = A(0), C(0), D(0), B(1), A(1), C(1)
+    stage<UB>(cur, voff, smem, 7, wave, 0);
     stage<UA>(cur, voff, smem, 0, wave, 0);
-    stage<UB>(cur, voff, smem, 1, wave, 0);
-    stage<UC>(cur, voff, smem, 2, wave, 0);
-    stage<UD>(cur, voff, smem, 3, wave, 0);
+    stage<UC>(cur, voff, smem, 1, wave, 0);
+    stage<UD>(cur, voff, smem, 2, wave, 0);
+    stage<UB>(cur, voff, smem, 3, wave, 1);
     stage<UA>(cur, voff, smem, 4, wave, 1);
-    stage<UB>(cur, voff, smem, 5, wave, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // units 0, 1
+    stage<UC>(cur, voff, smem, 5, wave, 1);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // B(0), A(0)
     __builtin_amdgcn_s_barrier();
     if (wr) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier interval behind group 0
     Regs R;
+    {
+        D256_LANE_ID(ln);
+        load_w<SEQ_B>(smem, 1, wc, ln & 15, ln >> 4, R.w0[0]);   // "phase -1": the first K-tile's first weight sub-tile
+    }
     for (int tile = blockIdx.x; tile < tiles; tile += grid) {
         D256_LANE_ID(ln);
         const int fr = ln & 15, fq = ln >> 4;

@@ -58,6 +58,18 @@ def make_call(v, x, p, wd, out):
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (v, rc)
         return call
+    if v.startswith("dlib:"):                               # dlib:PATH[:variant] -- another build's mxq_dense_f16 (default 2 = dense256)
+        _, so, *var = v.split(":")
+        fn = prof_lib(so).mxq_dense_f16
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        M = x.shape[0]
+
+        def call():
+            rc = fn(x.data_ptr(), wd.data_ptr(), out.data_ptr(), M, p.N, p.K, int(var[0]) if var else 2,
+                    torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, (v, rc)
+        return call
     if v.startswith("hlib:") or v.startswith("lib:"):      # another build of libmxq_hip.so (tools/build_variant.sh)
         kind, so, *var = v.split(":")
         lib = prof_lib(so)
