@@ -58,6 +58,17 @@ def make_call(v, x, p, wd, out):
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (v, rc)
         return call
+    if v.startswith("xlib:"):                               # xlib:PATH:symbol -- an experiment's dense entry (x, w16, y, M, N, K, stream)
+        _, so, sym = v.split(":")
+        fn = getattr(prof_lib(so), sym)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+        M = x.shape[0]
+
+        def call():
+            rc = fn(x.data_ptr(), wd.data_ptr(), out.data_ptr(), M, p.N, p.K, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, (v, rc)
+        return call
     if v.startswith("dlib:"):                               # dlib:PATH[:variant] -- another build's mxq_dense_f16 (default 2 = dense256)
         _, so, *var = v.split(":")
         fn = prof_lib(so).mxq_dense_f16
