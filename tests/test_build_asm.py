@@ -99,7 +99,33 @@ def test_gemm8_main_loops_keep_dma_in_flight():
         assert sum(bool(re.match(r"\s+v_(?!mfma)", l)) for l in lp) <= 12, "VALU work crept into the MFMA waves' loop"
 
 
-@pytest.mark.parametrize("src", ["gemm.hip", "gemm8.hip", "gemv.hip", "skinny.hip", "fakequant.hip", "actquant.hip", "pack.hip"])
+def test_dense256_pair_loop_is_the_designed_schedule():
+    """The 256 x 256 kernel's steady-state loop is one K-tile PAIR = 8 phases: per phase 16 MFMAs between two barriers, 2
+    LDS-DMA pieces behind ONE counted wait (vmcnt(10): five units stay in flight) and 8 or 4 fragment reads; nothing in the
+    loop drains the DMA queue, and the loop carries no VALU instruction at all (no accumulator copies)."""
+    lines = _kernel_body(_asm("dense256.hip"), "mxq_dense256_f16_kernel")
+    waits = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(10)" in l]
+    loops = []
+    for at in waits:
+        try:
+            lp = _innermost_loop(lines, at)
+        except AssertionError:
+            continue
+        if lp not in loops:
+            loops.append(lp)
+    loops = [lp for lp in loops if sum("v_mfma_f32_16x16x32_f16" in l for l in lp) == 128]
+    assert 1 <= len(loops) <= 2, "expected the K-tile pair loop (and the tile loop around it, which holds the last pair)"
+    for lp in loops:
+        assert sum(bool(re.search(r"\bs_barrier\b", l)) for l in lp) == 16
+        assert sum("s_waitcnt vmcnt(10)" in l for l in lp) == 8
+        assert sum(bool(re.search(r"buffer_load_dwordx4.* lds", l)) for l in lp) == 16
+        assert sum("ds_read_b128" in l for l in lp) == 48                      # (8 + 4 + 8 + 4) x 2 K-tiles
+        assert not [l for l in lp if re.search(r"s_waitcnt.*vmcnt\(0\)", l)], "drain inside the loop"
+    inner = min(loops, key=len)          # the pair loop proper
+    assert not [l for l in inner if re.match(r"\s+v_(?!mfma)", l)], "VALU work (accumulator copies?) inside the pair loop"
+
+
+@pytest.mark.parametrize("src", ["gemm.hip", "gemm8.hip", "dense256.hip", "midm.hip", "gemv.hip", "skinny.hip", "fakequant.hip", "actquant.hip", "pack.hip"])
 def test_no_spills_no_scratch(src):
     s = _asm(src, *(["-fno-slp-vectorize"] if src == "gemm8.hip" else []))     # the Makefile's per-file flag
     for m in re.finditer(r"\.vgpr_spill_count:\s+(\d+)", s):

@@ -55,6 +55,10 @@ def test_argument_validation_without_gpu(lib):
     assert lib.mxq_gemv_awq_f16(16, 16, 16, 16, 16, 1, 4096, 4096, 16, None) == -1
     assert lib.mxq_gemv_proto_f16(*([16] * 9), 1, 2048, 4096, 16, None) == -1
     assert lib.mxq_quantize_pack(16, 9, None, 16, 16, 64, 64, None) == -3
+    assert lib.mxq_dense_f16(None, 16, 16, 8, 256, 128, 0, None) == -2          # nn.Linear on the fake-quant weight
+    assert lib.mxq_dense_f16(16, 16, 16, 8, 250, 128, 0, None) == -1
+    assert lib.mxq_dense_f16(16, 16, 8, 8, 256, 128, 0, None) == -4
+    assert lib.mxq_dense_f16(16, 16, 16, 8, 256, 128, 3, None) == -1            # unknown kernel variant
 
 
 def test_argument_validation_rejects_before_any_launch(lib):
