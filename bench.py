@@ -135,6 +135,33 @@ def cpu_baseline(dev, budget_s=12.0):
                       "(4.295 GFLOP), median of the calls that fit ~12 s; the GPU runs the same call on the same inputs"}
 
 
+def long_prefill(layers, dev, tokens=32768, iters=3):
+    """Side figure, not `value`: BASELINE configs[4]'s shape -- ONE decoder layer's seven Linears at batch 8 x seq 4096
+    (32768 tokens per launch), where the dispatch hoists the dequant (dequant pass + csrc/dense256.hip inside every timed
+    launch).  HIP events around `iters` passes over the layer after one untimed pass."""
+    lin = layers[0]
+    g = torch.Generator(device=dev).manual_seed(11)
+    xs = {K: torch.randn(tokens, K, generator=g, device=dev).half() for K in (LS.HIDDEN, LS.INTERMEDIATE)}
+    ys = {N: torch.empty(tokens, N, device=dev, dtype=torch.float16) for N in (LS.HIDDEN, LS.INTERMEDIATE)}
+
+    def layer():
+        for _name, p in lin:
+            packing.linear(xs[p.K], p, out=ys[p.N], path="gemm")
+    layer()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        layer()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = sum(2.0 * tokens * p.N * p.K for _n, p in lin)
+    return {"workload": f"BASELINE configs[4] shape: one decoder layer (7 Linears), {tokens} tokens per launch, mixed 2/4-bit, "
+                        "hoisted-dequant mode (dequant pass inside the timed launches)",
+            "layer_ms": round(ms, 3), "TFLOPs": round(fl / ms / 1e9, 1), "mfma_frac": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +291,8 @@ def main():
                          "launches_per_step": launches_rank_step,
                          "algorithmic_flop_per_launch": flops_rank_step / launches_rank_step},
         }
+        if world == 1 and not args.fuse:
+            out["long_prefill"] = long_prefill(layers, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev)
         print(json.dumps(out), flush=True)
