@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Run ONE GEMM kernel variant at ONE shape a few times (for rocprofv3 --pmc runs).
-    python3 tools/gemm_prof.py gemm8 2048 4096 4096 [iters] [layout: mixed | w2g16 | w4row]"""
+    python3 tools/gemm_prof.py gemm8 2048 4096 4096 [iters] [layout: mixed | w2g16 | w4row]
+variant dense128 / dense256: the plain GEMM on the dequantised weight (mxq_dense_f16) with that kernel."""
 import os
 import sys
 
@@ -18,8 +19,11 @@ W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
 p = packing.quantize_pack(W) if layout == "mixed" else packing.quantize_pack_uniform(W, layout)
 x = torch.randn(M, K, generator=g, device=dev).half()
 out = torch.empty(M, N, device=dev, dtype=torch.float16)
+wd = packing.dequant(p) if variant in packing.DENSE_VARIANTS else None
 for _ in range(iters):
-    if layout == "mixed":
+    if wd is not None:
+        packing.linear_dense(x, wd, out=out, variant=variant)
+    elif layout == "mixed":
         packing.linear(x, p, out=out, path=variant)
     else:
         packing.linear_layout(x, p, out=out)
