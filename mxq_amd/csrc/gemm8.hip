@@ -147,15 +147,30 @@ __device__ __forceinline__ void load_frags(const char* smem, int t, int kk, int 
     for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz(wm * 64 + j * 16 + fr, kk * 4 + fq));
 }
 
+// ABL_FILL (profiling builds): FILLN independent v_add_f32 behind every MFMA, pinned there by sched_group_barrier -- what
+// vector-ALU work costs when it sits IN the MFMA waves' own streams, one or two ops per MFMA gap (r04 probe)
+struct Fill { float f[4]; };
 template <int I0, int I1, int ABL>
-__device__ __forceinline__ void mfma_rows(f32x4 (&acc)[4][4], const Frag4& wf, const Frag4& xf) {
+__device__ __forceinline__ void mfma_rows(f32x4 (&acc)[4][4], const Frag4& wf, const Frag4& xf, Fill* fl = nullptr) {
+    constexpr int FILLN = (ABL >> 6) & 3;
 #pragma unroll
     for (int i = I0; i < I1; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (ABL & ABL_NO_MFMA) asm volatile("" ::"v"(wf[i]), "v"(xf[j]));
             else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            if constexpr (FILLN > 0) {
+#pragma unroll
+                for (int q = 0; q < FILLN; ++q) fl->f[(j * FILLN + q) & 3] += 1.5f;
+            }
         }
+    if constexpr (FILLN > 0) {
+#pragma unroll
+        for (int n = 0; n < (I1 - I0) * 4; ++n) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, FILLN, 0);   // FILLN VALU ops
+        }
+    }
 }
 
 // the x tile of K-step t: wave w fills rows 32w .. 32w+31 of slot t % 3 with 4 DMAs of 8 full 128-B rows;
@@ -199,20 +214,21 @@ __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, in
                                          f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1, Frag4& xf1,
                                          Stamps& st) {
     u64t t0 = 0, t1 = 0, t2 = 0;
+    [[maybe_unused]] Fill fl = {{(float)t, (float)t + 1.f, (float)t + 2.f, (float)t + 3.f}};
     if constexpr (MXQ_STAMPS(ABL)) t0 = stamp();
-    mfma_rows<0, 1, ABL>(acc, wf1, xf1);
+    mfma_rows<0, 1, ABL>(acc, wf1, xf1, &fl);
     MXQ_FENCE();
     load_frags<DENSE>(smem, t, 0, wm, wn, fr, fq, wf0, xf0);
     MXQ_FENCE();
-    mfma_rows<1, 2, ABL>(acc, wf1, xf1);
+    mfma_rows<1, 2, ABL>(acc, wf1, xf1, &fl);
     MXQ_FENCE();
     if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) issue_x<0, 2>(xd, smem, wave, t + 2);
     MXQ_FENCE();
-    mfma_rows<2, 4, ABL>(acc, wf1, xf1);
+    mfma_rows<2, 4, ABL>(acc, wf1, xf1, &fl);
     MXQ_FENCE();
     load_frags<DENSE>(smem, t, 1, wm, wn, fr, fq, wf1, xf1);
     MXQ_FENCE();
-    mfma_rows<0, 2, ABL>(acc, wf0, xf0);
+    mfma_rows<0, 2, ABL>(acc, wf0, xf0, &fl);
     MXQ_FENCE();
 #ifdef MXQ_PROFILING
     if constexpr ((ABL & ABL_MMA_VALU) != 0) {
@@ -229,7 +245,8 @@ __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, in
     MXQ_FENCE();
     if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) issue_x<2, 4>(xd, smem, wave, t + 2);
     MXQ_FENCE();
-    mfma_rows<2, 4, ABL>(acc, wf0, xf0);
+    mfma_rows<2, 4, ABL>(acc, wf0, xf0, &fl);
+    if constexpr (((ABL >> 6) & 3) != 0) asm volatile("" ::"v"(fl.f[0]), "v"(fl.f[1]), "v"(fl.f[2]), "v"(fl.f[3]));
     if constexpr (MXQ_STAMPS(ABL)) t1 = stamp();
     // this step's 4 DMAs stay in flight across the barrier; the previous step's (x of step t+1) have landed
     if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -371,10 +388,10 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
     load_frags<DENSE>(smem, 0, 1, wm, wn, fr, fq, wf1, xf1);
     if (NT > 2) {
         if constexpr (!(ABL & ABL_NO_XDMA)) issue_x<0, 4>(xd, smem, wave, 2);
-        mfma_rows<0, 4, ABL>(acc, wf0, xf0);
+        mfma_rows<0, 4, ABL & ~192>(acc, wf0, xf0);
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     } else {
-        mfma_rows<0, 4, ABL>(acc, wf0, xf0);
+        mfma_rows<0, 4, ABL & ~192>(acc, wf0, xf0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
@@ -394,7 +411,7 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
     }
     for (; t < NT; ++t) mma_step<ABL, false, DENSE>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
     next();                                  // the ring is idle from here on
-    mfma_rows<0, 4, ABL>(acc, wf1, xf1);     // (NT-1, kk=1)
+    mfma_rows<0, 4, ABL & ~192>(acc, wf1, xf1);     // (NT-1, kk=1)
 
     if (NT != NT_tile) {
         // partial segment: park the accumulators in this unit's slot; counted in after the unit's last segment
@@ -1006,6 +1023,11 @@ extern "C" int mxq_prof_gemm8_ablate_f16(const void* x, const void* qweight, con
         case 16: return launch8<16>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
         case 32: return launch8<32>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
         case 48: return launch8<48>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        // 64 / 128 / 192: one / two / three in-stream filler VALU ops behind every MFMA (+ 4: without the dequant)
+        case 64: return launch8<64>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 68: return launch8<68>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 132: return launch8<132>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 196: return launch8<196>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
     }
     return -1;   // MXQ_E_SHAPE: not an ablation this build carries
 }
