@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 
 from mxq_amd import llama_shapes as LS  # noqa: E402
 from mxq_amd import packing  # noqa: E402
-from mxq_amd.pipeline import LayerPipeline  # noqa: E402
+from mxq_amd.pipeline import LayerPipeline, rank_census  # noqa: E402
 
 SEQ = 2048
 PEAK_F16_TFLOPS = 2500.0     # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode-pipeline", action="store_true",
+                    help="N > 1: skip the bounded configs[2] side figure (greedy decode through the layer pipeline)")
     ap.add_argument("--fuse", action="store_true",
                     help="NOT the headline configuration: q|k|v and gate|up as one launch each (5 launches per layer "
                          "instead of 7; same weights, same FLOPs), reported with config.fused_launches = true")
@@ -254,6 +256,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    bits_per_weight = sum(p.nbytes() for lin in layers for _, p in lin) * 8.0 / (LS.PARAMS_PER_LAYER * max(1, len(my_layers)))
     tokens_per_step = SEQ * n_micro
     flops_per_step = LS.linear_flops(SEQ) * n_micro                      # whole job
     flops_rank_step = LS.linear_flops(SEQ, len(my_layers)) * n_micro     # this rank's launches
@@ -264,12 +267,26 @@ def main():
     achieved = flops_rank_step / (dev_ms / args.steps * 1e-3) / 1e12
 
     traffic = None       # HBM bytes per launch from rocprofv3 PMC counters (collected offline, see the file)
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm8_traffic.json") for r in (3, 2))
-                  if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm_traffic.json") for r in (4,))
+                  if os.path.exists(q)), "") or \
+        next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm8_traffic.json") for r in (3, 2))
+              if os.path.exists(q)), "")
     if world == 1 and tpath:
         traffic = json.load(open(tpath))["avg_hbm_bytes_per_launch"]
+
+    # N > 1: who took part (all-reduce of ones + every rank's device identity), and a bounded BASELINE configs[2] figure:
+    # 32 greedy-decode tokens through the same layer pipeline, rank 0 re-decoding them in one process to compare the ids.
+    # After the timed region; every rank runs it.
+    census = rank_census(dev) if world > 1 else None
+    decode_fig = None
+    if world > 1 and not args.no_decode_pipeline:
+        from mxq_amd.llama_decode import decode_pipeline_figure
+        del layers
+        torch.cuda.empty_cache()
+        decode_fig = decode_pipeline_figure(pipe, dev, tokens=32, ctx=64, verify=True, dist=dist, backend=backend)
+        layers = []
     if rank == 0:
-        bpw = sum(p.nbytes() for lin in layers for _, p in lin) * 8.0 / (LS.PARAMS_PER_LAYER * len(my_layers))
+        bpw = bits_per_weight
         out = {
             "metric": "quantized-Linear TFLOP/s, Llama-2-7B W2/4A16 all-Linear prefill (tokens/s alongside)",
             "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
@@ -287,10 +304,21 @@ def main():
                        f"[2048,4096] fp16 hidden state"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": (f"offline constant: rocprofv3 PMC passes of this bench "
+                                            f"(2*FETCH_SIZE + WRITE_SIZE per launch), {os.path.relpath(tpath, ROOT)}; "
+                                            "not measured in this run") if traffic is not None else None,
                          "kernel": "mxq_gemm8_f16_kernel", "avg_launch_ms": round(kern_ms, 5),
                          "launches_per_step": launches_rank_step,
                          "algorithmic_flop_per_launch": flops_rank_step / launches_rank_step},
         }
+        if census is not None:
+            out["ranks_seen"] = census["ranks_seen"]
+            out["distinct_devices"] = census["distinct_devices"]
+            out["ranks"] = census["ranks"]
+            out["backend"] = backend
+        if decode_fig is not None:
+            decode_fig.pop("token_ids", None)
+            out["decode_pipeline"] = decode_fig
         if world == 1 and not args.fuse:
             out["long_prefill"] = long_prefill(layers, dev)
         if world == 1 and not args.no_cpu_baseline:

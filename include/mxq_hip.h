@@ -104,13 +104,15 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * `workspace` is device memory of at least mxq_gemm_workspace_bytes() bytes, 16-byte aligned, whose
  * first 64 KiB the caller zeroes ONCE (hipMemset) before first use; the kernels leave it zeroed, so
  * it can be reused by every later launch on the SAME stream (launches on different streams need
- * different workspaces).  workspace == NULL selects the workspace-free schedule of mxq_linear_f16.
+ * different workspaces).  workspace == NULL selects the workspace-free schedule of mxq_linear_f16; a workspace too small
+ * for the mid-M kernel's partial tiles hands 41..256 tokens to the prefill kernel.
  * The tail is only split where that pays (about 24 idle K-steps per CU; it does for 128 < M <= 1024 on
  * the Llama shapes, not for gate/up at M = 2048).
  * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 8 = the
  * 256x128-tile kernel (MFMA waves stream x, dedicated waves dequantise, persistent over tiles, stream-K tail;
  * csrc/gemm8.hip) at any M, 9 = the same but splitting its tail whenever that is structurally possible (tests),
- * 10 = the mid-M split-K kernel (csrc/midm.hip) at any M;
+ * 10 = the mid-M split-K kernel (csrc/midm.hip) at any M, 20 = the 8-wave kernel whose waves convert the weight tile
+ * between their own MFMAs (csrc/gemm10.hip; bit-identical to 8), 21 = the same with its tail always split (as 9);
  * anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
  * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
  * used by tools/ alone: they are not part of this ABI.) */
@@ -129,8 +131,8 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
 int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                              int layout, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Hoisted-dequant mode of the same Linear, for launches that cover many token tiles (batch x seq >= ~8k tokens, e.g.
- * BASELINE configs[4]): the fused kernel dequantises each 128 x 64 weight tile once per 256 tokens; here the bit-exact
+/* Hoisted-dequant mode of the same Linear, for launches that cover many token tiles (batch x seq >= 4096 tokens, e.g.
+ * BASELINE configs[4]; mxq_hoist_min_tokens()): the fused kernel dequantises each 128 x 64 weight tile once per 256 tokens; here the bit-exact
  * dequant kernel writes fp16 weights into `w16_scratch` (>= mxq_hoist_scratch_bytes(N, K) = 2*N*K bytes of device
  * memory, 16-byte aligned, overwritten) ONCE and the MFMA kernel streams fp16 tiles from it -- same products, same
  * summation order, results bit-identical to mxq_gemm_f16_layout.  The scratch is transient (nothing is cached
@@ -138,6 +140,15 @@ int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* row
 size_t mxq_hoist_scratch_bytes(int N, int K);
 int mxq_linear_f16_hoisted(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                            int layout, void* w16_scratch, size_t scratch_bytes, void* stream);
+
+/* ONE call for the whole dispatch -- the counterpart of the reference's single entry, whose launcher picks its schedule
+ * inside (gemm_cuda.h:3-4, gemm_cuda_gen.cu:424-478: tile kernel by OC, split_k_iters): streaming GEMV, skinny MFMA kernel,
+ * mid-M split-K kernel, fused prefill GEMM with its stream-K tail (mxq_linear_f16_layout_ws with `workspace`, which may
+ * be NULL), and -- from mxq_hoist_min_tokens() tokens on, when `w16_scratch` holds mxq_hoist_scratch_bytes(N, K) bytes --
+ * the hoisted-dequant mode above.  A NULL or too small scratch never fails: the fused kernel runs instead. */
+int mxq_hoist_min_tokens(void);
+int mxq_linear_f16_auto(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
+                        void* workspace, size_t workspace_bytes, void* w16_scratch, size_t scratch_bytes, void* stream);
 
 /* The second half of the hoisted mode on its own = the reference's implicit nn.Linear on the fake-quant fp16 weight
  * (mxq_quant/main.py:85 -> lib/eval.py:54): y[M, N] = x[M, K] . w16[N, K]^T, fp16 operands, fp32

@@ -45,6 +45,9 @@ SIGNATURES = {
     "mxq_gemm_workspace_bytes": (c_size_t, []),
     "mxq_hoist_scratch_bytes": (c_size_t, [c_int, c_int]),
     "mxq_linear_f16_hoisted": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "mxq_hoist_min_tokens": (c_int, []),
+    "mxq_linear_f16_auto": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t,
+                                    c_void_p]),
     "mxq_dense_f16": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_linear_f16_ws": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "mxq_linear_f16_layout_ws": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -201,7 +201,7 @@ int mxq_gemm_f16_layout(const void* x, const void* qweight, const void* rowmeta,
 static int dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, int variant, hipStream_t stream) {
     if (variant != 1) {
         const int e = mxq_launch_dense256_f16(x, w16, y, M, N, K, variant == 2, stream);
-        if (e != -2) return e;
+        if (e != MXQ_NOT_MY_SHAPE) return e;
         if (variant == 2) return MXQ_E_SHAPE;
     }
     return mxq_launch_gemm8_dense_f16(x, w16, y, M, N, K, stream);
@@ -262,21 +262,31 @@ static int gemm_ws(const void* x, const void* qweight, const void* rowmeta, void
                    void* workspace, size_t ws_bytes, hipStream_t stream) {
     // with a workspace the wave-specialised kernel wins at every token count (its stream-K split keeps all
     // CUs busy when there are few tiles: 64 tokens x 4096^2 34 us vs 57 us for the 128-row-tile kernel);
-    // without one, mxq_linear_f16's dispatch
+    // without one (mxq_gemm_f16_ws variant 0 only: mxq_linear_f16_ws forwards to mxq_linear_f16) the 128 x 128 kernel
     if (!workspace) return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, stream);
     return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, 0, stream);
 }
 
+// the mid-M kernel needs the workspace beyond its 64-KiB head for at least two slices' partial tiles per output tile;
+// with less it would run unsplit (44-54 us at 4096^2 where the prefill kernel's stream-K tail takes 34)
+static bool midm_ws_ok(int M, int N, size_t ws_bytes) {
+    const size_t tiles = (size_t)((M + 127) / 128) * ((N + 127) / 128);
+    return ws_bytes >= (size_t)65536 + tiles * 2 * 128 * 128 * sizeof(float);
+}
+
 int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace) return mxq_linear_f16(x, qweight, rowmeta, y, M, N, K, stream);   // the workspace-free dispatch
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
-    if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
+    if (!aligned16(workspace)) return MXQ_E_ALIGN;
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-    if (M <= (workspace ? skinny_max_tokens(N, K) : 48))
+    if (M <= skinny_max_tokens(N, K))
         return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
-    if (M <= MIDM_MAX_TOKENS && workspace)
-        return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
-                                   (hipStream_t)stream);
+    if (M <= MIDM_MAX_TOKENS && midm_ws_ok(M, N, workspace_bytes)) {
+        const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
+                                          (hipStream_t)stream);
+        if (e != MXQ_E_SHAPE) return e;      // a shape beyond its 32-bit offsets: the prefill kernel takes it
+    }
     return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -289,14 +299,31 @@ int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* row
         return mxq_linear_f16_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, stream);
     if (M <= 4) return mxq_launch_gemv_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
     if (layout == MXQ_LAYOUT_MIXEDC) {
-        if (M <= (workspace ? skinny_max_tokens(N, K) : 48))
+        if (M <= (workspace ? skinny_max_tokens(N, K) : 64))
             return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
-        if (M <= MIDM_MAX_TOKENS && workspace)
-            return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, 0, 0,
-                                       (hipStream_t)stream);
+        if (M <= MIDM_MAX_TOKENS && (!workspace || midm_ws_ok(M, N, workspace_bytes))) {
+            const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, 0, 0,
+                                              (hipStream_t)stream);
+            if (e != MXQ_E_SHAPE) return e;
+        }
     }
     return mxq_launch_gemm8_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes,
                                        (hipStream_t)stream);
+}
+
+// Token count from which hoisting the dequant out of the token loop (dequant pass + dense 256 x 256 kernel) beats the
+// fused kernel on the Llama shapes (tools/ab_gemm.py; profiles/r03_dense256.txt)
+static const int HOIST_MIN_TOKENS = 4096;
+int mxq_hoist_min_tokens(void) { return HOIST_MIN_TOKENS; }
+
+int mxq_linear_f16_auto(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
+                        void* workspace, size_t workspace_bytes, void* w16_scratch, size_t scratch_bytes, void* stream) {
+    if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
+    if (!layout_ok(layout)) return MXQ_E_SHAPE;
+    if (w16_scratch && !aligned16(w16_scratch)) return MXQ_E_ALIGN;
+    if (M >= HOIST_MIN_TOKENS && w16_scratch && scratch_bytes >= (size_t)N * K * 2)
+        return mxq_linear_f16_hoisted(x, qweight, rowmeta, y, M, N, K, layout, w16_scratch, scratch_bytes, stream);
+    return mxq_linear_f16_layout_ws(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, stream);
 }
 
 int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -311,6 +338,9 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (variant == 8 || variant == 9)
         return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 9,
                                     (hipStream_t)stream);
+    if (variant == 20 || variant == 21)   // the 8-wave kernel with the conversion inside the MFMA waves; 21: tail always split
+        return mxq_launch_gemm10_layout_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes,
+                                            variant == 21, (hipStream_t)stream);
     return MXQ_E_SHAPE;
 }
 

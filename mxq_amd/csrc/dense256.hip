@@ -300,10 +300,10 @@ int cu_count8() {
 
 }   // namespace
 
-// -> 0 launched; -2 the shape is not this kernel's (K-tile count odd or < 2, rows beyond the 32-bit descriptor offsets, or
+// -> 0 launched; MXQ_NOT_MY_SHAPE: the shape is not this kernel's (K-tile count odd or < 2, rows beyond the 32-bit descriptor offsets, or
 // -- unless force -- a tile count that fills the chip too unevenly): the caller takes the 256 x 128 kernel
 int mxq_launch_dense256_f16(const void* x, const void* w16, void* y, int M, int N, int K, int force, hipStream_t stream) {
-    if (K % (2 * BK) != 0 || K < 2 * BK || (int64_t)BM * K * 2 >= ((int64_t)1 << 32)) return -2;
+    if (K % (2 * BK) != 0 || K < 2 * BK || (int64_t)BM * K * 2 >= ((int64_t)1 << 32)) return MXQ_NOT_MY_SHAPE;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
     const int cus = cu_count8();
     if (!force) {
@@ -312,7 +312,7 @@ int mxq_launch_dense256_f16(const void* x, const void* w16, void* y, int M, int 
         const int t128 = tiles_m * ((N + 127) / 128);
         const double e256 = (double)tiles / ((double)((tiles + cus - 1) / cus) * cus);
         const double e128 = (double)t128 / ((double)((t128 + cus - 1) / cus) * cus);
-        if (1.17 * e256 < e128) return -2;
+        if (1.17 * e256 < e128) return MXQ_NOT_MY_SHAPE;
     }
     hipError_t e = hipFuncSetAttribute((const void*)mxq_dense256_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;

@@ -31,14 +31,22 @@ int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta
                          hipStream_t stream);   // 256x128 tile: MFMA waves stream x, dedicated waves dequantise; stream-K tail with a workspace (gemm8.hip); force: split even when it does not pay
 int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K,
                                hipStream_t stream);   // hoisted-dequant mode: w16 = dense fp16 [N, K] weight
-// the same product with a 256 x 256 tile and a quadrant-phase ping-pong schedule (dense256.hip); -2: not this kernel's
-// shape (odd K-tile count, or -- unless force -- too few tiles to fill the chip twice): take the kernel above
+// internal "take the other kernel" return of a launcher that declines a shape (never leaves capi.hip; distinct from
+// every MXQ_E_* code and every hipError_t)
+#define MXQ_NOT_MY_SHAPE (-1000)
+// the same product with a 256 x 256 tile and a quadrant-phase ping-pong schedule (dense256.hip); MXQ_NOT_MY_SHAPE: odd
+// K-tile count, or -- unless force -- too few tiles to fill the chip twice: take the kernel above
 int mxq_launch_dense256_f16(const void* x, const void* w16, void* y, int M, int N, int K, int force, hipStream_t stream);
 int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
+// 256 x 128 tile, EIGHT waves: every wave converts its share of the weight tile between its own MFMAs (gemm10.hip);
+// gemm8's persistent loop, stream-K tail and workspace; force: split the tail even when it does not pay
+int mxq_launch_gemm10_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                 int layout, void* workspace, size_t ws_bytes, int force, hipStream_t stream);
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream);
-// skinny MFMA kernel, 1 <= M <= 64 (skinny.hip; the dispatch uses it for 5..48 tokens); layout MXQ_LAYOUT_MIXED or MXQ_LAYOUT_MIXEDC
+// skinny MFMA kernel, 1 <= M <= 64 (skinny.hip; the dispatch uses it for 5..40 tokens with a workspace -- 20 for weights
+// beyond 24 M elements -- and up to 64 without one: capi.hip skinny_max_tokens); layout MXQ_LAYOUT_MIXED or MXQ_LAYOUT_MIXEDC
 int mxq_launch_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                           int layout, hipStream_t stream);
 // mid-size token counts (48 < M <= ~1024): split-K over workgroups + combine (midm.hip); layout MXQ_LAYOUT_MIXED / MIXEDC;

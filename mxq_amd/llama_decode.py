@@ -236,3 +236,77 @@ class DecodeStage:
         self.pos.zero_()
         self.k_cache.zero_()
         self.v_cache.zero_()
+
+
+def decode_pipeline_figure(pipe, dev, tokens: int = 32, ctx: int = 64, layers: int = LS.N_LAYERS, compact: bool = False,
+                           verify: bool = False, graph: bool = True, warm: int = 8, dist=None, backend: str = "nccl") -> dict:
+    """BASELINE configs[2] as one measurement: greedy decode of ``tokens`` tokens at batch 1 with the decoder layers
+    sharded over ``pipe``'s ranks (rank r owns ``layer_range(r, world, layers)``), the hidden state and the next-token
+    id moving point to point (pipeline.LayerPipeline.decode).  Every rank calls it; every rank returns the same kind of
+    dict, rank 0's carries the token ids.  ``verify`` (world > 1): rank 0 also decodes the same tokens in ONE process
+    (all layers, token-loop graph) and reports whether the ids are identical (``tokens_equal_single_process``).
+    Used by tools/decode_bench.py and by bench.py's ``decode_pipeline`` side figure (reference analogue: accelerate's
+    layer placement, mxq_quant/main.py:23, lib/prune.py:371-378)."""
+    import time
+    from .pipeline import layer_range
+    world, rank = pipe.world, pipe.rank
+    stage = DecodeStage(layer_range(rank, world, layers), dev, max_ctx=ctx, first=pipe.is_first, last=pipe.is_last,
+                        compact=compact)
+    if graph:
+        stage.capture()
+    hbuf = torch.zeros(1, stage.hidden, device=dev, dtype=torch.float16)
+    tbuf = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def stage_fn(h, step):
+        if not graph:
+            out = stage.step(h)
+            stage.advance()
+            return out
+        return stage.step_graph(h)
+
+    single = world == 1 and graph
+    if single:
+        stage.capture_token_loop(tbuf)     # token -> token in one graph (embedding, layers, head, argmax)
+
+    def run(n):
+        stage.reset()
+        if single:
+            return stage.decode_tokens(tbuf, 1, n)
+        return pipe.decode(1, n, stage.embed_token if pipe.is_first else None, stage_fn,
+                           stage.head if pipe.is_last else None, hbuf, tbuf)
+
+    if max(warm, tokens) > ctx:
+        raise ValueError("ctx must hold the warm-up run and the timed run (each starts at position 0)")
+    run(warm)
+    torch.cuda.synchronize(dev)
+    if dist is not None and world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    toks = run(tokens)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    nbytes = torch.tensor([float(stage.packed_bytes())], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+    if dist is not None and world > 1:
+        dist.all_reduce(nbytes)
+    equal = None
+    if verify and world > 1 and rank == 0:
+        del stage
+        ref = DecodeStage(range(layers), dev, max_ctx=ctx, first=True, last=True, compact=compact)
+        rtok = torch.zeros(1, dtype=torch.int64, device=dev)
+        ref.capture_token_loop(rtok)
+        ref.reset()
+        want = ref.decode_tokens(rtok, 1, tokens)
+        equal = want == toks
+        bad = next((i for i, (a, b) in enumerate(zip(want, toks)) if a != b), None)
+        del ref
+    else:
+        bad = None
+    return {"config": "BASELINE configs[2]: Llama-2-7B W2/4A16 greedy decode, batch 1, whole layers sharded over the ranks",
+            "n_gpus": world, "layers": layers, "tokens": tokens, "ctx": ctx,
+            "tokens_per_s": round(tokens / dt, 1), "ms_per_token": round(dt / tokens * 1e3, 3),
+            "packed_weight_GB_per_token": round(nbytes.item() / 1e9, 3),
+            "weight_stream_GBps": round(nbytes.item() / (dt / tokens) / 1e9, 1),
+            "metadata_mode": "compact (fp16 zero-points)" if compact else "exact (fp32 zero-points)",
+            "hipgraph": bool(graph), "first_tokens": toks[:8], "token_ids": toks,
+            "backend": backend if world > 1 else None,
+            "tokens_equal_single_process": equal, "first_mismatch": bad}

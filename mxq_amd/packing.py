@@ -74,7 +74,7 @@ def gemm_workspace(device: torch.device, counters: bool = True) -> torch.Tensor:
 
 
 _HOIST: Dict[tuple, torch.Tensor] = {}
-HOIST_MIN_TOKENS = 4096     # "auto" hoists the dequant out of the token loop from this many tokens on (tools/ab_gemm.py)
+HOIST_MIN_TOKENS = 4096     # mxq_hoist_min_tokens(): "auto" hoists the dequant out of the token loop from this many tokens on
 
 
 def hoist_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
@@ -96,7 +96,8 @@ def _layout_code(p) -> int:
 
 def linear_hoisted(x: torch.Tensor, p, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Quantised Linear with the dequant hoisted out of the token loop (dequant kernel once into a scratch buffer,
-    then the MFMA kernel on fp16 tiles): bit-identical to the fused GEMM, faster from ~8k tokens per launch."""
+    then the MFMA kernel on fp16 tiles): bit-identical to the fused GEMM, faster from HOIST_MIN_TOKENS (4096) tokens per
+    launch (profiles/r03_dense256.txt)."""
     _need_gpu(x, p.qweight)
     if x.dtype != torch.float16 or x.shape[-1] != p.K:
         raise ValueError("activations must be fp16 [..., in_features]")
@@ -305,7 +306,7 @@ def linear_dense(x: torch.Tensor, w16: torch.Tensor, out: Optional[torch.Tensor]
     return out.reshape(*x.shape[:-1], N)
 
 
-GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
+GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10, "gemm10": 20, "gemm10sk": 21}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
 
 
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
@@ -332,10 +333,24 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         raise ValueError("out must be a contiguous float16 [tokens, out_features] tensor")
     if M == 0:
         return out.reshape(*x.shape[:-1], p.N)
-    if path == "hoist" or (path in ("auto", "gemm") and M >= HOIST_MIN_TOKENS):
+    if path == "hoist":
         return linear_hoisted(x, p, out=out)
     lib = _lib.load()
     args = (x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K)
+    if path == "auto" and M > 4:
+        # ONE C call for the whole dispatch (include/mxq_hip.h: mxq_linear_f16_auto): skinny / mid-M split-K / fused
+        # prefill kernel with its stream-K tail / hoisted-dequant mode, chosen inside the library by token count
+        hoists = M >= HOIST_MIN_TOKENS
+        ws = gemm_workspace(x2.device, counters=M > MIDM_MAX_TOKENS and not hoists)
+        scratch = hoist_scratch(x2.device, lib.mxq_hoist_scratch_bytes(p.N, p.K)) if hoists else None
+        with torch.cuda.device(x.device):
+            _lib.check(lib.mxq_linear_f16_auto(*args, _layout_code(p), ws.data_ptr(), ws.numel(),
+                                               scratch.data_ptr() if scratch is not None else None,
+                                               scratch.numel() if scratch is not None else 0, _stream(x2)),
+                       "mxq_linear_f16_auto")
+        return out.reshape(*x.shape[:-1], p.N)
+    if path == "gemm" and M >= HOIST_MIN_TOKENS:
+        return linear_hoisted(x, p, out=out)
     if path == "skinny":
         with torch.cuda.device(x.device):
             _lib.check(lib.mxq_skinny_f16(*args, 3 if p.compact else 0, _stream(x2)), "mxq_skinny_f16")
@@ -344,13 +359,8 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         if path not in ("auto", "gemm", "gemv", "gemm8", "fused"):
             raise ValueError(f"path {path!r} is not available for compact metadata")
         with torch.cuda.device(x.device):
-            if path == "auto" and M > 4:        # skinny / mid-M split-K / prefill kernel by token count and weight size (capi.hip)
-                ws = gemm_workspace(x2.device, counters=M > MIDM_MAX_TOKENS)
-                _lib.check(lib.mxq_linear_f16_layout_ws(*args, 3, ws.data_ptr(), ws.numel(), _stream(x2)),
-                           "mxq_linear_f16_layout_ws[compact]")
-            else:
-                fn = lib.mxq_gemv_f16_layout if path == "gemv" or (path == "auto" and M <= 4) else lib.mxq_gemm_f16_layout
-                _lib.check(fn(*args, 3, _stream(x2)), f"mxq_linear_f16[{path}, compact]")
+            fn = lib.mxq_gemv_f16_layout if path == "gemv" or (path == "auto" and M <= 4) else lib.mxq_gemm_f16_layout
+            _lib.check(fn(*args, 3, _stream(x2)), f"mxq_linear_f16[{path}, compact]")
         return out.reshape(*x.shape[:-1], p.N)
     with torch.cuda.device(x.device):
         if path == "gemv":
@@ -360,7 +370,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         else:
             midm = path == "midm" or (path == "auto" and M <= MIDM_MAX_TOKENS)
             ws = (gemm_workspace(x2.device, counters=not midm)
-                  if path in ("auto", "gemm", "fused", "gemm8", "gemm9", "midm") else None)
+                  if path in ("auto", "gemm", "fused", "gemm8", "gemm9", "midm", "gemm10", "gemm10sk") else None)
             wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
             if path == "auto":
                 rc = lib.mxq_linear_f16_ws(*args, wsp, wsn, _stream(x2))

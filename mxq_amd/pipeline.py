@@ -50,6 +50,35 @@ def layer_range(rank: int, world: int, n_layers: int) -> range:
     return range(n_layers * rank // world, n_layers * (rank + 1) // world)
 
 
+def rank_census(dev=None, group=None) -> dict:
+    """Who took part: every rank contributes a one (all-reduce, on the device for RCCL) and its identity -- rank, pid,
+    host, device index and the device's UUID / PCI bus id -- gathered onto every rank.  ``ranks_seen == world`` and
+    ``distinct_devices == world`` in a bench line prove that N processes ran on N different GPUs (bench.py --gpus N;
+    a gloo rehearsal on one GPU shows ``distinct_devices`` 1)."""
+    import os
+    import socket
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    me = {"rank": rank, "pid": os.getpid(), "host": socket.gethostname(), "device_index": None, "device": None,
+          "device_id": None}
+    if dev is not None and torch.cuda.is_available():
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(idx)
+        ident = getattr(props, "uuid", None)
+        if ident is None or not str(ident).strip("0-"):
+            ident = ":".join(str(getattr(props, k, "?")) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        me.update(device_index=idx, device=props.name, device_id=f"{me['host']}/{ident}")
+    if world == 1:
+        return {"ranks_seen": 1, "distinct_devices": 1 if me["device_id"] else 0, "ranks": [me]}
+    staged = dev is not None and dev.type == "cuda" and "nccl" not in str(dist.get_backend(group))
+    one = torch.ones(1, dtype=torch.int32, device="cpu" if (dev is None or staged) else dev)
+    dist.all_reduce(one, group=group)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me, group=group)
+    ids = {r["device_id"] for r in ranks if r and r["device_id"]}
+    return {"ranks_seen": int(one.item()), "distinct_devices": len(ids), "ranks": ranks}
+
+
 class LayerPipeline:
     """Point-to-point activation pipeline between consecutive ranks of ``group``.
 
@@ -63,6 +92,7 @@ class LayerPipeline:
         if rank is None:
             rank = dist.get_rank(group) if world > 1 else 0
         self.rank, self.world = rank, world
+        self._device_capable = None       # does the group's backend move device memory (RCCL)?  decided on first use
 
     def _peer(self, group_rank: int) -> int:
         """Global rank of member ``group_rank`` of this pipeline's group."""
@@ -78,7 +108,17 @@ class LayerPipeline:
     # therefore staged through host memory here: .cpu() synchronises with the producing stream, copy_() back is
     # stream-ordered.  CPU tensors (the gloo unit tests) and RCCL go straight through.
     def _staged(self, t: torch.Tensor) -> bool:
-        return t.is_cuda and dist.get_backend(self.group) != "nccl"
+        # by capability, not by name equality: a group created without an explicit backend reports a composite
+        # ("cpu:gloo,cuda:nccl" / "undefined") and still moves device tensors with RCCL
+        if not t.is_cuda:
+            return False
+        if self._device_capable is None:
+            try:
+                cfg = str(dist.get_backend_config(self.group))
+            except Exception:
+                cfg = str(dist.get_backend(self.group))
+            self._device_capable = "nccl" in cfg
+        return not self._device_capable
 
     def _send(self, t: torch.Tensor, dst: int) -> None:
         dist.send(t.cpu() if self._staged(t) else t, dst=dst, group=self.group)
@@ -157,10 +197,13 @@ class LayerPipeline:
                 s = b % 2
                 if swork[s] is not None:
                     swork[s].wait()             # isend(b-2) done: its ring slot is free
-                if sbuf[s] is None:
-                    sbuf[s] = torch.empty_like(h, memory_format=torch.contiguous_format)
-                sbuf[s].copy_(h)
-                swork[s] = self._isend(sbuf[s], dst)
+                if self._staged(h):             # host-memory backend: .cpu() IS the copy out of the stage's buffer
+                    swork[s] = self._isend(h, dst)
+                else:
+                    if sbuf[s] is None:
+                        sbuf[s] = torch.empty_like(h, memory_format=torch.contiguous_format)
+                    sbuf[s].copy_(h)
+                    swork[s] = self._isend(sbuf[s], dst)
             elif collect:
                 outs.append(h.clone() if (rbuf is not None and any(h is r for r in rbuf)) else h)
         for w in swork:

@@ -342,7 +342,7 @@ def test_quantizer_reproduces_fasterquant_loop_g1(dev, g1):
 # ----------------------------------------------------------------------------------------
 # dequant-GEMM / GEMV
 # ----------------------------------------------------------------------------------------
-GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm"]      # packing.GEMM_PATHS: every kernel the product library ships
+GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm", "gemm10", "gemm10sk"]      # packing.GEMM_PATHS: every kernel the product library ships
 
 
 def _packed_case(dev, N, K, seed):
@@ -414,7 +414,8 @@ def test_gemm_integer_exact_layout(dev):
                                    (1024, 4224, 2048),    # 132 tiles: XCDs 0-3 hold 17 tail tiles, 4-7 hold 16
                                    (100, 1152, 8192),     # 9 tiles: XCD 0 holds two, the others one; half-empty 256-row tile
                                    (2048, 5120, 1024)])   # 320 tiles = one full round + a 64-tile tail
-def test_gemm_stream_k_tail(dev, M, N, K, sk="gemm9"):
+@pytest.mark.parametrize("sk", ["gemm9", "gemm10sk"])
+def test_gemm_stream_k_tail(dev, M, N, K, sk):
     """csrc/gemm8.hip: tiles beyond the last full round of CUs are split along K over all CUs and
     reduced through the workspace.  Checks (1) against the oracle matmul, (2) that the workspace
     counters are left zeroed, (3) run-to-run bit-determinism, (4) agreement with the 128x128-tile
@@ -437,7 +438,8 @@ def test_gemm_stream_k_tail(dev, M, N, K, sk="gemm9"):
     assert torch.equal(packing.linear(xd, p, path="gemm8"), yd)
 
 
-def test_stream_k_partition_fuzz(dev, sk="gemm9"):
+@pytest.mark.parametrize("sk", ["gemm9", "gemm10sk"])
+def test_stream_k_partition_fuzz(dev, sk):
     """Random (tokens, out, in) shapes through the forced stream-K schedule against the single-tile kernel:
     exercises unit ranges that start / end anywhere inside tiles, XCDs with unequal tail lengths, units with
     one, two and many segments, ragged M and N edges."""
@@ -458,6 +460,65 @@ def test_stream_k_partition_fuzz(dev, sk="gemm9"):
         assert torch.equal(packing.linear(x, p, path=sk).float(), y), (M, N, K)
     ws = packing.gemm_workspace(torch.device(dev))
     assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 4096, 4096), (2048, 11008, 4096), (2048, 4096, 11008), (300, 144, 192),
+                                   (1000, 2064, 704), (256, 128, 64), (257, 4096, 128), (640, 11008, 4096)])
+def test_gemm10_equals_gemm8_bit_for_bit(dev, M, N, K):
+    """csrc/gemm10.hip (8 waves, conversion inside the MFMA waves) forms the same fp16 weights, the same products and the
+    same sums in the same order as csrc/gemm8.hip: identical output bits, with and without the stream-K split, at the
+    bench's three shapes and at ragged ones (one K-step, two, an odd count; N below a tile; a 2-tile tail)."""
+    from mxq_amd import packing
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    p = packing.quantize_pack((torch.randn(N, K, generator=g, device=dev) * 0.02).half())
+    x = torch.randn(M, K, generator=g, device=dev).half()
+    y8 = packing.linear(x, p, path="gemm8")
+    assert torch.equal(packing.linear(x, p, path="gemm10"), y8)
+    assert torch.equal(packing.linear(x, p, path="gemm10sk"), packing.linear(x, p, path="gemm9"))
+    r = x.float() @ packing.dequant(p).float().t()
+    assert ((y8.float() - r).abs().max() / r.abs().max()).item() <= REL_TOL
+
+
+def test_linear_auto_c_entry_takes_the_fastest_path(dev):
+    """include/mxq_hip.h: mxq_linear_f16_auto -- ONE C call for the whole dispatch.  From mxq_hoist_min_tokens() tokens on
+    and given a scratch buffer it runs the hoisted-dequant mode (bit-identical to mxq_linear_f16_hoisted and to the fused
+    kernel); without a scratch, or below the threshold, the _ws dispatch; every layout."""
+    from mxq_amd import _lib, packing
+    lib = _lib.load()
+    assert lib.mxq_hoist_min_tokens() == packing.HOIST_MIN_TOKENS
+    g = torch.Generator(device=dev).manual_seed(4)
+    N, K = 512, 1024
+    W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
+    ws = packing.gemm_workspace(torch.device(dev))
+    scratch = torch.empty(lib.mxq_hoist_scratch_bytes(N, K), dtype=torch.uint8, device=dev)
+    cases = [(packing.quantize_pack(W), 0), (packing.quantize_pack(W, compact_meta=True), 3),
+             (packing.quantize_pack_uniform(W, "w2g16"), 1), (packing.quantize_pack_uniform(W, "w4row"), 2)]
+    for M in (4096, 4100, 100, 3):
+        x = torch.randn(M, K, generator=g, device=dev).half()
+        for p, layout in cases:
+            args = (x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr())
+            y = torch.empty(M, N, dtype=torch.float16, device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(lib.mxq_linear_f16_auto(*args, y.data_ptr(), M, N, K, layout, ws.data_ptr(), ws.numel(),
+                                               scratch.data_ptr(), scratch.numel(), st), "auto")
+            y2 = torch.empty_like(y)
+            _lib.check(lib.mxq_linear_f16_auto(*args, y2.data_ptr(), M, N, K, layout, ws.data_ptr(), ws.numel(), None, 0, st), "auto")
+            ref = x.float() @ (packing.dequant(p) if layout in (0, 3) else packing.expand_uniform(p, codes=False)[0]).float().t()
+            for got in (y, y2):
+                assert ((got.float() - ref).abs().max() / ref.abs().max()).item() <= REL_TOL, (M, layout)
+            if M >= 4096:
+                yh = torch.empty_like(y)
+                _lib.check(lib.mxq_linear_f16_hoisted(*args, yh.data_ptr(), M, N, K, layout, scratch.data_ptr(),
+                                                      scratch.numel(), st), "hoisted")
+                assert torch.equal(y, yh) and torch.equal(y, y2), (M, layout)     # hoisted == fused, bit for bit
+    # a scratch that is too small never fails: the fused kernel runs
+    p, layout = cases[0]
+    x = torch.randn(4096, K, generator=g, device=dev).half()
+    y = torch.empty(4096, N, dtype=torch.float16, device=dev)
+    assert lib.mxq_linear_f16_auto(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), y.data_ptr(), 4096, N, K, 0,
+                                   ws.data_ptr(), ws.numel(), scratch.data_ptr(), 1024,
+                                   torch.cuda.current_stream().cuda_stream) == 0
+    assert torch.equal(y, packing.linear(x, p, path="fused"))
 
 
 def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from mxq_amd.pipeline import LayerPipeline, layer_range
+from mxq_amd.pipeline import LayerPipeline, layer_range, rank_census
 
 N_LAYERS, HID, VOCAB = 6, 32, 50
 
@@ -57,6 +57,10 @@ def _worker(rank, world, port, q):
         assert pipe.run_microbatches(lambda h: ybuf.copy_(h * 2), xs * 3, torch.empty(4, HID), collect=False) == []
         gen = pipe.decode(3, 6, lambda t: emb.index_select(0, t), fn, lambda h: (h @ head.t()).argmax(-1),
                           torch.empty(1, HID), torch.zeros(1, dtype=torch.int64))
+        # bench.py's proof of participation: every rank counted once, every rank's identity on every rank
+        cen = rank_census()
+        assert cen["ranks_seen"] == world and [r["rank"] for r in cen["ranks"]] == list(range(world))
+        assert len({r["pid"] for r in cen["ranks"]}) == world and cen["distinct_devices"] == 0    # CPU run: no device
         # by value (numpy), not as shared-memory tensors: a shared tensor must be rebuilt while its producer still runs
         q.put((rank, [o.numpy().copy() for o in outs], gen))
         dist.barrier()
