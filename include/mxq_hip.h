@@ -91,7 +91,7 @@ int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void
 /* The code paths of mxq_linear_f16, exposed for benchmarking / testing: streaming GEMV (M <= 4), skinny MFMA kernel
  * (5..40 tokens in the dispatch: every packed byte read once, a lane dequantises the MFMA operand it owns; the reference
  * re-reads the weights once per batch row, gemv_mxq_cuda.cu:261-262), prefill GEMM.  mxq_skinny_f16 accepts 1 <= M <= 64
- * and layout MXQ_LAYOUT_MIXED (0) or MXQ_LAYOUT_MIXEDC (3, compact metadata, below). */
+ * and any layout (MXQ_LAYOUT_*, below: mixed with exact or compact metadata, W2G16, W4ROW). */
 int mxq_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
                    void* stream);
 int mxq_gemm_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -111,8 +111,7 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 8 = the
  * 256x128-tile kernel (MFMA waves stream x, dedicated waves dequantise, persistent over tiles, stream-K tail;
  * csrc/gemm8.hip) at any M, 9 = the same but splitting its tail whenever that is structurally possible (tests),
- * 10 = the mid-M split-K kernel (csrc/midm.hip) at any M, 20 = the 8-wave kernel whose waves convert the weight tile
- * between their own MFMAs (csrc/gemm10.hip; bit-identical to 8), 21 = the same with its tail always split (as 9);
+ * 10 = the mid-M split-K kernel (csrc/midm.hip) at any M;
  * anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
  * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
  * used by tools/ alone: they are not part of this ABI.) */
@@ -122,8 +121,9 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
 int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                     int variant, void* workspace, size_t workspace_bytes, void* stream);
 /* mxq_linear_f16_ws for a weight in any layout (MXQ_LAYOUT_*: mixed with exact or compact metadata, W2G16, W4ROW).
- * Dispatch by token count: <= 4 the streaming GEMV, then the skinny MFMA kernel (up to 40 tokens, 20 for weights of more
- * than 24 M elements, where its time has overtaken the split-K kernel's) and up to 256 tokens the mid-M split-K
+ * Dispatch by token count: <= 4 the streaming GEMV, then the skinny MFMA kernel (mixed layouts: up to 40 tokens, 20 for
+ * weights of more than 24 M elements, where its time has overtaken the split-K kernel's; uniform layouts: up to 48, where
+ * the prefill kernel takes over) and up to 256 tokens the mid-M split-K
  * kernel (csrc/midm.hip: K cut into slices over the workgroups, fp32 partial tiles in the workspace beyond its first
  * 64 KiB, summed in slice order by a second launch -- the reference launcher's split_k_iters regime,
  * gemm_cuda_gen.cu:429-475) for the mixed layouts, the prefill kernel otherwise.  The mid-M kernel does not touch

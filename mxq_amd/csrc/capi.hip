@@ -10,6 +10,9 @@ namespace {
 inline bool shape_ok(int N, int K) { return N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0; }
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 inline bool dtype_ok(int d) { return d == MXQ_DTYPE_F32 || d == MXQ_DTYPE_F16 || d == MXQ_DTYPE_BF16; }
+inline bool layout_ok(int l) {
+    return l == MXQ_LAYOUT_MIXED || l == MXQ_LAYOUT_W2G16 || l == MXQ_LAYOUT_W4ROW || l == MXQ_LAYOUT_MIXEDC;
+}
 }   // namespace
 
 extern "C" {
@@ -112,7 +115,7 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
 int mxq_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
                    void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
-    if (M > 64 || (layout != MXQ_LAYOUT_MIXED && layout != MXQ_LAYOUT_MIXEDC)) return MXQ_E_SHAPE;
+    if (M > 64 || !layout_ok(layout)) return MXQ_E_SHAPE;
     return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
 }
 
@@ -151,9 +154,6 @@ int mxq_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const vo
 }
 
 // ---- uniform layouts of the config-5 sweep ---------------------------------------------------
-static bool layout_ok(int l) {
-    return l == MXQ_LAYOUT_MIXED || l == MXQ_LAYOUT_W2G16 || l == MXQ_LAYOUT_W4ROW || l == MXQ_LAYOUT_MIXEDC;
-}
 
 size_t mxq_qweight_bytes_layout(int N, int K, int layout) {
     if (!shape_ok(N, K) || !layout_ok(layout)) return 0;
@@ -298,9 +298,10 @@ int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* row
     if (layout == MXQ_LAYOUT_MIXED)
         return mxq_linear_f16_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, stream);
     if (M <= 4) return mxq_launch_gemv_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
+    // every layout: the skinny MFMA kernel up to the token count where the split-K / prefill kernels overtake it
+    if (M <= (workspace && layout == MXQ_LAYOUT_MIXEDC ? skinny_max_tokens(N, K) : layout == MXQ_LAYOUT_MIXEDC ? 64 : 48))
+        return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
     if (layout == MXQ_LAYOUT_MIXEDC) {
-        if (M <= (workspace ? skinny_max_tokens(N, K) : 64))
-            return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
         if (M <= MIDM_MAX_TOKENS && (!workspace || midm_ws_ok(M, N, workspace_bytes))) {
             const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, 0, 0,
                                               (hipStream_t)stream);
@@ -338,9 +339,6 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (variant == 8 || variant == 9)
         return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 9,
                                     (hipStream_t)stream);
-    if (variant == 20 || variant == 21)   // the 8-wave kernel with the conversion inside the MFMA waves; 21: tail always split
-        return mxq_launch_gemm10_layout_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes,
-                                            variant == 21, (hipStream_t)stream);
     return MXQ_E_SHAPE;
 }
 

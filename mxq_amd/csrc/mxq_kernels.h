@@ -39,10 +39,6 @@ int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, i
 int mxq_launch_dense256_f16(const void* x, const void* w16, void* y, int M, int N, int K, int force, hipStream_t stream);
 int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
-// 256 x 128 tile, EIGHT waves: every wave converts its share of the weight tile between its own MFMAs (gemm10.hip);
-// gemm8's persistent loop, stream-K tail and workspace; force: split the tail even when it does not pay
-int mxq_launch_gemm10_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                                 int layout, void* workspace, size_t ws_bytes, int force, hipStream_t stream);
 int mxq_launch_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                         hipStream_t stream);
 // skinny MFMA kernel, 1 <= M <= 64 (skinny.hip; the dispatch uses it for 5..40 tokens with a workspace -- 20 for weights

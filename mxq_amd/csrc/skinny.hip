@@ -17,7 +17,9 @@
 //   * per chunk 2 x MT MFMAs (MT = 1..4 blocks of 16 tokens; beyond 48 tokens the prefill kernel's tile is the faster
 //     one on the MLP shapes: 54 vs 51 us at 64 tokens, but 42 vs 50 us at 48); the waves' partial tiles meet in LDS.
 // D^T = W . x^T as in the prefill kernel: a lane ends with 4 consecutive channels of one token.
-// Layouts: mixed with exact (v1) or compact metadata.
+// Layouts: mixed with exact (v1) or compact metadata, and the uniform layouts of BASELINE config 5: W2G16 (both K slices
+// of a chunk are 2-bit groups: slice 1 holds groups 2 + (kq >> 1)) and W4ROW (every lane converts one 4-bit code word per
+// slice with the row's scale / zero-point) -- the reference serves uniform W4 at any batch (gemv_cuda.cu:346-399).
 #include <hip/hip_runtime.h>
 
 #include "mxq_dequant.h"
@@ -53,12 +55,15 @@ struct Chunk {            // one lane's packed words of one chunk
     uint32_t qs0, qz0, qs2, qz2;
 };
 
-template <int MT, int THREADS, bool COMPACT>
+template <int MT, int THREADS, int LAYOUT>
 __global__ __launch_bounds__(THREADS) void mxq_skinny_f16_kernel(const uint16_t* __restrict__ x,
                                                                  const uint32_t* __restrict__ qweight,
                                                                  const float4* __restrict__ rowmeta,
                                                                  uint16_t* __restrict__ y, int M, int N, int K) {
     constexpr int WAVES = THREADS / 64;
+    constexpr bool COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
+    constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || COMPACT, W2 = LAYOUT == MXQ_LAYOUT_W2G16, W4 = LAYOUT == MXQ_LAYOUT_W4ROW;
+    constexpr int BLK_DW = W4 ? 128 : COMPACT ? MXQC_BLK_DW : MXQ_BLK_DW;
     typedef MxqMixed<COMPACT> F;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [WAVES][MT][16 rows][16 tokens] fp32
     const int tid = threadIdx.x, lane = tid & 63;
@@ -66,25 +71,39 @@ __global__ __launch_bounds__(THREADS) void mxq_skinny_f16_kernel(const uint16_t*
     const int r = lane & 15, kq = lane >> 4;
     const int rb = blockIdx.x;
     const int NC = K / 64;
-    const uint32_t* tiles = qweight + (int64_t)rb * NC * F::BLK_DW;
+    const uint32_t* tiles = qweight + (int64_t)rb * NC * BLK_DW;
     const int g0 = kq >> 1, h0 = kq & 1;
-    const bool four = kq >= 2;                                    // slice 1: the four-bit quarter (lane-dependent)
+    const int g1 = W2 ? 2 + (kq >> 1) : 2;                        // slice 1's 2-bit group
+    const bool four = MIXED && kq >= 2;                           // mixed: slice 1 of lanes kq >= 2 is the four-bit quarter
     // lane-dependent dword offsets of the slice-1 words (both arms load SOMETHING: no divergent loads)
-    const int off_c1 = four ? mxq_c4(kq - 2, r) : mxq_c2(2, r);
+    const int off_c1 = W4 ? mxq_w4_c4(2 + (kq >> 1), kq & 1, r) : W2 ? mxq_w2_c2(g1, r) : four ? mxq_c4(kq - 2, r) : mxq_c2(2, r);
 
     auto load_chunk = [&](int c) {
         Chunk k = {};
         if (c < NC) {
-            const uint32_t* t = tiles + (int64_t)c * F::BLK_DW;
-            k.c0 = t[mxq_c2(g0, r)];
-            k.z0 = __float_as_uint(F::z2(t, g0, r));
+            const uint32_t* t = tiles + (int64_t)c * BLK_DW;
             k.c1 = t[off_c1];
-            k.z1 = __float_as_uint(F::z2(t, 2, r));
-            k.scw = F::scw(t, r);
-            k.qs0 = t[F::qq(g0)];
-            k.qz0 = t[F::qq(g0) + 1];
-            k.qs2 = t[F::qq(2)];
-            k.qz2 = t[F::qq(2) + 1];
+            if constexpr (W4) {
+                k.c0 = t[mxq_w4_c4(kq >> 1, kq & 1, r)];
+            } else if constexpr (W2) {                            // SC / QQ sit where the mixed layout has them
+                k.c0 = t[mxq_w2_c2(g0, r)];
+                k.z0 = t[mxq_w2_z2(g0, r)];
+                k.z1 = t[mxq_w2_z2(g1, r)];
+                k.scw = ((const uint16_t*)t)[mxq_sc_u16(r)];
+                k.qs0 = t[mxq_qq(g0)];
+                k.qz0 = t[mxq_qq(g0) + 1];
+                k.qs2 = t[mxq_qq(g1)];
+                k.qz2 = t[mxq_qq(g1) + 1];
+            } else {
+                k.c0 = t[mxq_c2(g0, r)];
+                k.z0 = __float_as_uint(F::z2(t, g0, r));
+                k.z1 = __float_as_uint(F::z2(t, 2, r));
+                k.scw = F::scw(t, r);
+                k.qs0 = t[F::qq(g0)];
+                k.qz0 = t[F::qq(g0) + 1];
+                k.qs2 = t[F::qq(2)];
+                k.qz2 = t[F::qq(2) + 1];
+            }
         }
         return k;
     };
@@ -121,12 +140,13 @@ __global__ __launch_bounds__(THREADS) void mxq_skinny_f16_kernel(const uint16_t*
         load_x(c + WAVES, bn);
         uint32_t o[4];
         // slice 0: columns 0..31 of the chunk
-        deq2_half(cur.c0, h0, mxq_scale(__uint_as_float(cur.qs0), __uint_as_float(cur.qz0), (cur.scw >> (4 * g0)) & 15u),
-                  __uint_as_float(cur.z0), o);
+        if constexpr (W4) mxq_deq4x8(cur.c0, s4, z4, o);
+        else deq2_half(cur.c0, h0, mxq_scale(__uint_as_float(cur.qs0), __uint_as_float(cur.qz0), (cur.scw >> (4 * g0)) & 15u),
+                       __uint_as_float(cur.z0), o);
         half8 a0 = __builtin_bit_cast(half8, (u32x4){o[0], o[1], o[2], o[3]});
-        // slice 1: columns 32..63: group 2 (lanes kq < 2) or the four-bit quarter (kq >= 2)
-        if (four) mxq_deq4x8(cur.c1, s4, z4, o);
-        else deq2_half(cur.c1, kq, mxq_scale(__uint_as_float(cur.qs2), __uint_as_float(cur.qz2), (cur.scw >> 8) & 15u),
+        // slice 1: columns 32..63: mixed: group 2 (lanes kq < 2) or the four-bit quarter (kq >= 2); W2G16: group 2 + (kq >> 1)
+        if (W4 || four) mxq_deq4x8(cur.c1, s4, z4, o);
+        else deq2_half(cur.c1, MIXED ? kq : h0, mxq_scale(__uint_as_float(cur.qs2), __uint_as_float(cur.qz2), (cur.scw >> (4 * g1)) & 15u),
                        __uint_as_float(cur.z1), o);
         half8 a1 = __builtin_bit_cast(half8, (u32x4){o[0], o[1], o[2], o[3]});
 #pragma unroll
@@ -157,36 +177,40 @@ __global__ __launch_bounds__(THREADS) void mxq_skinny_f16_kernel(const uint16_t*
     }
 }
 
-template <int MT, int THREADS, bool COMPACT>
+template <int MT, int THREADS, int LAYOUT>
 int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream) {
     const size_t smem = (size_t)(THREADS / 64) * MT * 256 * 4;
-    mxq_skinny_f16_kernel<MT, THREADS, COMPACT><<<N / 16, THREADS, smem, stream>>>(
+    mxq_skinny_f16_kernel<MT, THREADS, LAYOUT><<<N / 16, THREADS, smem, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K);
     return (int)hipGetLastError();
 }
 
-template <bool COMPACT>
+template <int LAYOUT>
 int launch_c(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream) {
     const bool big = N / 16 > 384;     // many row blocks: 8 waves, so that several workgroups share a CU
     if (M <= 16)
-        return big ? launch_t<1, 512, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream)
-                   : launch_t<1, 1024, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream);
+        return big ? launch_t<1, 512, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream)
+                   : launch_t<1, 1024, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream);
     if (M <= 32)
-        return big ? launch_t<2, 512, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream)
-                   : launch_t<2, 1024, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream);
+        return big ? launch_t<2, 512, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream)
+                   : launch_t<2, 1024, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream);
     if (M <= 48)
-        return big ? launch_t<3, 512, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream)
-                   : launch_t<3, 1024, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream);
-    return launch_t<4, 512, COMPACT>(x, qweight, rowmeta, y, M, N, K, stream);   // (16 waves would spill at 128 VGPRs)
+        return big ? launch_t<3, 512, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream)
+                   : launch_t<3, 1024, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream);
+    return launch_t<4, 512, LAYOUT>(x, qweight, rowmeta, y, M, N, K, stream);   // (16 waves would spill at 128 VGPRs)
 }
 
 }   // namespace
 
-// 1 <= M <= 64; layout MXQ_LAYOUT_MIXED or MXQ_LAYOUT_MIXEDC
+// 1 <= M <= 64; any layout
 int mxq_launch_skinny_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                           int layout, hipStream_t stream) {
     if (M < 1 || M > 64) return -1;
-    if (layout == MXQ_LAYOUT_MIXED) return launch_c<false>(x, qweight, rowmeta, y, M, N, K, stream);
-    if (layout == MXQ_LAYOUT_MIXEDC) return launch_c<true>(x, qweight, rowmeta, y, M, N, K, stream);
+    switch (layout) {
+        case MXQ_LAYOUT_MIXED: return launch_c<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_MIXEDC: return launch_c<MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_W2G16: return launch_c<MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, stream);
+        case MXQ_LAYOUT_W4ROW: return launch_c<MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, stream);
+    }
     return -1;
 }

@@ -306,7 +306,7 @@ def linear_dense(x: torch.Tensor, w16: torch.Tensor, out: Optional[torch.Tensor]
     return out.reshape(*x.shape[:-1], N)
 
 
-GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10, "gemm10": 20, "gemm10sk": 21}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
+GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
 
 
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
@@ -370,7 +370,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         else:
             midm = path == "midm" or (path == "auto" and M <= MIDM_MAX_TOKENS)
             ws = (gemm_workspace(x2.device, counters=not midm)
-                  if path in ("auto", "gemm", "fused", "gemm8", "gemm9", "midm", "gemm10", "gemm10sk") else None)
+                  if path in ("auto", "gemm", "fused", "gemm8", "gemm9", "midm") else None)
             wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
             if path == "auto":
                 rc = lib.mxq_linear_f16_ws(*args, wsp, wsn, _stream(x2))
@@ -474,7 +474,9 @@ def expand_uniform(p: PackedUniform, codes: bool = True):
 
 def linear_layout(x: torch.Tensor, p, out: Optional[torch.Tensor] = None, path: str = "gemm") -> torch.Tensor:
     """Quantised Linear on a PackedMXQ (mixed) or PackedUniform weight: path "gemm" = MFMA dequant-GEMM at any
-    token count, "gemv" = the streaming GEMV (<= 4 tokens), "auto" = GEMV up to 4 tokens, GEMM beyond."""
+    token count, "gemv" = the streaming GEMV (<= 4 tokens), "skinny" = the skinny MFMA kernel (<= 64 tokens), "auto" = the
+    library's dispatch (mxq_linear_f16_auto: GEMV up to 4 tokens, skinny kernel up to 48, fused GEMM, hoisted mode from
+    HOIST_MIN_TOKENS)."""
     layout = LAYOUTS[getattr(p, "layout", "mixed")]
     if layout == 0:
         return linear(x, p, out=out, path=path)        # the mixed layout's default (fastest) kernels
@@ -485,16 +487,27 @@ def linear_layout(x: torch.Tensor, p, out: Optional[torch.Tensor] = None, path: 
     M = x2.shape[0]
     if out is None:
         out = torch.empty((M, p.N), dtype=torch.float16, device=x.device)
-    if path not in ("gemm", "gemv", "auto", "hoist", "fused"):
+    if path not in ("gemm", "gemv", "auto", "hoist", "fused", "skinny"):
         raise ValueError(f"unknown path {path!r}")
-    if path == "hoist" or (path in ("gemm", "auto") and M >= HOIST_MIN_TOKENS):
-        return linear_hoisted(x, p, out=out)
-    lib = _lib.load()
-    fn, what = ((lib.mxq_gemv_f16_layout, "mxq_gemv_f16_layout") if path == "gemv" or (path == "auto" and M <= 4)
-                else (lib.mxq_gemm_f16_layout, "mxq_gemm_f16_layout"))
     if M == 0:
         return out.reshape(*x.shape[:-1], p.N)
+    if path == "hoist" or (path == "gemm" and M >= HOIST_MIN_TOKENS):
+        return linear_hoisted(x, p, out=out)
+    lib = _lib.load()
+    args = (x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K, layout)
     with torch.cuda.device(x.device):
-        _lib.check(fn(x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K, layout,
-                      _stream(x2)), what)
+        if path == "auto" and M > 4:        # the library's own dispatch: skinny kernel / fused prefill GEMM / hoisted mode
+            hoists = M >= HOIST_MIN_TOKENS
+            ws = gemm_workspace(x2.device, counters=not hoists)
+            scratch = hoist_scratch(x2.device, lib.mxq_hoist_scratch_bytes(p.N, p.K)) if hoists else None
+            _lib.check(lib.mxq_linear_f16_auto(*args, ws.data_ptr(), ws.numel(),
+                                               scratch.data_ptr() if scratch is not None else None,
+                                               scratch.numel() if scratch is not None else 0, _stream(x2)),
+                       "mxq_linear_f16_auto")
+        elif path == "skinny":
+            _lib.check(lib.mxq_skinny_f16(*args, _stream(x2)), "mxq_skinny_f16")
+        else:
+            fn, what = ((lib.mxq_gemv_f16_layout, "mxq_gemv_f16_layout") if path in ("gemv", "auto")
+                        else (lib.mxq_gemm_f16_layout, "mxq_gemm_f16_layout"))
+            _lib.check(fn(*args, _stream(x2)), what)
     return out.reshape(*x.shape[:-1], p.N)

@@ -342,7 +342,7 @@ def test_quantizer_reproduces_fasterquant_loop_g1(dev, g1):
 # ----------------------------------------------------------------------------------------
 # dequant-GEMM / GEMV
 # ----------------------------------------------------------------------------------------
-GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm", "gemm10", "gemm10sk"]      # packing.GEMM_PATHS: every kernel the product library ships
+GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm"]      # packing.GEMM_PATHS: every kernel the product library ships
 
 
 def _packed_case(dev, N, K, seed):
@@ -414,7 +414,7 @@ def test_gemm_integer_exact_layout(dev):
                                    (1024, 4224, 2048),    # 132 tiles: XCDs 0-3 hold 17 tail tiles, 4-7 hold 16
                                    (100, 1152, 8192),     # 9 tiles: XCD 0 holds two, the others one; half-empty 256-row tile
                                    (2048, 5120, 1024)])   # 320 tiles = one full round + a 64-tile tail
-@pytest.mark.parametrize("sk", ["gemm9", "gemm10sk"])
+@pytest.mark.parametrize("sk", ["gemm9"])
 def test_gemm_stream_k_tail(dev, M, N, K, sk):
     """csrc/gemm8.hip: tiles beyond the last full round of CUs are split along K over all CUs and
     reduced through the workspace.  Checks (1) against the oracle matmul, (2) that the workspace
@@ -438,7 +438,7 @@ def test_gemm_stream_k_tail(dev, M, N, K, sk):
     assert torch.equal(packing.linear(xd, p, path="gemm8"), yd)
 
 
-@pytest.mark.parametrize("sk", ["gemm9", "gemm10sk"])
+@pytest.mark.parametrize("sk", ["gemm9"])
 def test_stream_k_partition_fuzz(dev, sk):
     """Random (tokens, out, in) shapes through the forced stream-K schedule against the single-tile kernel:
     exercises unit ranges that start / end anywhere inside tiles, XCDs with unequal tail lengths, units with
@@ -460,23 +460,6 @@ def test_stream_k_partition_fuzz(dev, sk):
         assert torch.equal(packing.linear(x, p, path=sk).float(), y), (M, N, K)
     ws = packing.gemm_workspace(torch.device(dev))
     assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
-
-
-@pytest.mark.parametrize("M,N,K", [(2048, 4096, 4096), (2048, 11008, 4096), (2048, 4096, 11008), (300, 144, 192),
-                                   (1000, 2064, 704), (256, 128, 64), (257, 4096, 128), (640, 11008, 4096)])
-def test_gemm10_equals_gemm8_bit_for_bit(dev, M, N, K):
-    """csrc/gemm10.hip (8 waves, conversion inside the MFMA waves) forms the same fp16 weights, the same products and the
-    same sums in the same order as csrc/gemm8.hip: identical output bits, with and without the stream-K split, at the
-    bench's three shapes and at ragged ones (one K-step, two, an odd count; N below a tile; a 2-tile tail)."""
-    from mxq_amd import packing
-    g = torch.Generator(device=dev).manual_seed(M + N + K)
-    p = packing.quantize_pack((torch.randn(N, K, generator=g, device=dev) * 0.02).half())
-    x = torch.randn(M, K, generator=g, device=dev).half()
-    y8 = packing.linear(x, p, path="gemm8")
-    assert torch.equal(packing.linear(x, p, path="gemm10"), y8)
-    assert torch.equal(packing.linear(x, p, path="gemm10sk"), packing.linear(x, p, path="gemm9"))
-    r = x.float() @ packing.dequant(p).float().t()
-    assert ((y8.float() - r).abs().max() / r.abs().max()).item() <= REL_TOL
 
 
 def test_linear_auto_c_entry_takes_the_fastest_path(dev):
@@ -1534,6 +1517,49 @@ def test_uniform_gemv_vs_oracle(dev, layout, M, N, K):
     assert np.array_equal(ya, y)
     with pytest.raises(ValueError):
         packing.linear_layout(torch.zeros(5, K, dtype=torch.float16, device=dev), p, path="gemv")
+
+
+@pytest.mark.parametrize("layout", ["w2g16", "w4row"])
+@pytest.mark.parametrize("M,N,K", [(5, 64, 128), (16, 256, 704), (17, 4096, 4096), (33, 16, 64), (48, 11008, 4096), (64, 144, 192)])
+def test_uniform_skinny_vs_oracle(dev, layout, M, N, K):
+    """csrc/skinny.hip on the uniform layouts (W2G16: both K slices of a chunk are 2-bit groups; W4ROW: one 4-bit code word
+    per lane and slice): against the oracle's dequantised weight, 1 .. 4 token blocks, ragged K; and the library's
+    dispatch takes it up to 48 tokens (the reference serves uniform W4 at any batch, gemv_cuda.cu:346-399)."""
+    from mxq_amd import packing
+    g = torch.Generator().manual_seed(N + K + M)
+    W16 = (torch.randn(N, K, generator=g) * 0.02).half()
+    ref = O.uniform_quantize(W16.numpy(), layout)
+    p = packing.quantize_pack_uniform(W16.to(dev), layout)
+    x = torch.randn(M, K, generator=g).half()
+    y = packing.linear_layout(x.to(dev), p, path="skinny")
+    _check_gemm(y.cpu().numpy(), O.linear_ref(x.numpy(), ref["w_deq32"].astype(np.float16)), f"skinny {layout} {M}x{N}x{K}")
+    if M <= 48:
+        assert torch.equal(packing.linear_layout(x.to(dev), p, path="auto"), y), "auto dispatch should be the skinny kernel here"
+    else:
+        _check_gemm(packing.linear_layout(x.to(dev), p, path="auto").cpu().numpy(),
+                    O.linear_ref(x.numpy(), ref["w_deq32"].astype(np.float16)), f"auto {layout} {M}x{N}x{K}")
+
+
+def test_uniform_skinny_integer_exact(dev):
+    """Small-integer weights and activations: every product and sum exact, so a wrong lane -> (group, half / code word)
+    mapping of the uniform layouts in the skinny kernel is an exact mismatch."""
+    from mxq_amd import packing
+    rng = np.random.default_rng(12)
+    N, K, M = 64, 256, 24
+    for layout in ("w2g16", "w4row"):
+        W = rng.integers(0, 4 if layout == "w2g16" else 16, (N, K)).astype(np.float16)
+        # every group / row spans the full code range, so the quantiser reproduces the integers exactly
+        if layout == "w2g16":
+            W.reshape(N, K // 16, 16)[:, :, 0] = 0; W.reshape(N, K // 16, 16)[:, :, 1] = 3
+        else:
+            W[:, 0] = 0; W[:, 1] = 15
+        p = packing.quantize_pack_uniform(torch.from_numpy(W).to(dev), layout)
+        w16, _ = packing.expand_uniform(p, codes=False)
+        assert np.array_equal(w16.cpu().numpy(), W), layout
+        x = rng.integers(-2, 3, (M, K)).astype(np.float16)
+        yref = x.astype(np.float32) @ W.astype(np.float32).T
+        y = packing.linear_layout(torch.from_numpy(x).to(dev), p, path="skinny").cpu().numpy().astype(np.float32)
+        assert np.array_equal(y, yref), layout
 
 
 @pytest.mark.parametrize("layout", ["w2g16", "w4row"])
