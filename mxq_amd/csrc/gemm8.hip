@@ -25,16 +25,22 @@
 //   * the output leaves without an LDS round trip (store_tile_xpose), so a workgroup that runs several tiles issues
 //     the next tile's first DMAs behind the last barrier of this one and they fly under its epilogue.
 //
-// Grid = min(tiles, CUs) persistent workgroups dealing whole tiles round-robin + (with a workspace) one stream-K
-// workgroup per CU for the tiles beyond the last full round ("tail"): their K-steps are dealt evenly, XCD by XCD
-// (tail tile t belongs to XCD t & 7; an XCD's 32 units share its tail tiles so the operands stay in that L2).  A
-// unit's K range covers the end of one tile and the start of the next; each piece ("segment") runs the same pipeline
-// on a shifted K window.  A segment that does not cover its tile's whole K leaves its fp32 accumulators in a
-// workspace slot and, after the unit's last segment, bumps a per-(tile, wave) K-step counter; the wave whose bump
-// completes the count sums the slots in unit order (its own re-read from the slot) -- a fixed order, so the
-// result does not depend on which wave finishes -- writes fp16 y and re-zeroes the counter.  Nobody ever waits on
-// another workgroup.  Slots and counters cross XCDs (one L2 each): slot traffic is agent-scope relaxed atomics
-// (global_store / load ... sc1), ordered against the counter bump by s_waitcnt vmcnt(0).
+// Grid = min(tiles, CUs) persistent workgroups dealing whole tiles round-robin; with a workspace, the tiles beyond the
+// last full round ("tail") are split along K over the SAME workgroups (hybrid stream-K; the reference launcher's
+// split_k_iters, gemm_cuda_gen.cu:429-478): workgroup 8u + e is also unit u of XCD e (tail tile t belongs to XCD t & 7; an
+// XCD's units share its tail tiles so the operands stay in that L2) and runs K-steps [bound(u), bound(u+1)) of that XCD's
+// tail tiles laid end to end -- up to one piece that ENDS a tile, whole tiles, and one piece that STARTS a tile.  Each
+// piece ("segment") runs the same pipeline on a shifted K window.  The unit that holds a tile's LAST K-step is the
+// tile's OWNER.  A unit runs its pieces in DESCENDING K order: first the piece that starts a tile (it cannot be the
+// owner's): its fp32 accumulators go to a workspace slot and -- once those stores have retired, which the next
+// segment's first DMA wait covers for free -- a per-(tile, wave) K-step counter is bumped; last the piece that ends a
+// tile: the owner keeps ITS accumulators in registers, waits until the counter shows every other contributor's steps,
+// adds their slots in unit order (a fixed order: results do not depend on timing), writes fp16 y and re-zeroes the
+// counter.  (Round 2-3: every contributor parked, the last arriver read them all back -- 2-3 slots of 128 KB per
+// workgroup, all at the end of the launch: ~20 us; now the parks happen mid-launch and an owner reads 1-2 slots.)
+// An owner waits only for units with a LOWER index, which never wait before their parked piece: no cycle; every
+// workgroup of the grid (<= one per CU, 144 KB of LDS each) is resident, and the spin is bounded.  Slots and counters
+// cross XCDs (one L2 each): slot traffic is agent-scope sc1 accesses, ordered against the counter by vmcnt.
 #include <hip/hip_runtime.h>
 
 #include "mxq_dequant.h"
@@ -60,6 +66,7 @@ constexpr int OFF_W = OFF_A + A_SLOTS * A_STAGE;
 constexpr int OFF_WD = OFF_W, WD_SLOTS = 3;
 constexpr int SMEM_BYTES = OFF_WD + WD_SLOTS * W_STAGE;
 static_assert(OFF_W + 2 * W_STAGE <= SMEM_BYTES && SMEM_BYTES <= 160 * 1024, "LDS budget");
+static_assert(N_MMA * 16384 <= SMEM_BYTES, "the stream-K owner stages a 16-KB slot per MFMA wave in the idle rings");
 constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K] matrix (never part of the C ABI)
 
 // profiling-only switches (template parameter ABL; the product library instantiates ABL = 0 only, and the stamp / ballast
@@ -114,6 +121,8 @@ struct SkSeg {
     int S;            // K-steps in one XCD's tail = tail tiles per XCD * NT
     int j;            // tile index inside the XCD's tail
     int first;        // 1: the segment starts at the unit's range start (slot 0), else slot 1
+    int owner;        // 1: a partial segment that ENDS its tile: finish the tile here (sk_finish_owner)
+    int pend_j, pend_n;   // a parked piece whose counter bump is due as soon as its stores have retired (-1: none)
 };
 // A wave's 16 KB slot, 16 bytes per lane and fragment: ONE sc1 (write-through / L1-bypassing) 16-byte access per fragment,
 // 1 KB contiguous per instruction.  (Round 2 began with two 8-byte agent-scope atomics per fragment: 8-byte accesses run at
@@ -360,6 +369,59 @@ __device__ __forceinline__ void mma_prologue_issue(const XDma& xd, char* smem, i
     }
 }
 
+// a parked piece's K-steps enter its tile's count (pre: the slot stores have retired -- the caller's vmcnt wait)
+__device__ __forceinline__ void sk_bump_pending(SkSeg& sk, int wave, int lane) {
+    if (sk.pend_j >= 0) {
+        if (lane == 0)
+            __hip_atomic_fetch_add(sk.cnt + (sk.pend_j * 8 + sk.e) * N_MMA + wave, sk.pend_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sk.pend_j = -1;
+    }
+}
+
+// The owner of tile sk.j (the unit whose piece holds the tile's last K-step; `own` steps, accumulators in registers): wait
+// until the wave's counter shows the other NT_tile - own steps, add the contributors' slots in unit order, write y and
+// re-zero the counter.  Contributors are units with a lower index; their piece of this tile is the FIRST thing they run.
+constexpr int SK_SPIN_BOUND = 1 << 22;
+__device__ __forceinline__ void sk_finish_owner(const SkSeg& sk, int own, int NT_tile, int wave, int lane, char* smem,
+                                                f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
+    const int j = sk.j, lo = j * NT_tile;
+    int* c = sk.cnt + (j * 8 + sk.e) * N_MMA + wave;
+    const int need = NT_tile - own;
+    for (int spin = 0; spin < SK_SPIN_BOUND; ++spin) {
+        int v = 0;
+        if (lane == 0) v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane(v) >= need) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler ordering only: the slot loads are agent-scope themselves
+    int uf = 0;
+    while (uf + 1 < sk.units && sk_bound(uf + 1, sk.S, sk.units) <= lo) ++uf;
+    // A contributor's slot comes through LDS, not through registers: 16 LDS-DMA pieces (sc1: the bytes were written by
+    // another XCD) into this wave's 16 KB of the idle rings, all in flight together = ONE loaded-memory round trip per
+    // slot and no second accumulator set (64 more VGPRs spilled at the 168-register cap).  The rings are idle: this is the
+    // unit's last segment, every LDS read of it lies before its last barrier, and the dequant waves have passed theirs.
+    char* stage = smem + wave * 16384;
+    for (int v = uf; v < sk.u; ++v) {
+        const int vb = sk_bound(v, sk.S, sk.units);
+        if (sk_bound(v + 1, sk.S, sk.units) <= (vb > lo ? vb : lo)) continue;   // empty range: no slot was written
+        const float* src = sk.ws + ((int64_t)((v * 8 + sk.e) * 2 + (vb >= lo ? 0 : 1)) * (BM * BN)) + wave * 4096;
+        const rsrc_t r = make_rsrc(src, 16384u);
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(stage + f * 1024), 16,
+                                                     (uint32_t)lane * 16u, (uint32_t)f * 1024u, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = acc[i][jj] + *(const f32x4*)(stage + (i * 4 + jj) * 1024 + lane * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next slot's DMA overwrites the stage
+    }
+    if (lane == 0)   // ready for the next launch
+        __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    store_tile_xpose(acc, y, M, N, m0, n0, wave >> 1, wave & 1, lane & 15, lane >> 4);
+}
+
 // One segment = NT K-steps of one tile.  pre: its prologue DMAs are already in flight (issued by the caller behind
 // the previous segment's last barrier; other VMEM traffic of this wave -- the previous tile's output stores -- may
 // sit in between, so the first wait is a full one).  After the last barrier, BEFORE the final 16 MFMAs and the
@@ -368,7 +430,7 @@ __device__ __forceinline__ void mma_prologue_issue(const XDma& xd, char* smem, i
 template <int ABL, bool DENSE, class Next>
 __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int NT, const XDma& xd, bool pre,
                                             uint16_t* __restrict__ y, int M, int N, int m0, int n0, int NT_tile,
-                                            const SkSeg& sk, Next&& next) {
+                                            SkSeg& sk, Next&& next) {
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
     f32x4 acc[4][4];
 #pragma unroll
@@ -380,6 +442,9 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
     if (!pre) mma_prologue_issue<ABL>(xd, smem, wave, NT);
     if (NT > 1 && !pre) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // vmcnt retires in order: the wait for this segment's first x tile has also retired every older operation of the
+    // wave -- the slot stores of the piece it parked before.  Its K-step count moves now, for free.
+    sk_bump_pending(sk, wave, lane);
     __builtin_amdgcn_s_barrier();   // prologue barrier 1: x tile 0 and packed blocks 0..3 landed
     __builtin_amdgcn_s_barrier();   // prologue barrier 2: W16(0) written by the dequant waves
 
@@ -412,14 +477,26 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
     for (; t < NT; ++t) mma_step<ABL, false, DENSE>(smem, t, wave, wm, wn, fr, fq, xd, acc, wf0, xf0, wf1, xf1, st);
     next();                                  // the ring is idle from here on
     mfma_rows<0, 4, ABL & ~192>(acc, wf1, xf1);     // (NT-1, kk=1)
+    // (three ways out from here -- store, park, owner's reduction: without this pin the register allocator renames the
+    //  accumulators across the last 16 MFMAs to suit one of them and spills 28 registers)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
 
     if (NT != NT_tile) {
-        // partial segment: park the accumulators in this unit's slot; counted in after the unit's last segment
+        if (sk.owner) {   // the piece that ends its tile: the others' pieces were parked long ago (they run first)
+            sk_finish_owner(sk, NT, NT_tile, wave, lane, smem, acc, y, M, N, m0, n0);
+            return;
+        }
+        // a piece that starts its tile: park the accumulators in this unit's slot; the count moves once the stores retired
         float* mine = sk.ws + ((int64_t)((sk.u * 8 + sk.e) * 2 + (sk.first ? 0 : 1)) * (BM * BN)) + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) st_agent(mine, i * 4 + j, lane, acc[i][j]);
+        sk.pend_j = sk.j;
+        sk.pend_n = NT;
         return;
     }
     if constexpr (!(ABL & ABL_NO_STORE)) {
@@ -432,38 +509,6 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
             for (int j = 0; j < 4; ++j) s_ += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (s_ == 123.456f) y[0] = 1;
     }
-}
-
-// The wave that completed a tile's K-step count: sum every contributor's slot in unit order and write y.
-__device__ __forceinline__ void sk_finish(const SkSeg& sk, int j, int NT_tile, int wave, int lane, char* smem,
-                                          uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
-    const int lo = j * NT_tile, hi = lo + NT_tile;
-    int uf = 0;
-    while (uf + 1 < sk.units && sk_bound(uf + 1, sk.S, sk.units) <= lo) ++uf;
-    f32x4 acc[4][4];
-    bool any = false;
-    for (int v = uf; v < sk.units && sk_bound(v, sk.S, sk.units) < hi; ++v) {
-        const int vb = sk_bound(v, sk.S, sk.units);
-        if (sk_bound(v + 1, sk.S, sk.units) <= (vb > lo ? vb : lo)) continue;   // empty range: no slot was written
-        const float* src = sk.ws + ((int64_t)((v * 8 + sk.e) * 2 + (vb >= lo ? 0 : 1)) * (BM * BN)) + wave * 4096;
-        // all 16 fragments of the slot in flight together: a slot costs the finisher ONE loaded-memory round trip (two
-        // batches of 8 were two; the same change on the mid-M combine kernel was worth 1.2 us)
-        f32x4 p[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) p[i][jj] = ld_agent(src, i * 4 + jj, lane);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = any ? acc[i][jj] + p[i][jj] : p[i][jj];
-        __builtin_amdgcn_sched_barrier(0);
-        any = true;
-    }
-    if (lane == 0)   // ready for the next launch
-        __hip_atomic_store(sk.cnt + (j * 8 + sk.e) * N_MMA + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    store_tile_xpose(acc, y, M, N, m0, n0, wave >> 1, wave & 1, lane & 15, lane >> 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -741,10 +786,10 @@ __device__ __forceinline__ void wdma_segment(const WDma& w, char* smem, bool pre
 
 #define MXQ_LANE_ID(ln) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln))
 
-// grid = dp_grid persistent workgroups, which deal the first dp_tiles tiles round-robin (tile = block + k * dp_grid:
-// blocks b and b + 8 share an XCD and dp_grid is a multiple of 8 or the tile count itself, so a workgroup's tiles
-// keep its XCD's label) and overlap one tile's output with the next one's first DMAs, + 8 * units stream-K
-// workgroups for the `tail` tiles beyond them.
+// grid = max(dp_grid, 8 * units) persistent workgroups: the first dp_grid deal the first dp_tiles tiles round-robin
+// (tile = block + k * dp_grid: blocks b and b + 8 share an XCD and dp_grid is a multiple of 8 or the tile count itself, so a
+// workgroup's tiles keep its XCD's label) and overlap one tile's output with the next one's first DMAs; the first
+// 8 * units then run, as stream-K units, their shares of the `tail` tiles beyond them.
 template <int ABL, int LAYOUT>
 __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* __restrict__ x,
                                                                const uint32_t* __restrict__ qweight,
@@ -772,14 +817,48 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
         if constexpr (!(ABL & (EXP_NO_PRIO | EXP_MMA_PRIO))) __builtin_amdgcn_s_setprio(3);
     }
 
-    if (bid < dp_grid) {
-        // ---- persistent data-parallel workgroup: whole tiles bid, bid + dp_grid, ...
-        int tm, tn;
-        tile_of_block(bid, tiles_m, tiles_n, tm, tn);
-        if (wave < N_MMA) {
-            int ln;
-            MXQ_LANE_ID(ln);
-            XDma cur, nxt;
+    sk.owner = 0;
+    sk.pend_j = -1;
+    sk.pend_n = 0;
+    const bool has_dp = bid < dp_grid;
+    const bool has_sk = tail > 0 && bid < 8 * units;
+    // ---- stream-K unit u of XCD e (= this workgroup): K-steps [b0, b1) of that XCD's tail tiles laid end to end
+    int b0 = 0, b1 = 0, base = 0;
+    if (has_sk) {
+        sk.e = bid & 7;
+        sk.u = bid >> 3;
+        base = dp_tiles + sk.e;
+        sk.S = ((tail + 7 - sk.e) >> 3) * NT;   // tail tile t belongs to XCD t & 7: the first tail % 8 XCDs hold one more
+        b0 = sk_bound(sk.u, sk.S, units);
+        b1 = sk_bound(sk.u + 1, sk.S, units);
+    }
+    // a unit's pieces in DESCENDING K order: the piece that starts a tile first (parked early), whole tiles, the piece that
+    // ends a tile last (its owner finishes it).  Every wave walks the same list, so the barrier counts of the roles match.
+    const int j_hi = b1 > b0 ? (b1 - 1) / NT : -1, j_lo = b1 > b0 ? b0 / NT : 0;
+
+    // piece j of this unit (descending order): K-steps [pos, end) of tail tile base + 8 j
+    auto piece = [&](int j, int& pos, int& end) {
+        pos = b0 > j * NT ? b0 : j * NT;
+        end = b1 < (j + 1) * NT ? b1 : (j + 1) * NT;
+    };
+
+    if (wave < N_MMA) {
+        int ln;
+        MXQ_LANE_ID(ln);
+        XDma cur, nxt;
+        bool pre = false;
+        // the prologue DMAs of piece j, issued behind the previous segment's last barrier (they fly under its epilogue)
+        auto issue_piece = [&](int j) {
+            int pos, end, tm, tn;
+            piece(j, pos, end);
+            tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
+            xdma_setup(nxt, x, M, K, tm * BM, pos - j * NT, wave, ln);
+            mma_prologue_issue<ABL>(nxt, smem, wave, end - pos);
+        };
+        if (has_dp) {
+            // ---- persistent data-parallel part: whole tiles bid, bid + dp_grid, ...
+            int tm, tn;
+            tile_of_block(bid, tiles_m, tiles_n, tm, tn);
             xdma_setup(cur, x, M, K, tm * BM, 0, wave, ln);
             mma_prologue_issue<ABL>(cur, smem, wave, NT);
             for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
@@ -791,11 +870,38 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
                     if (more) {
                         xdma_setup(nxt, x, M, K, tm * BM, 0, wave, ln);
                         mma_prologue_issue<ABL>(nxt, smem, wave, NT);
+                    } else if (j_hi >= j_lo) {
+                        issue_piece(j_hi);         // the unit's first piece follows the last whole tile
                     }
                 });
                 cur = nxt;
             }
-        } else if constexpr (LAYOUT == LAYOUT_DENSE16) {
+            pre = j_hi >= j_lo;
+        }
+        for (int j = j_hi; j >= j_lo; --j) {
+            int pos, end, tm, tn;
+            piece(j, pos, end);
+            sk.j = j;
+            sk.first = pos == b0;
+            sk.owner = end - pos != NT && end == (j + 1) * NT;
+            tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
+            MXQ_LANE_ID(ln);
+            if (!pre) xdma_setup(cur, x, M, K, tm * BM, pos - j * NT, wave, ln);
+            mma_segment<ABL, LAYOUT == LAYOUT_DENSE16>(smem, wave, ln, end - pos, cur, pre, y, M, N, tm * BM, tn * BN, NT, sk, [&] {
+                if (j > j_lo) issue_piece(j - 1);
+            });
+            cur = nxt;
+            pre = true;
+        }
+        if (sk.pend_j >= 0) {   // the unit ended on a parked piece: its stores must have retired before the count moves
+            MXQ_LANE_ID(ln);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sk_bump_pending(sk, wave, ln);
+        }
+    } else if constexpr (LAYOUT == LAYOUT_DENSE16) {
+        if (has_dp) {
+            int tm, tn;
+            tile_of_block(bid, tiles_m, tiles_n, tm, tn);
             int ln;
             MXQ_LANE_ID(ln);
             WDma cur, nxt;
@@ -813,13 +919,35 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
                 });
                 cur = nxt;
             }
-        } else {
+        }
+        for (int j = j_hi; j >= j_lo; --j) {
+            const int pos = b0 > j * NT ? b0 : j * NT, end = b1 < (j + 1) * NT ? b1 : (j + 1) * NT;
+            int tm, tn;
+            tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
             int ln;
             MXQ_LANE_ID(ln);
-            Deq cur, nxt;
-            typename PkOf<LAYOUT>::type S[DEQ_R] = {};
+            WDma w;
+            wdma_setup(w, (const uint16_t*)qweight, N, K, tn * BN, pos - j * NT, end - pos, wave, ln);
+            wdma_segment(w, smem, false, nothing);
+        }
+    } else {
+        typename PkOf<LAYOUT>::type S[DEQ_R] = {};
+        int ln;
+        MXQ_LANE_ID(ln);
+        Deq cur, nxt;
+        bool pre = false;                  // a segment's last burst loads the next segment's first group
+        auto piece_deq = [&](int j, Deq& d, int& n0) {
+            int pos, end, tm, tn;
+            piece(j, pos, end);
+            tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
+            n0 = tn * BN;
+            deq_setup<LAYOUT>(d, smem, wave, ln, qweight, N, K, n0, pos - j * NT, end - pos);
+        };
+        int n0_sk = 0;
+        if (has_dp) {
+            int tm, tn;
+            tile_of_block(bid, tiles_m, tiles_n, tm, tn);
             deq_setup<LAYOUT>(cur, smem, wave, ln, qweight, N, K, tn * BN, 0, NT);
-            bool pre = false;                  // a tile's last burst loads the next tile's first group
             for (int tile = bid; tile < dp_tiles; tile += dp_grid) {
                 MXQ_LANE_ID(ln);
                 const int n0 = tn * BN;
@@ -827,6 +955,8 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
                 if (more) {
                     tile_of_block(tile + dp_grid, tiles_m, tiles_n, tm, tn);
                     deq_setup<LAYOUT>(nxt, smem, wave, ln, qweight, N, K, tn * BN, 0, NT);
+                } else if (j_hi >= j_lo) {
+                    piece_deq(j_hi, nxt, n0_sk);   // the unit's first piece follows the last whole tile
                 } else {
                     deq_none(nxt, cur);
                 }
@@ -835,81 +965,15 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
                 cur = nxt;
             }
         }
-        return;
-    }
-
-    // ---- stream-K unit u of XCD e: K-steps [b0, b1) of that XCD's tail tiles laid end to end
-    const int su = bid - dp_grid;
-    sk.e = su & 7;
-    sk.u = su >> 3;
-    const int base = dp_tiles + sk.e;
-    sk.S = ((tail + 7 - sk.e) >> 3) * NT;   // tail tile t belongs to XCD t & 7: the first tail % 8 XCDs hold one more
-    const int b0 = sk_bound(sk.u, sk.S, units), b1 = sk_bound(sk.u + 1, sk.S, units);
-    // every wave walks the same segment list, so the barrier counts of the two roles stay matched
-    if (wave < N_MMA) {
-        int pj0 = -1, pn0 = 0, pj1 = -1, pn1 = 0;
-        for (int pos = b0; pos < b1;) {
-            sk.j = pos / NT;
-            const int end = b1 < (sk.j + 1) * NT ? b1 : (sk.j + 1) * NT;
-            sk.first = pos == b0;
-            int tm, tn;
-            tile_of_block(base + sk.j * 8, tiles_m, tiles_n, tm, tn);
-            int ln;
+        for (int j = j_hi; j >= j_lo; --j) {
             MXQ_LANE_ID(ln);
-            XDma xd;
-            xdma_setup(xd, x, M, K, tm * BM, pos - sk.j * NT, wave, ln);
-            mma_segment<ABL, LAYOUT == LAYOUT_DENSE16>(smem, wave, ln, end - pos, xd, false, y, M, N, tm * BM, tn * BN, NT, sk, nothing);
-            if (end - pos != NT) {
-                if (sk.first) { pj0 = sk.j; pn0 = end - pos; }
-                else { pj1 = sk.j; pn1 = end - pos; }
-            }
-            pos = end;
-        }
-        if (pj0 >= 0 || pj1 >= 0) {
-            int ln;
-            MXQ_LANE_ID(ln);
-            // every slot store of this wave has reached the coherence point before any count moves
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int old0 = 0, old1 = 0;
-            if (ln == 0) {   // both bumps in flight together
-                if (pj0 >= 0) old0 = __hip_atomic_fetch_add(cnt + (pj0 * 8 + sk.e) * N_MMA + wave, pn0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (pj1 >= 0) old1 = __hip_atomic_fetch_add(cnt + (pj1 * 8 + sk.e) * N_MMA + wave, pn1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            old0 = __builtin_amdgcn_readfirstlane(old0);
-            old1 = __builtin_amdgcn_readfirstlane(old1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler ordering only: the slot loads are agent-scope themselves
-            if (pj0 >= 0 && old0 + pn0 == NT) {
-                int tm, tn;
-                tile_of_block(base + pj0 * 8, tiles_m, tiles_n, tm, tn);
-                sk_finish(sk, pj0, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
-            }
-            if (pj1 >= 0 && old1 + pn1 == NT) {
-                int tm, tn;
-                tile_of_block(base + pj1 * 8, tiles_m, tiles_n, tm, tn);
-                sk_finish(sk, pj1, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
-            }
-        }
-    } else {
-        for (int pos = b0; pos < b1;) {
-            const int j = pos / NT;
-            const int end = b1 < (j + 1) * NT ? b1 : (j + 1) * NT;
-            int tm, tn;
-            tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
-            int ln;
-            MXQ_LANE_ID(ln);
-            if constexpr (LAYOUT == LAYOUT_DENSE16) {
-                WDma w;
-                wdma_setup(w, (const uint16_t*)qweight, N, K, tn * BN, pos - j * NT, end - pos, wave, ln);
-                wdma_segment(w, smem, false, nothing);
-            } else {
-                Deq c, none;
-                typename PkOf<LAYOUT>::type S[DEQ_R] = {};
-                deq_setup<LAYOUT>(c, smem, wave, ln, qweight, N, K, tn * BN, pos - j * NT, end - pos);
-                deq_none(none, c);
-                deq_segment<ABL, LAYOUT>(c, none, wave, ln, rowmeta, N, tn * BN, false, S);
-            }
-            pos = end;
+            if (!pre) piece_deq(j, cur, n0_sk);
+            const int n0 = n0_sk;
+            if (j > j_lo) piece_deq(j - 1, nxt, n0_sk);
+            else deq_none(nxt, cur);
+            deq_segment<ABL, LAYOUT>(cur, nxt, wave, ln, rowmeta, N, n0, pre, S);
+            pre = true;
+            cur = nxt;
         }
     }
 }
@@ -947,10 +1011,13 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     if (workspace && tiles % cus != 0 && units * 8 * N_MMA * sizeof(int) <= CNT_BYTES &&
         ws_bytes >= CNT_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
         const int t8 = (tiles % cus) / 8;   // tail tiles per XCD (the first tail % 8 XCDs hold one more)
-        // Splitting the tail costs ~20 us (every unit parks 128 KB of fp32 partials, the finishers read them back)
-        // and saves the idle share of one tile time, (1 - tail/CUs) * NT K-steps of ~1 us: worth it from ~24 idle
-        // K-steps per CU (M = 512: 60 -> 37 us at 4096^2; NOT Llama's gate/up at M = 2048, tail 176 / 256, NT = 64)
-        const bool pays = (int64_t)(cus - tiles % cus) * NT >= (int64_t)24 * cus;
+        // Splitting the tail saves the idle share of one tile time, (1 - tail/CUs) * NT K-steps of ~1 us, and costs the
+        // pieces' extra prologues, the parked partials and -- most of it -- K-steps that run ~1.3 x slower than whole
+        // tiles' (units of one tile walk different K ranges: nothing they read is shared through L2).  Round 4's
+        // protocol (pieces in descending K order, the owner reduces in registers: header): worth it from ~20 idle K-steps
+        // per CU -- Llama's gate/up at 2048 tokens (tail 176 / 256, NT = 64): 183.6 -> 180.5 us; at 1024 tokens 109 -> 101
+        // (profiles/r04_streamk.txt).  Round 2-3's (every piece parked, last arriver reduces) needed 24.
+        const bool pays = (int64_t)(cus - tiles % cus) * NT >= (int64_t)20 * cus;
         if ((force || pays) && (int64_t)t8 * NT >= (int64_t)units * 4) {
             tail = tiles % cus;
             dp_tiles = tiles - tail;
@@ -969,7 +1036,9 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
         }
     }
     const int dp_grid = dp_tiles < cus ? dp_tiles : cus;   // persistent: at most one data-parallel workgroup per CU
-    const int grid = dp_grid + (tail ? 8 * units : 0);
+    // workgroup 8u + e runs its whole tiles and then, as unit u of XCD e, its share of the tail: never more than one
+    // workgroup per CU, all of them resident (an owner may wait for lower-numbered units: header)
+    const int grid = tail && 8 * units > dp_grid ? 8 * units : dp_grid;
     mxq_gemm8_f16_kernel<ABL, LAYOUT><<<grid, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
         dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace);
