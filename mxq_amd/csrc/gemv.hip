@@ -29,8 +29,15 @@
 //     4 v_perm per 4 weights).  The result is the fp32 sum over the UNROUNDED weights s (q - z): it differs from
 //     the sum over the reference's fp16-rounded weights by the fp16 rounding of each weight (2^-11 relative,
 //     independent per weight), ~1e-5 of the output scale at K = 4096 -- far inside the path's 1e-3 tolerance.
-// One workgroup per 16-row block; lane -> (row r = lane & 15, chunk slot cs = lane >> 4); a wave consumes 4
-// consecutive 16x64 blocks (2304 contiguous bytes) per tile, straight to VGPRs; waves split K by tiles.
+//   * Round 4: a workgroup takes RB CONSECUTIVE row blocks (1 / 2 / 4 by row-block count) and stages the activations ONCE
+//     for all of them: the widest launches (q|k|v: 768 row blocks, gate|up: 1376) were 768 / 1376 small workgroups, each
+//     waiting 2-4 us for its own copy of x, and the launch ended with the workgroups the dispatcher started last
+//     (profiles/r03_gemv_dma_experiment.txt: median finish 12.2 us, max 16.1).  The RB row blocks' packed blocks are
+//     contiguous, so the waves walk ONE flattened tile list (same wave count on the chip, same tiles per wave, two tiles
+//     in flight + one computing across row-block boundaries); a wave whose next tile belongs to the next row block
+//     leaves its partial sums in LDS, and one reduction at the end writes all RB x 16 outputs.
+// lane -> (row r = lane & 15, chunk slot cs = lane >> 4); a wave consumes 4 consecutive 16x64 blocks (2304 contiguous
+// bytes) per tile, straight to VGPRs; waves split the tile list.
 #include <hip/hip_runtime.h>
 
 #include "mxq_dequant.h"
@@ -65,7 +72,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // residual (nullable): y <- residual + W.x (the decoder layer's skip connection).
 // LAYOUT: MXQ_LAYOUT_MIXED / MIXEDC (3 two-bit groups + the 4-bit quarter per chunk; exact / compact metadata),
 // MXQ_LAYOUT_W2G16 (4 two-bit groups) or MXQ_LAYOUT_W4ROW (4 four-bit quarters, scale / zero per row from rowmeta).
-template <int MB, int GEMV_THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED>
+template <int MB, int GEMV_THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED, int RB = 1>
 __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16_t* __restrict__ x,
                                                                      const uint32_t* __restrict__ qweight,
                                                                      const float4* __restrict__ rowmeta,
@@ -78,18 +85,20 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     constexpr int NG2 = MIXED ? 3 : LAYOUT == MXQ_LAYOUT_W2G16 ? 4 : 0;   // two-bit groups per chunk
     constexpr int NW4 = MIXED ? 2 : LAYOUT == MXQ_LAYOUT_W4ROW ? 8 : 0;   // four-bit code words per chunk
     constexpr int BLK_DW = LAYOUT == MXQ_LAYOUT_W4ROW ? 128 : COMPACT ? MXQC_BLK_DW : MXQ_BLK_DW;
-    // LDS: x [MB][K] fp16 (code-dot order) | xsum [MB][K/16] f32 | red [W][MB][16] f32 | wsum [W] f32 | dummy slots
+    // LDS: x [MB][K] fp16 (code-dot order) | xsum [MB][K/16] f32 | red [RB][W][MB][16][3] f32 | wsum [W] f32 | dummy slots
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, cs = lane >> 4;
-    const int rb = blockIdx.x;
+    const int rb0 = blockIdx.x * RB;                    // this workgroup's first row block
     const int NC = K / 64, NC4 = (NC + 3) / 4, NG = K / 16;
+    const int nrb = min(RB, N / 16 - rb0);              // ... and how many it has (the last workgroup may have fewer)
+    const int NT = nrb * NC4;                           // its tile list (RB > 1 only when K % 256 == 0: tiles never straddle)
     GEMV_STAMP(0)
 
     float* xsum = (float*)(smem + (size_t)MB * K * 2);
     float* red = xsum + MB * NG;
-    float* wsum = red + W * MB * 16;
+    float* wsum = red + RB * W * MB * 16 * 3;
     char* dummy = (char*)(wsum + W);                    // [64 lanes][32 B] + [64] f32: where idle threads "stage"
 
     // ---- activation loads first (L2-resident, small), 2 staging steps hoisted; branch-free (clamped addresses)
@@ -122,9 +131,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
         uint2 qq[NG2 ? NG2 : 1];
     };
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(qweight + (int64_t)rb * NC * BLK_DW), 0, NC * BLK_DW * 4, 0x00020000);
+        (void*)(qweight + (int64_t)rb0 * NC * BLK_DW), 0, nrb * NC * BLK_DW * 4, 0x00020000);
     const int lane_off = (cs * BLK_DW) * 4;             // byte offset of the lane's block inside a tile
-    auto load_tile = [&](int c4) {                      // c4 >= NC4 or a chunk >= NC: out of range = zeros, no traffic
+    auto load_tile = [&](int c4) {                      // tile index in the list; beyond its end (or a chunk >= NC): zeros, no traffic
         Tile t = {};
         const int so = c4 * (4 * BLK_DW * 4);           // wave-uniform
         auto dw = [&](int idx) { return __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off + idx * 4, so, MXQ_GEMV_WAUX); };
@@ -153,7 +162,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     // (the sched_barriers pin the issue order the wait counts are computed from: activations, row metadata, all of
     // tile 0, all of tile 1, and only then the staging arithmetic -- left alone, the scheduler sinks a tile-0 load
     // behind tile 1, and the loop's first wait then covers most of tile 1 in EVERY iteration)
-    const float4 rm = rowmeta[rb * 16 + r];
+    // the 4-bit arm's per-row parameters are applied in the final reduction: thread (row block, token, row) loads its own
+    const int f_rbl = tid / (MB * 16), f_m = (tid >> 4) % MB, f_r = tid & 15;
+    const float4 rm = rowmeta[min(rb0 + min(f_rbl, nrb - 1), N / 16 - 1) * 16 + f_r];
     __builtin_amdgcn_sched_barrier(0);
     Tile T0 = load_tile(wave);
     __builtin_amdgcn_sched_barrier(0);
@@ -205,7 +216,6 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
         for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
         if (lane == 0) wsum[wave] = ss;
     }
-    const float s4 = mxq_scale(rm.z, rm.w, (uint32_t)rm.y), z4 = rm.x;
     __syncthreads();
     GEMV_STAMP(1)
 
@@ -214,9 +224,31 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     float P[MB], Q[MB], R[MB], X4[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) P[m] = Q[m] = R[m] = X4[m] = 0.f;
-    auto compute = [&](int c4, const Tile& t) {
-        const int chunk = c4 * 4 + cs;
-        if (chunk < NC) {                               // no memory ops inside: the wait counts stay exact
+    // a wave's partial sums of local row block `rbl`: over its 4 chunk slots, then into LDS -- {4 (P - Q), R, X4} per
+    // (token, row); the row's s4 / z4 enter in the final reduction
+    auto flush = [&](int rbl) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            float a = 4.0f * (P[m] - Q[m]), b = R[m], c = X4[m];
+            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64); c += __shfl_xor(c, 16, 64);
+            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64); c += __shfl_xor(c, 32, 64);
+            if (cs == 0) {
+                float* d = red + (((rbl * W + wave) * MB + m) * 16 + r) * 3;
+                d[0] = a; d[1] = b; d[2] = c;
+            }
+            P[m] = Q[m] = R[m] = X4[m] = 0.f;
+        }
+    };
+    int cur_rbl = wave / NC4;                          // row block of the wave's first tile (wave-uniform, as every tile index)
+    auto compute = [&](int ti, const Tile& t) {
+        if (ti < NT) {                                  // no memory ops inside: the wait counts stay exact
+            const int rbl = ti / NC4;
+            if (RB > 1 && rbl != cur_rbl) {
+                flush(cur_rbl);
+                cur_rbl = rbl;
+            }
+            const int chunk = (ti - rbl * NC4) * 4 + cs;
+            if (chunk < NC) {
             const char* xk = smem + (size_t)chunk * 128;
             const float* xg = xsum + chunk * 4;
 #pragma unroll
@@ -247,10 +279,11 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
                     X4[m] += xg[m * NG + G0 + q];
                 }
             }
+            }
         }
     };
     // two tiles in flight while a third is computed; the register sets rotate by unrolling (no copies)
-    for (int c4 = wave; c4 < NC4; c4 += 3 * W) {
+    for (int c4 = wave; c4 < NT; c4 += 3 * W) {
         T2 = load_tile(c4 + 2 * W);
         compute(c4, T0);
         T0 = load_tile(c4 + 3 * W);
@@ -259,80 +292,95 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
         compute(c4 + 2 * W, T2);
     }
     GEMV_STAMP(2)
-    float acc[MB];
+    // (a wave without a tile of some row block -- more waves than tiles, odd shapes -- must still leave zeros there)
+    if (wave < NT) flush(cur_rbl);
+    for (int rbl = 0; rbl < nrb; ++rbl) {
+        // wave w holds tiles w, w + W, ...: it touched row block rbl iff one of them lies in [rbl NC4, (rbl + 1) NC4)
+        const int first = wave >= rbl * NC4 ? wave : wave + ((rbl * NC4 - wave + W - 1) / W) * W;
+        if (first >= (rbl + 1) * NC4 || first >= NT) {
+            if (cs == 0) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-        acc[m] = 0.f;
-        if constexpr (NG2 > 0) acc[m] = 4.0f * (P[m] - Q[m]);
-        if constexpr (NW4 > 0) acc[m] += 16.0f * s4 * (R[m] - __builtin_fmaf(z4, 0.0625f, 1.0f) * X4[m]);
-    }
-
-    // reduce over the 4 chunk slots of the wave, then over waves
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-        float v = acc[m];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (cs == 0) red[(wave * MB + m) * 16 + r] = v;
+                for (int m = 0; m < MB; ++m) {
+                    float* d = red + (((rbl * W + wave) * MB + m) * 16 + r) * 3;
+                    d[0] = 0.f; d[1] = 0.f; d[2] = 0.f;
+                }
+            }
+        }
     }
     __syncthreads();
-    if (tid < MB * 16) {
-        const int m = tid >> 4, rr = tid & 15;
-        float v = 0.f;
+    if (tid < nrb * MB * 16) {
+        const float s4 = mxq_scale(rm.z, rm.w, (uint32_t)rm.y), z4 = rm.x;
+        float a = 0.f, b = 0.f, c = 0.f;
 #pragma unroll
-        for (int w = 0; w < W; ++w) v += red[(w * MB + m) * 16 + rr];
+        for (int w = 0; w < W; ++w) {
+            const float* d = red + (((f_rbl * W + w) * MB + f_m) * 16 + f_r) * 3;
+            a += d[0]; b += d[1]; c += d[2];
+        }
+        float v = 0.f;
+        if constexpr (NG2 > 0) v = a;
+        if constexpr (NW4 > 0) v += 16.0f * s4 * (b - __builtin_fmaf(z4, 0.0625f, 1.0f) * c);
         if constexpr (PRO == 1) {
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < W; ++w) tot += wsum[w];
             v *= rsqrtf(tot / (float)K + eps);
         }
-        if (m < M) {
+        if (f_m < M) {
+            const int n = (rb0 + f_rbl) * 16 + f_r;
             _Float16 h = (_Float16)v;
-            if (residual) h = __builtin_bit_cast(_Float16, residual[(int64_t)m * N + rb * 16 + rr]) + h;
-            y[(int64_t)m * N + rb * 16 + rr] = __builtin_bit_cast(uint16_t, h);
+            if (residual) h = __builtin_bit_cast(_Float16, residual[(int64_t)f_m * N + n]) + h;
+            y[(int64_t)f_m * N + n] = __builtin_bit_cast(uint16_t, h);
         }
     }
     GEMV_STAMP(3)
 }
 
-template <int MB, int THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED>
+template <int MB, int THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED, int RB = 1>
 int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
              const void* norm_w, float eps, const void* residual, hipStream_t stream) {
     constexpr int W = THREADS / 64;
-    const size_t smem = (size_t)MB * K * 2 + (size_t)MB * (K / 16) * 4 + (size_t)W * (MB * 16 + 1) * 4 + 64 * 32 + 64 * 4;
+    static_assert(RB * MB * 16 <= THREADS, "one thread per output of the final reduction");
+    const size_t smem = (size_t)MB * K * 2 + (size_t)MB * (K / 16) * 4 + (size_t)RB * W * MB * 16 * 3 * 4 + (size_t)W * 4 +
+                        64 * 32 + 64 * 4;
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT>,
+        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT, RB>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT><<<N / 16, THREADS, smem, stream>>>(
+    const int rbs = N / 16;
+    mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT, RB><<<(rbs + RB - 1) / RB, THREADS, smem, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K,
         (const uint16_t*)norm_w, eps, (const uint16_t*)residual);
     return (int)hipGetLastError();
 }
 
-// Waves per workgroup by row-block count: every workgroup resident at once (~5 waves per SIMD at ~90 VGPRs), some
-// 2-3 thousand waves on the chip, each with several tiles to pipeline.  <= 384 row blocks (N = 4096): 8 waves (K = 4096:
-// 2 tiles each, all in flight from the start; K = 11008: 5-6 each); <= 768 (q|k|v): 4 waves; more (gate|up: 1376): 2.
-__host__ inline int gemv_threads(int N, int forced) {
+// Workgroup shape by row-block count: every workgroup resident at once (~5 waves per SIMD at ~90 VGPRs), some 2-3 thousand
+// waves on the chip, each with several tiles to pipeline -- 8 waves per row block up to 384 row blocks (N = 4096; K = 4096:
+// 2 tiles each, all in flight from the start; K = 11008: 5-6 each), 4 per row block up to 768 (q|k|v), 2 beyond (gate|up:
+// 1376).  Round 4: with K % 256 == 0 (whole tiles per row block) the wide launches keep those wave counts but as 8-wave
+// workgroups of 2 / 4 consecutive row blocks that stage the activations once (code 2 / 4 in the high bits).
+__host__ inline int gemv_shape(int N, int K, int forced) {
     if (forced) return forced;
     const int rbs = N / 16;
-    return rbs <= 384 ? 512 : rbs <= 768 ? 256 : 128;
+    if (rbs <= 384) return 512;
+    if (K % 256 == 0) return rbs <= 768 ? (2 << 16) | 512 : (4 << 16) | 512;
+    return rbs <= 768 ? 256 : 128;
 }
 
-#define MXQ_GEMV_DISPATCH(MB, PRO, LAYOUT, TH)                                                                          \
-    ((TH) == 512   ? launch_t<MB, 512, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
-     : (TH) == 256 ? launch_t<MB, 256, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
-     : (TH) == 128 ? launch_t<MB, 128, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
-                   : (int)hipErrorInvalidValue)
+#define MXQ_GEMV_DISPATCH(MB, PRO, LAYOUT, TH)                                                                                  \
+    ((TH) == 512              ? launch_t<MB, 512, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
+     : (TH) == 256            ? launch_t<MB, 256, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
+     : (TH) == 128            ? launch_t<MB, 128, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
+     : (TH) == ((2 << 16) | 512) ? launch_t<MB, 512, PRO, LAYOUT, 2>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream) \
+     : (TH) == ((4 << 16) | 512) ? launch_t<MB, 512, PRO, LAYOUT, 4>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream) \
+                              : (int)hipErrorInvalidValue)
 
 template <int MB, int LAYOUT = MXQ_LAYOUT_MIXED>
 int launch(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, hipStream_t stream,
            int threads = 0) {
     const void *norm_w = nullptr, *residual = nullptr;
     const float eps = 0.f;
-    const int th = gemv_threads(N, threads);
+    const int th = gemv_shape(N, K, threads);
     return MXQ_GEMV_DISPATCH(MB, 0, LAYOUT, th);
 }
 
@@ -366,7 +414,7 @@ int mxq_launch_gemv_layout_f16(const void* x, const void* qweight, const void* r
 template <int LAYOUT>
 static int fused_layout(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K, int prologue,
                         const void* norm_w, float eps, const void* residual, hipStream_t stream, int threads = 0) {
-    const int th = gemv_threads(N, threads), M = 1;
+    const int th = gemv_shape(N, K, threads), M = 1;
     switch (prologue) {
         case 0: return MXQ_GEMV_DISPATCH(1, 0, LAYOUT, th);
         case 1: return MXQ_GEMV_DISPATCH(1, 1, LAYOUT, th);

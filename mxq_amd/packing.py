@@ -30,46 +30,69 @@ def _stream(t: torch.Tensor) -> int:
 
 
 _WORKSPACES: Dict[tuple, torch.Tensor] = {}
-_WS_EAGER: Dict[tuple, bool] = {}    # key -> the buffer was created AND zeroed outside any graph capture
+_WS_EAGER: Dict[tuple, bool] = {}    # key -> the counter head has been zeroed (eagerly, or by a memset recorded in its graph)
 _WS_HEAD = 65536      # bytes of K-step counters at the head of a workspace (include/mxq_hip.h)
 MIDM_MAX_TOKENS = 256     # capi.hip: token counts that mxq_linear_f16_ws hands to the mid-M split-K kernel (no counters)
 
 
+_CAPTURE_KEYS: list = []          # capture workspaces in order of creation (bounded: _MAX_CAPTURE_WS)
+_MAX_CAPTURE_WS = 32
+_hip_rt = None
+
+
+def _capture_id(stream_handle: int) -> int:
+    """Id of the capture sequence the stream is recording (hipStreamGetCaptureInfo): unique per captured graph."""
+    global _hip_rt
+    import ctypes
+    if _hip_rt is None:
+        _hip_rt = ctypes.CDLL("libamdhip64.so")
+        _hip_rt.hipStreamGetCaptureInfo.restype = ctypes.c_int
+        _hip_rt.hipStreamGetCaptureInfo.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int),
+                                                    ctypes.POINTER(ctypes.c_ulonglong)]
+    status, cid = ctypes.c_int(0), ctypes.c_ulonglong(0)
+    rc = _hip_rt.hipStreamGetCaptureInfo(ctypes.c_void_p(stream_handle), ctypes.byref(status), ctypes.byref(cid))
+    if rc != 0 or status.value != 1:          # hipStreamCaptureStatusActive == 1
+        raise RuntimeError(f"hipStreamGetCaptureInfo: rc {rc}, status {status.value} on a stream torch reports as capturing")
+    return int(cid.value)
+
+
 def gemm_workspace(device: torch.device, counters: bool = True) -> torch.Tensor:
     """Scratch buffer of the stream-K prefill GEMM and of the mid-M kernel's partial tiles (include/mxq_hip.h:
-    mxq_linear_f16_ws), one per (device, stream): launches on one stream run in order and may share it, launches on
-    different streams may not.  Its counter head must be zero when a stream-K launch starts; the kernels leave it
-    zeroed.
+    mxq_linear_f16_ws).  Its counter head must be zero when a stream-K launch starts; the kernels leave it zeroed.
 
-    A buffer created in eager mode is zeroed once, then and there, and needs nothing more: every launch (eager or
-    replayed from a graph) finds the counters as the previous one left them -- zero.  A buffer FIRST created under
-    hipGraph capture has never been zeroed for real until a replay runs, and an earlier capture's memset belongs to a
-    graph that may never be replayed: such a buffer gets a captured memset in front of EVERY captured launch that uses
-    the counters (4.5 us per launch in the graph: round 3 found it inside every graph-replay timing of round 2).  So
-    the buffer that captured launches use is created and zeroed together with the first EAGER buffer of the device:
-    run one eager ``linear`` (or ``gemm_workspace(device)``) before capturing, as every tool here does, and no memset
-    is captured.  All graphs of a device share that buffer: replay them one at a time.
+    Eager launches: one buffer per (device, stream), created and zeroed on first use -- launches on one stream run in
+    order and may share it, launches on different streams may not.
+
+    Captured launches: one buffer per CAPTURED GRAPH (keyed by the capture sequence's id), so two graphs replayed at
+    the same time on two streams never share partial sums or counters (round 3 shared one buffer per device among all
+    graphs and only documented "replay them one at a time").  It is born under capture, i.e. never zeroed for real
+    until a replay runs: its first hand-out records ONE memset of the 64-KiB counter head into the graph (once per
+    replay, ~2 us, in front of the graph's first launch -- not one per launch, which round 3 found inside every
+    graph-replay timing of round 2); later launches of the same graph find the counters as the previous one left them.
 
     ``counters=False``: the caller's kernel uses the buffer beyond the head only (the mid-M kernel's partial tiles):
-    no memset is ever captured for it."""
+    no memset is recorded for it."""
     dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(device).cuda_stream
     capturing = torch.cuda.is_current_stream_capturing()
-    # captured launches share ONE buffer per device (torch captures on a side stream of its own, so a per-stream key
-    # would always be born under capture); it is created and zeroed EAGERLY, together with the first eager buffer
-    key = (dev_index, "capture") if capturing else (dev_index, torch.cuda.current_stream(device).cuda_stream)
+    key = (dev_index, "capture", _capture_id(stream)) if capturing else (dev_index, stream)
     ws = _WORKSPACES.get(key)
     if ws is None:
         nbytes = _lib.load().mxq_gemm_workspace_bytes()
         ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        ws[:_WS_HEAD].zero_()
         _WS_EAGER[key] = not capturing
-        ckey = (dev_index, "capture")
-        if not capturing and ckey not in _WORKSPACES:
-            cws = _WORKSPACES[ckey] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            cws[:_WS_HEAD].zero_()
-            _WS_EAGER[ckey] = True
-    elif capturing and counters and not _WS_EAGER.get(key, False):
-        ws[:_WS_HEAD].zero_()
+        if capturing:
+            _WS_EAGER[key] = False                    # ... until a counters hand-out has recorded the memset
+            _CAPTURE_KEYS.append(key)
+            while len(_CAPTURE_KEYS) > _MAX_CAPTURE_WS:    # the graph's memory pool keeps the buffer alive, not this cache
+                old = _CAPTURE_KEYS.pop(0)
+                _WORKSPACES.pop(old, None)
+                _WS_EAGER.pop(old, None)
+        else:
+            ws[:_WS_HEAD].zero_()
+    if capturing and counters and not _WS_EAGER.get(key, False):
+        ws[:_WS_HEAD].zero_()                          # recorded once per graph
+        _WS_EAGER[key] = True
     return ws
 
 
@@ -120,12 +143,12 @@ def reset_gemm_workspace(device: Optional[torch.device] = None):
     """Re-zero the counter heads of the cached stream-K workspaces (all devices, or one).  Needed only after a
     GEMM launch was aborted mid-kernel (device reset, killed process sharing the buffer): the kernels themselves
     always leave the counters zeroed.  Synchronises the device(s) involved."""
-    for (dev_index, _stream), ws in list(_WORKSPACES.items()):
+    for key, ws in list(_WORKSPACES.items()):
+        dev_index = key[0]
         if device is None or (device.index if device.index is not None else torch.cuda.current_device()) == dev_index:
             torch.cuda.synchronize(dev_index)
             ws[:_WS_HEAD].zero_()
             torch.cuda.synchronize(dev_index)
-            _WS_EAGER[(dev_index, _stream)] = True
 
 
 def _need_gpu(*ts: torch.Tensor):

@@ -24,3 +24,24 @@ def test_decode_pipeline_world2_tokens_equal_single_process(compact):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["tokens_equal_single_process"] == 12 and d["backend"] == "gloo"
+
+
+@pytest.mark.gpu
+def test_bench_world2_proves_its_ranks_and_carries_the_decode_figure():
+    """bench.py --gpus 2 (gloo rehearsal: both ranks share cuda:0): the JSON line must show WHO took part -- ranks_seen
+    from an all-reduce of ones, every rank's pid / device identity -- and carry the bounded configs[2] side figure
+    (32 greedy-decode tokens through the same layer pipeline, rank 0 re-decoding them in one process).  On the driver's
+    8-GPU SCALE run the same fields read ranks_seen = distinct_devices = N over RCCL."""
+    env = dict(os.environ, MXQ_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert d["distinct_devices"] == 1                                   # a rehearsal: one GPU under both ranks
+    assert [x["rank"] for x in d["ranks"]] == [0, 1] and len({x["pid"] for x in d["ranks"]}) == 2
+    assert all(x["device_id"] for x in d["ranks"])
+    fig = d["decode_pipeline"]
+    assert fig["n_gpus"] == 2 and fig["tokens"] == 32 and fig["tokens_equal_single_process"] is True
+    assert fig["tokens_per_s"] > 0 and d["value"] > 0

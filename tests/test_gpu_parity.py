@@ -530,22 +530,49 @@ def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):
     assert all(torch.equal(o, ref) for lst in outs for o in lst)
     keys = {k for k in packing._WORKSPACES if k[0] == x.device.index}
     assert len(keys) >= 3                                          # default stream + two side streams
-    # the buffer captured launches use was created and zeroed eagerly (together with the first eager one): nothing
-    # but the GEMM is captured.  One that is BORN under capture gets a captured memset in front of every launch.
-    ckey = (x.device.index, "capture")
-    assert packing._WS_EAGER[ckey]
-    packing._WORKSPACES.pop(ckey)
-    packing._WS_EAGER.pop(ckey)
-    g2 = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g2):
-        packing.linear(x, p, out=out, path="gemm9")
-    assert not packing._WS_EAGER[ckey]
-    packing._WORKSPACES[ckey][:65536].fill_(7)                     # whatever the buffer holds before the first replay
+    # every captured graph owns its workspace (keyed by the capture sequence's id): ONE memset of the counter head is
+    # recorded per graph, and whatever the buffer holds before a replay does not matter
+    ckeys = [k for k in packing._WORKSPACES if k[0] == x.device.index and len(k) == 3 and k[1] == "capture"]
+    assert len(ckeys) >= 1
+    for k in ckeys:
+        packing._WORKSPACES[k][:65536].fill_(7)
     for _ in range(2):
         out.zero_()
-        g2.replay()
+        graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+def test_two_stream_k_graphs_replayed_concurrently(dev):
+    """Two graphs with stream-K launches (partial tiles + counters in the workspace), replayed AT THE SAME TIME on two
+    streams, many times: each graph has its own workspace, so neither corrupts the other's partial sums (round 3 shared
+    one buffer per device among all captured launches)."""
+    from mxq_amd import packing
+    pa, _, g = _packed_case(dev, 2048, 4096, 21)
+    pb, _, _ = _packed_case(dev, 1152, 8192, 22)
+    xa = torch.randn(512, 4096, generator=g).half().to(dev)
+    xb = torch.randn(100, 8192, generator=g).half().to(dev)
+    refa, refb = packing.linear(xa, pa, path="gemm9"), packing.linear(xb, pb, path="gemm9")
+    outa, outb = torch.empty_like(refa), torch.empty_like(refb)
+    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(ga):
+        for _ in range(4):
+            packing.linear(xa, pa, out=outa, path="gemm9")
+    with torch.cuda.graph(gb):
+        for _ in range(4):
+            packing.linear(xb, pb, out=outb, path="gemm9")
+    ckeys = [k for k in packing._WORKSPACES if len(k) == 3 and k[1] == "capture"]
+    assert len({packing._WORKSPACES[k].data_ptr() for k in ckeys}) >= 2
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(10):
+        outa.zero_(); outb.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            ga.replay()
+        with torch.cuda.stream(s2):
+            gb.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(outa, refa) and torch.equal(outb, refb)
 
 
 def test_linear_empty_and_nonfinite_inputs(dev):
