@@ -357,14 +357,16 @@ int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, i
 // Workgroup shape by row-block count: every workgroup resident at once (~5 waves per SIMD at ~90 VGPRs), some 2-3 thousand
 // waves on the chip, each with several tiles to pipeline -- 8 waves per row block up to 384 row blocks (N = 4096; K = 4096:
 // 2 tiles each, all in flight from the start; K = 11008: 5-6 each), 4 per row block up to 768 (q|k|v), 2 beyond (gate|up:
-// 1376).  Round 4: with K % 256 == 0 (whole tiles per row block) the wide launches keep those wave counts but as 8-wave
-// workgroups of 2 / 4 consecutive row blocks that stage the activations once (code 2 / 4 in the high bits).
+// 1376).  Round 4 (profiles/r04_gemv_rowblocks.txt): workgroups of RB consecutive row blocks staging the activations once
+// pay only where the workgroup COUNT stays high -- gate|up as 688 workgroups of 2 row blocks x 4 waves: 16.65 vs 17.24 us;
+// every shape that drops to <= 1.5 workgroups per CU loses 15-30 % (a CU with two 8-wave workgroups next to CUs with one
+// finishes last: the launch is bound per CU, not per chip).  Code: RB in the high bits.
 __host__ inline int gemv_shape(int N, int K, int forced) {
     if (forced) return forced;
     const int rbs = N / 16;
     if (rbs <= 384) return 512;
-    if (K % 256 == 0) return rbs <= 768 ? (2 << 16) | 512 : (4 << 16) | 512;
-    return rbs <= 768 ? 256 : 128;
+    if (rbs <= 768) return 256;
+    return K % 256 == 0 ? (2 << 16) | 256 : 128;
 }
 
 #define MXQ_GEMV_DISPATCH(MB, PRO, LAYOUT, TH)                                                                                  \
@@ -373,6 +375,8 @@ __host__ inline int gemv_shape(int N, int K, int forced) {
      : (TH) == 128            ? launch_t<MB, 128, PRO, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream)      \
      : (TH) == ((2 << 16) | 512) ? launch_t<MB, 512, PRO, LAYOUT, 2>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream) \
      : (TH) == ((4 << 16) | 512) ? launch_t<MB, 512, PRO, LAYOUT, 4>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream) \
+     : (TH) == ((2 << 16) | 256) ? launch_t<MB, 256, PRO, LAYOUT, 2>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream) \
+     : (TH) == ((4 << 16) | 256) ? launch_t<MB, 256, PRO, LAYOUT, 4>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream) \
                               : (int)hipErrorInvalidValue)
 
 template <int MB, int LAYOUT = MXQ_LAYOUT_MIXED>
