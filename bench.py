@@ -162,6 +162,35 @@ def long_prefill(layers, dev, tokens=32768, iters=3):
             "layer_ms": round(ms, 3), "TFLOPs": round(fl / ms / 1e9, 1), "mfma_frac": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4)}
 
 
+def fused_launch_figure(layers, dev, x_h, x_i, y_h, steps=5):
+    """Side figure, not `value`: the same 224 Linears with q|k|v and gate|up as ONE launch each (128 launches per step;
+    the packed blocks are independent per 16 rows, so the fused weight is the concatenation along the output dimension --
+    what the decode stage does, mxq_amd/llama_decode.py).  Same FLOPs, same outputs (concatenated); fewer, longer
+    launches: q|k|v is exactly 3 rounds of tiles and gate|up's tail is a smaller share of its launch."""
+    fused = [[("qkv", packing.concat_packed([p for _, p in lin[0:3]])), lin[3],
+              ("gate_up", packing.concat_packed([p for _, p in lin[4:6]])), lin[6]] for lin in layers]
+    ys = {N: torch.empty(SEQ, N, device=dev, dtype=torch.float16) for N in (3 * LS.HIDDEN, 2 * LS.INTERMEDIATE)}
+
+    def step():
+        for lin in fused:
+            for _name, p in lin:
+                x = x_i if p.K == LS.INTERMEDIATE else x_h
+                packing.linear(x, p, out=(ys[p.N] if p.N in ys else y_h), path="gemm")
+    step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    fl = LS.linear_flops(SEQ, len(layers))
+    return {"workload": "the headline's 224 Linears as 128 launches per step: q|k|v and gate|up fused along the output "
+                        "dimension (NOT the headline configuration)",
+            "ms_per_step": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "launches_per_step": 4 * len(layers)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,7 +313,7 @@ def main():
     achieved = flops_rank_step / (dev_ms / args.steps * 1e-3) / 1e12
 
     traffic = None       # HBM bytes per launch from rocprofv3 PMC counters (collected offline, see the file)
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm_traffic.json") for r in (4,))
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm8_traffic.json") for r in (4,))
                   if os.path.exists(q)), "") or \
         next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm8_traffic.json") for r in (3, 2))
               if os.path.exists(q)), "")
@@ -338,6 +367,7 @@ def main():
             decode_fig.pop("token_ids", None)
             out["decode_pipeline"] = decode_fig
         if world == 1 and not args.fuse:
+            out["fused_launches_figure"] = fused_launch_figure(layers, dev, x_h, x_i, y_h)
             out["long_prefill"] = long_prefill(layers, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev)

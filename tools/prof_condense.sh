@@ -24,7 +24,7 @@ python3 - <<PY
 import json
 lines=[l for l in open('gpurun_out/${T}_config5_sweep.log') if l.startswith('{"config"')]
 d=json.loads(lines[-1])
-d["note"]="tools/prof_round.sh ${T}: launches of >= 4096 tokens take the hoisted-dequant mode automatically (dequant once into a transient fp16 scratch + a dense MFMA kernel on fp16 tiles -- csrc/dense256.hip at this size --, bit-identical results); the dequant pass is inside every timed launch."
+d["hoist_note"]="tools/prof_round.sh ${T}: launches of >= 4096 tokens take the hoisted-dequant mode automatically (dequant once into a transient fp16 scratch + a dense MFMA kernel on fp16 tiles -- csrc/dense256.hip at this size --, bit-identical results); the dequant pass is inside every timed launch."
 json.dump(d,open('profiles/${P}_config5_sweep.json','w'),indent=1)
 print({k:v["TFLOPs"] for k,v in d["arms"].items()})
 PY

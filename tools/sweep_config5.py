@@ -5,7 +5,15 @@
 and 32-layer totals; and PyTorch's fp16 GEMM (hipBLASLt) on the dequantised weight as reference.  Every
 quantised arm is checked at the full size (<= 1e-3 max-norm and Frobenius against the fp32 product on the
 kernel-dequantised weight, 4096 sampled token rows) before its time is reported.
-    python tools/sweep_config5.py [--m 32768] [--iters 5] [--rounds 5]"""
+    python tools/sweep_config5.py [--m 32768] [--iters 5] [--rounds 5]
+
+Round 4 adds the legs where the arms DIFFER (at 32768 tokens every arm's default path is the hoisted mode: one dense
+kernel on an fp16 scratch, so the three arms can only tie):
+  * `hbm_bound`: M = 1 (streaming GEMV) and M = 16 (skinny MFMA kernel) per arm -- mixed, mixed with compact metadata,
+    W2G16, W4ROW -- in us, GB/s of packed bytes and % of the 8 TB/s spec: decode is where bits per weight are bytes per
+    token (reference: gemv_kernel_g128_2bit / gemv_kernel_g128, gemv_cuda.cu:188-330);
+  * `fused_at_full_size`: the FUSED kernel (dequant inside the K loop, path "fused") at the sweep's token count, where the
+    layouts' conversion work differs (2-bit LUT groups vs 4-bit arithmetic)."""
 import argparse
 import json
 import os
@@ -87,6 +95,9 @@ def main():
     report = {"config": f"W2A16 / W4A16 / mixed-2/4 sweep, M = {M} tokens (batch 8 x seq 4096)",
               "method": f"{args.rounds} rounds over all (shape, arm) cases in rotated / reversed order after {args.warm_s} s of "
                         f"warm-up, {args.iters} launches per sample; ms = median, spread = (max - min) / median", "arms": {}}
+    report["note"] = ("arms 'mixed' / 'w2g16' / 'w4row' at this token count take the hoisted-dequant mode: ONE dequant pass into "
+                      "an fp16 scratch + the SAME dense 256 x 256 kernel -- they differ only by their dequant pass; see "
+                      "'fused_at_full_size' and 'hbm_bound' for the legs where the layouts differ")
     for arm in ARMS:
         layer_t = layer_f = 0.0
         rows = []
@@ -106,6 +117,77 @@ def main():
                                "TFLOPs": round(layer_f / layer_t / 1e12, 1),
                                "tokens_per_s": round(M / (32 * layer_t), 1)}
         print(arm, json.dumps(report["arms"][arm]), flush=True)
+    # ---- the fused kernel at the full size (per layer): the conversion work differs by layout
+    fused = {}
+    for name, N, K, mult in SHAPES:
+        g = torch.Generator(device=dev).manual_seed(N * 7 + K)
+        W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
+        x = torch.randn(M, K, generator=g, device=dev).half()
+        out = torch.empty(M, N, device=dev, dtype=torch.float16)
+        for arm in ("mixed", "w2g16", "w4row"):
+            p = packing.quantize_pack(W) if arm == "mixed" else packing.quantize_pack_uniform(W, arm)
+            t = min(burst(lambda: packing.linear_layout(x, p, out=out, path="fused"), args.iters) for _ in range(3))
+            fused.setdefault(arm, []).append((name, N, K, mult, t))
+        del W, x, out
+    report["fused_at_full_size"] = {}
+    for arm, rows in fused.items():
+        lt = sum(mult * t for _, _, _, mult, t in rows)
+        lf = sum(mult * 2.0 * M * N * K for _, N, K, mult, _ in rows)
+        report["fused_at_full_size"][arm] = {
+            "per_linear": [{"linear": n, "ms": round(t * 1e3, 3), "TFLOPs": round(2.0 * M * N * K / t / 1e12, 1)} for n, N, K, _, t in rows],
+            "layer_ms": round(lt * 1e3, 3), "TFLOPs": round(lf / lt / 1e12, 1)}
+    print("fused_at_full_size", json.dumps(report["fused_at_full_size"]), flush=True)
+
+    # ---- the HBM-bound leg: M = 1 (GEMV) and M = 16 (skinny kernel); hipGraph replay over >= 600 MB of DISTINCT packed
+    # weights per graph so that every launch streams from HBM (the 256 MiB Infinity Cache would serve a replay otherwise)
+    def graph_us(calls):
+        calls[0]()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for c in calls:
+                c()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            gr.replay()
+            e0.record()
+            gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / len(calls) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+
+    hbm = []
+    for name, N, K, mult in SHAPES:
+        g = torch.Generator(device=dev).manual_seed(N * 7 + K)
+        W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
+        for arm in ("mixed", "mixed-compact", "w2g16", "w4row"):
+            base = (packing.quantize_pack(W, compact_meta=arm == "mixed-compact") if arm.startswith("mixed")
+                    else packing.quantize_pack_uniform(W, arm))
+            nbytes = base.nbytes()
+            ncopy = max(2, int(600e6 / nbytes) + 1)
+
+            def clone(b):
+                if isinstance(b, packing.PackedMXQ):
+                    return packing.PackedMXQ(b.qweight.clone(), b.rowmeta.clone(), b.N, b.K, b.compact)
+                return packing.PackedUniform(b.qweight.clone(), b.rowmeta.clone(), b.N, b.K, b.layout)
+            ws = [base] + [clone(base) for _ in range(ncopy - 1)]
+            row = {"linear": name, "N": N, "K": K, "arm": arm, "bits_per_weight": round(base.bits_per_weight(), 3),
+                   "packed_MB": round(nbytes / 1e6, 2)}
+            for Mh in (1, 16):
+                xh = torch.randn(Mh, K, generator=g, device=dev).half()
+                oh = torch.empty(Mh, N, device=dev, dtype=torch.float16)
+                calls = [(lambda p=p: packing.linear_layout(xh, p, out=oh, path="auto")) for p in ws]
+                us = graph_us(calls)
+                row[f"M{Mh}"] = {"us": round(us, 2), "GBps": round(nbytes / us / 1e3, 1), "pct_of_8TBps": round(nbytes / us / 1e3 / 80.0, 1)}
+            hbm.append(row)
+            print("hbm_bound", json.dumps(row), flush=True)
+            del ws
+        del W
+    report["hbm_bound"] = {"method": "hipGraph replay over >= 600 MB of distinct packed weights per graph, median of 5; bytes = the "
+                                     "packed weight (codes + metadata + rowmeta); M = 1: streaming GEMV, M = 16: skinny MFMA kernel",
+                           "rows": hbm}
     print(json.dumps(report))
 
 
