@@ -338,7 +338,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
     path: "auto" (GEMV kernel for <= 4 tokens, skinny MFMA kernel up to 40 -- 20 for weights beyond 24 M elements --,
     mid-M split-K kernel up to 256, prefill GEMM beyond: the C dispatch of mxq_linear_f16_ws), "gemm", "gemv", "midm",
     "skinny" (1..64 tokens), "hoist" (dequant hoisted out of the token loop; "auto" / "gemm" take it from
-    HOIST_MIN_TOKENS tokens on), "fused" (never hoist), or an explicit GEMM
+    HOIST_MIN_TOKENS tokens on), "fused" (never hoist), "whole" (fused kernel, whole tiles only), or an explicit GEMM
     kernel: "gemm1" (128x128 tile), "gemm8" (256x128 tile, wave-specialised, persistent, stream-K tail), "gemm9"
     (gemm8 splitting its tail whenever that is structurally possible: tests)."""
     _need_gpu(x, p.qweight)
@@ -377,6 +377,11 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
     if path == "skinny":
         with torch.cuda.device(x.device):
             _lib.check(lib.mxq_skinny_f16(*args, 3 if p.compact else 0, _stream(x2)), "mxq_skinny_f16")
+        return out.reshape(*x.shape[:-1], p.N)
+    if path == "whole":   # the fused prefill kernel on whole tiles only (no workspace: no stream-K split, so a tile's sums
+        #                   do not depend on the launch's token count: tests compare launches of different sizes bit for bit)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.mxq_gemm_f16_layout(*args, _layout_code(p), _stream(x2)), "mxq_gemm_f16_layout[whole]")
         return out.reshape(*x.shape[:-1], p.N)
     if p.compact:      # compact metadata: the layout entry points (same kernels, other field offsets)
         if path not in ("auto", "gemm", "gemv", "gemm8", "fused"):
@@ -510,6 +515,8 @@ def linear_layout(x: torch.Tensor, p, out: Optional[torch.Tensor] = None, path: 
     M = x2.shape[0]
     if out is None:
         out = torch.empty((M, p.N), dtype=torch.float16, device=x.device)
+    if path == "whole":
+        path = "fused"                                 # (uniform layouts: "fused" already runs without a workspace)
     if path not in ("gemm", "gemv", "auto", "hoist", "fused", "skinny"):
         raise ValueError(f"unknown path {path!r}")
     if M == 0:
