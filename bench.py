@@ -197,6 +197,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="no side figures and no CPU baseline: the process launches nothing but the headline's kernels "
+                         "(what tools/prof_round.sh traces, so that the trace's per-kernel average is the headline's)")
     ap.add_argument("--graph", action="store_true",
                     help="N = 1: replay the step as one hipGraph (measured r04: 1073.3 vs 1073.4 TFLOP/s stream-ordered -- the "
                          "queue never runs dry, so this is not the default)")
@@ -366,10 +369,10 @@ def main():
         if decode_fig is not None:
             decode_fig.pop("token_ids", None)
             out["decode_pipeline"] = decode_fig
-        if world == 1 and not args.fuse:
+        if world == 1 and not args.fuse and not args.headline_only:
             out["fused_launches_figure"] = fused_launch_figure(layers, dev, x_h, x_i, y_h)
             out["long_prefill"] = long_prefill(layers, dev)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             out["cpu_baseline"] = cpu_baseline(dev)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -5,7 +5,7 @@ set -e
 T=${1:-r02}
 P=${2:-r02}        # prefix of the committed files: profiles/<P>_*
 cd "$(dirname "$0")/.."
-python3 tools/prof_summary.py gpurun_out/${T}_bench profiles/${P}_bench_gemm8.txt "bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+python3 tools/prof_summary.py gpurun_out/${T}_bench profiles/${P}_bench_gemm8.txt "bench.py --steps 5 --warmup 2 --headline-only"
 cp gpurun_out/${T}_bench.json profiles/${P}_bench_gemm8.json
 python3 tools/traffic_json.py gpurun_out ${T} profiles/${P}_gemm8_traffic.json
 { echo "# rocprofv3 --pmc passes of tools/gemm_prof.py gemm 2048 4096 4096 (tools/prof_round.sh ${T})"

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_bench -- python3 $R/bench.py --steps 5 --warmup 2 --headline-only > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench trace done"
 for shape in "4096 4096" "11008 4096" "4096 11008"; do
   set -- $shape
