@@ -77,6 +77,11 @@ constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K
 [[maybe_unused]] constexpr int ABL_NO_Q4 = 16, ABL_MMA_VALU = 32;
 // scheduling experiments (correct results): issue priorities of the two roles
 [[maybe_unused]] constexpr int EXP_NO_PRIO = 1024, EXP_MMA_PRIO = 2048, EXP_STAMPS = 4096;
+// r04 "halving" ablations (timing only; the operands stay RANDOM, unlike the remove-it-all ablations whose constant LDS
+// contents let the chip clock higher): 512 = the MFMA waves issue 2 of their 4 x pieces per step (the other rows of the
+// slot keep an earlier step's x); 8192 = a burst converts only the first of its 3 chunks (the other two W16 writes carry
+// the previous burst's weights)
+[[maybe_unused]] constexpr int ABL_HALF_XDMA = 512, ABL_THIRD_DEQ = 8192;
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
@@ -252,13 +257,14 @@ __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, in
     }
 #endif
     MXQ_FENCE();
-    if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) issue_x<2, 4>(xd, smem, wave, t + 2);
+    if constexpr (ISSUE && !(ABL & (ABL_NO_XDMA | ABL_HALF_XDMA))) issue_x<2, 4>(xd, smem, wave, t + 2);
     MXQ_FENCE();
     mfma_rows<2, 4, ABL>(acc, wf0, xf0, &fl);
     if constexpr (((ABL >> 6) & 3) != 0) asm volatile("" ::"v"(fl.f[0]), "v"(fl.f[1]), "v"(fl.f[2]), "v"(fl.f[3]));
     if constexpr (MXQ_STAMPS(ABL)) t1 = stamp();
     // this step's 4 DMAs stay in flight across the barrier; the previous step's (x of step t+1) have landed
-    if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    if constexpr (ISSUE && (ABL & ABL_HALF_XDMA) != 0) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (ISSUE && !(ABL & ABL_NO_XDMA)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if constexpr (MXQ_STAMPS(ABL)) t2 = stamp();
     __builtin_amdgcn_s_barrier();
@@ -684,6 +690,10 @@ __device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const floa
         if constexpr (!(ABL & ABL_NO_DEQ)) {
 #pragma unroll
             for (int i = 0; i < R; ++i) {
+                if ((ABL & ABL_THIRD_DEQ) != 0 && i > 0 && base > 0) {   // (the first burst converts all three: real weights stay in res)
+                    asm volatile("" ::"v"(S[i].c[0]), "v"(S[i].c[1]));
+                    continue;
+                }
                 widen_pk<LAYOUT>(S[i]);
                 convert_pk<LAYOUT, H, (ABL & ABL_NO_Q4) != 0>(c, S[i], res[i]);
             }
@@ -1092,6 +1102,9 @@ extern "C" int mxq_prof_gemm8_ablate_f16(const void* x, const void* qweight, con
         case 16: return launch8<16>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
         case 32: return launch8<32>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
         case 48: return launch8<48>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 512: return launch8<512>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 8192: return launch8<8192>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+        case 8704: return launch8<8704>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
         // 64 / 128 / 192: one / two / three in-stream filler VALU ops behind every MFMA (+ 4: without the dequant)
         case 64: return launch8<64>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
         case 68: return launch8<68>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
