@@ -438,6 +438,35 @@ def test_gemm_stream_k_tail(dev, M, N, K, sk):
     assert torch.equal(packing.linear(xd, p, path="gemm8"), yd)
 
 
+@pytest.mark.parametrize("M,N,K", [(640, 11008, 4096),     # 258 tiles: a 2-tile tail on 256 CUs (Llama gate/up at 640-768 tokens)
+                                   (768, 11008, 4096),
+                                   (1536, 11008, 4096),    # 516 tiles: two full rounds + a 4-tile tail
+                                   (256, 34176, 4096),     # 267 tiles: an 11-tile tail, XCDs 0-2 hold two tail tiles, 3-7 one
+                                   (2048, 11008, 4096)])   # 688 tiles: the 176-tile tail the dispatch splits since round 4
+def test_gemm_small_tail_stream_k_through_the_dispatch(dev, M, N, K):
+    """The PRODUCT dispatch's stream-K branches (csrc/gemm8.hip launch8: a tail of a few tiles split over fewer units per
+    XCD; the large tail of gate/up at 2048 tokens) -- reached by `auto` / `gemm8`, not only by the forced-split test
+    path: against the fp32 product on the dequantised weight, twice with identical bits, counters left zero."""
+    from mxq_amd import packing
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    p = packing.quantize_pack((torch.randn(N, K, generator=g, device=dev) * 0.02).half())
+    x = torch.randn(M, K, generator=g, device=dev).half()
+    wd = packing.dequant(p)
+    ws = packing.gemm_workspace(torch.device(dev))
+    for path in ("gemm8", "auto"):
+        y = packing.linear(x, p, path=path)
+        worst = 0.0
+        for n0 in range(0, N, 8192):                   # fp32 reference in column slabs
+            r = x.float() @ wd[n0:n0 + 8192].float().t()
+            worst = max(worst, ((y[:, n0:n0 + 8192].float() - r).abs().max() / r.abs().max()).item())
+        assert worst <= REL_TOL, (path, worst)
+        assert torch.equal(packing.linear(x, p, path=path), y), path
+        assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0, path
+    # the split changes the summation order of the tail tiles only: whole-tile launch within rounding
+    yw = packing.linear(x, p, path="whole")
+    assert ((y.float() - yw.float()).abs().max() / yw.float().abs().max()).item() <= REL_TOL
+
+
 @pytest.mark.parametrize("sk", ["gemm9"])
 def test_stream_k_partition_fuzz(dev, sk):
     """Random (tokens, out, in) shapes through the forced stream-K schedule against the single-tile kernel:
