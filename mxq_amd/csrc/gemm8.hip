@@ -126,7 +126,8 @@ struct SkSeg {
     int S;            // K-steps in one XCD's tail = tail tiles per XCD * NT
     int j;            // tile index inside the XCD's tail
     int first;        // 1: the segment starts at the unit's range start (slot 0), else slot 1
-    int owner;        // 1: a partial segment that ENDS its tile: finish the tile here (sk_finish_owner)
+    int owner;        // 1: a partial segment that ENDS its tile: finish the tile here (sk_finish_owner) ...
+    int dist;         // ... unless the tile has >= SK_DIST_MIN contributors: then every piece is parked (sk_reduce_distributed)
     int pend_j, pend_n;   // a parked piece whose counter bump is due as soon as its stores have retired (-1: none)
 };
 // A wave's 16 KB slot, 16 bytes per lane and fragment: ONE sc1 (write-through / L1-bypassing) 16-byte access per fragment,
@@ -297,34 +298,40 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[4][4], uint16_t* _
 // +-2; v_permlane16_swap: lanes +-16 <-> blocks +-1) transpose the grid, after which lane fq owns block fq whole:
 // 32 contiguous bytes = two 16-byte stores, and the 4 lanes together write the token's full 128-B line.  Needs no
 // LDS, so the x ring can be refilled for the NEXT tile while this one is still being written (persistent loop).
-__device__ __forceinline__ void store_tile_xpose(const f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N,
-                                                 int m0, int n0, int wm, int wn, int fr, int fq) {
+// ... one token block j of a wave's sub-tile: c4[i] = the lane's 4 channels of W-fragment block i for token j * 16 + fr
+__device__ __forceinline__ void store_block_xpose(const f32x4 (&c4)[4], uint16_t* __restrict__ y, int M, int N, int m0, int n0,
+                                                  int wm, int wn, int j, int fr, int fq) {
     typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
     const int n = n0 + wn * 64 + fq * 16;
+    uint32_t c[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        c[i][0] = mxq_pack_f16(c4[i][0], c4[i][1]);
+        c[i][1] = mxq_pack_f16(c4[i][2], c4[i][3]);
+    }
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        u32x2v r;
+        r = __builtin_amdgcn_permlane32_swap(c[0][d], c[2][d], false, false); c[0][d] = r[0]; c[2][d] = r[1];
+        r = __builtin_amdgcn_permlane32_swap(c[1][d], c[3][d], false, false); c[1][d] = r[0]; c[3][d] = r[1];
+        r = __builtin_amdgcn_permlane16_swap(c[0][d], c[1][d], false, false); c[0][d] = r[0]; c[1][d] = r[1];
+        r = __builtin_amdgcn_permlane16_swap(c[2][d], c[3][d], false, false); c[2][d] = r[0]; c[3][d] = r[1];
+    }
+    const int m = m0 + wm * 64 + j * 16 + fr;
+    if (m < M && n < N) {
+        uint16_t* dst = y + (int64_t)m * N + n;
+        // streaming stores: y is written once and not read by this kernel, so it should not displace x / W
+        // lines in L2 (+0.7-1.5 % at 32768 tokens, neutral at 2048: profiles/r03_nt_stores.txt)
+        __builtin_nontemporal_store((u32x4){c[0][0], c[0][1], c[1][0], c[1][1]}, (u32x4*)dst);
+        __builtin_nontemporal_store((u32x4){c[2][0], c[2][1], c[3][0], c[3][1]}, (u32x4*)(dst + 8));
+    }
+}
+__device__ __forceinline__ void store_tile_xpose(const f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N,
+                                                 int m0, int n0, int wm, int wn, int fr, int fq) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        uint32_t c[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            c[i][0] = mxq_pack_f16(acc[i][j][0], acc[i][j][1]);
-            c[i][1] = mxq_pack_f16(acc[i][j][2], acc[i][j][3]);
-        }
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            u32x2v r;
-            r = __builtin_amdgcn_permlane32_swap(c[0][d], c[2][d], false, false); c[0][d] = r[0]; c[2][d] = r[1];
-            r = __builtin_amdgcn_permlane32_swap(c[1][d], c[3][d], false, false); c[1][d] = r[0]; c[3][d] = r[1];
-            r = __builtin_amdgcn_permlane16_swap(c[0][d], c[1][d], false, false); c[0][d] = r[0]; c[1][d] = r[1];
-            r = __builtin_amdgcn_permlane16_swap(c[2][d], c[3][d], false, false); c[2][d] = r[0]; c[3][d] = r[1];
-        }
-        const int m = m0 + wm * 64 + j * 16 + fr;
-        if (m < M && n < N) {
-            uint16_t* dst = y + (int64_t)m * N + n;
-            // streaming stores: y is written once and not read by this kernel, so it should not displace x / W
-            // lines in L2 (+0.7-1.5 % at 32768 tokens, neutral at 2048: profiles/r03_nt_stores.txt)
-            __builtin_nontemporal_store((u32x4){c[0][0], c[0][1], c[1][0], c[1][1]}, (u32x4*)dst);
-            __builtin_nontemporal_store((u32x4){c[2][0], c[2][1], c[3][0], c[3][1]}, (u32x4*)(dst + 8));
-        }
+        const f32x4 c4[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+        store_block_xpose(c4, y, M, N, m0, n0, wm, wn, j, fr, fq);
     }
 }
 
@@ -375,6 +382,87 @@ __device__ __forceinline__ void mma_prologue_issue(const XDma& xd, char* smem, i
     }
 }
 
+// contributors of tail tile j of this XCD (units whose K range meets it, in unit order): their number, and this unit's
+// place among them (-1: none of its steps)
+constexpr int SK_SPIN_BOUND = 1 << 22;
+#ifndef MXQ_SK_DIST_MIN
+#define MXQ_SK_DIST_MIN 6
+#endif
+constexpr int SK_DIST_MIN = MXQ_SK_DIST_MIN;       // from this many contributors on, ALL of them reduce the tile (sk_reduce_distributed)
+constexpr int SK_DONE_OFF = 4096;    // ints: per-tile "done" counts behind the per-(tile, wave) K-step counts
+// (unit u holds step k iff bound(u) <= k < bound(u + 1), i.e. u = ceil((k + 1) units / S) - 1; every unit of an XCD with a tail
+//  holds at least one step -- launcher: S >= 4 units -- so the contributors are the contiguous range uf .. uf + C - 1.  Two
+//  integer divisions; a scan over the units costs 64 of them, ~5 us of vector-ALU time, and ran once per piece and per task
+//  in the first build)
+__device__ __forceinline__ int sk_contributors(const SkSeg& sk, int j, int NT_tile, int& uf) {
+    const uint32_t lo = (uint32_t)j * (uint32_t)NT_tile, hi = lo + (uint32_t)NT_tile;
+    const uint32_t U = (uint32_t)sk.units, S = (uint32_t)sk.S;
+    uf = (int)(((lo + 1u) * U + S - 1u) / S) - 1;
+    const int ul = (int)((hi * U + S - 1u) / S) - 1;
+    return ul - uf + 1;
+}
+
+// (same-process A/B, profiles/r04_streamk.txt: all-contributors reduction wins where a tile has 8 contributors that finish
+//  together -- gate/up at 640 / 768 / 1536 tokens: 82.1 -> 77.0, 83.5 -> 78.1, 145.2 -> 140.9 us -- and loses 1-8 us at 3-4
+//  contributors, where the owner's one or two extra round trips cost less than everybody's park + sync: threshold 6)
+// A tile with >= SK_DIST_MIN contributors: EVERY contributor has parked its piece (the one that ends the tile too) and every
+// one of them sums a share -- the 32 (producing wave, token block) tasks of the tile are dealt over the contributors' 8 C
+// waves; a task waits until the producing wave's K-step count is complete, brings the C slots' four fragments through LDS
+// (up to four slots per batch: 16 sc1 LDS-DMA pieces in flight = one round trip), adds them in unit order and writes the
+// token block.  The contributors of such a tile finish together (equal shares of K-steps), so an owner alone would read
+// their slots one round trip after the other -- 7 of them at 640 tokens x 11008 (258 tiles: 2 tail tiles over 8 units
+// each): 84.9 us against 65 of K-steps.  Any contributor may have to wait for any other here: every workgroup of the launch
+// is resident (grid <= CUs, one per CU) and the spin is bounded.
+__device__ __forceinline__ void sk_reduce_distributed(const SkSeg& sk, int j, int C, int uf, int NT_tile, int wave, int lane,
+                                                      char* smem, uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
+    const int lo = j * NT_tile, self = sk.u - uf;
+    // only the FIRST contributor's range can have started before the tile (its piece here is then its second: slot 1)
+    const int first_slot = sk_bound(uf, sk.S, sk.units) >= lo ? 0 : 1;
+    int* cw = sk.cnt + (j * 8 + sk.e) * N_MMA;
+    char* stage = smem + wave * 16384;
+    for (int t = self * N_MMA + wave; t < 4 * N_MMA; t += C * N_MMA) {
+        const int ws = t >> 2, jj = t & 3;
+        for (int spin = 0; spin < SK_SPIN_BOUND; ++spin) {
+            int v = 0;
+            if (lane == 0) v = __hip_atomic_load(cw + ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readfirstlane(v) >= NT_tile) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler ordering only: the slot loads are sc1
+        f32x4 c4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        int staged = 0;
+        auto flush = [&]() {                                     // (sums start from +0: unit order, fixed)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int b = 0; b < staged; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c4[i] = c4[i] + *(const f32x4*)(stage + b * 4096 + i * 1024 + lane * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next batch's DMA overwrites the stage
+            staged = 0;
+        };
+        for (int k = 0; k < C; ++k) {
+            const int v = uf + k;
+            const float* src = sk.ws + ((int64_t)((v * 8 + sk.e) * 2 + (k == 0 ? first_slot : 0)) * (BM * BN)) + ws * 4096;
+            const rsrc_t r = make_rsrc(src, 16384u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(stage + staged * 4096 + i * 1024),
+                                                         16, (uint32_t)lane * 16u, (uint32_t)(i * 4 + jj) * 1024u, 0, 16);
+            if (++staged == 4) flush();
+        }
+        if (staged) flush();
+        store_block_xpose(c4, y, M, N, m0, n0, ws >> 1, ws & 1, jj, lane & 15, lane >> 4);
+    }
+    // this wave is through with the tile; the last of the contributors' 8 C waves re-zeroes its counters for the next launch
+    if (lane == 0) {
+        int* done = sk.cnt + SK_DONE_OFF + j * 8 + sk.e;
+        if (__hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == C * N_MMA - 1) {
+#pragma unroll
+            for (int w = 0; w < N_MMA; ++w) __hip_atomic_store(cw + w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // a parked piece's K-steps enter its tile's count (pre: the slot stores have retired -- the caller's vmcnt wait)
 __device__ __forceinline__ void sk_bump_pending(SkSeg& sk, int wave, int lane) {
     if (sk.pend_j >= 0) {
@@ -387,7 +475,6 @@ __device__ __forceinline__ void sk_bump_pending(SkSeg& sk, int wave, int lane) {
 // The owner of tile sk.j (the unit whose piece holds the tile's last K-step; `own` steps, accumulators in registers): wait
 // until the wave's counter shows the other NT_tile - own steps, add the contributors' slots in unit order, write y and
 // re-zero the counter.  Contributors are units with a lower index; their piece of this tile is the FIRST thing they run.
-constexpr int SK_SPIN_BOUND = 1 << 22;
 __device__ __forceinline__ void sk_finish_owner(const SkSeg& sk, int own, int NT_tile, int wave, int lane, char* smem,
                                                 f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
     const int j = sk.j, lo = j * NT_tile;
@@ -400,8 +487,8 @@ __device__ __forceinline__ void sk_finish_owner(const SkSeg& sk, int own, int NT
         __builtin_amdgcn_s_sleep(4);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler ordering only: the slot loads are agent-scope themselves
-    int uf = 0;
-    while (uf + 1 < sk.units && sk_bound(uf + 1, sk.S, sk.units) <= lo) ++uf;
+    int uf;
+    sk_contributors(sk, j, NT_tile, uf);
     // A contributor's slot comes through LDS, not through registers: 16 LDS-DMA pieces (sc1: the bytes were written by
     // another XCD) into this wave's 16 KB of the idle rings, all in flight together = ONE loaded-memory round trip per
     // slot and no second accumulator set (64 more VGPRs spilled at the 168-register cap).  The rings are idle: this is the
@@ -491,7 +578,7 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
 
     if (NT != NT_tile) {
-        if (sk.owner) {   // the piece that ends its tile: the others' pieces were parked long ago (they run first)
+        if (sk.owner && !sk.dist) {   // the piece that ends its tile: the others' pieces were parked long ago (they run first)
             sk_finish_owner(sk, NT, NT_tile, wave, lane, smem, acc, y, M, N, m0, n0);
             return;
         }
@@ -828,6 +915,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
     }
 
     sk.owner = 0;
+    sk.dist = 0;
     sk.pend_j = -1;
     sk.pend_n = 0;
     const bool has_dp = bid < dp_grid;
@@ -894,6 +982,8 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             sk.j = j;
             sk.first = pos == b0;
             sk.owner = end - pos != NT && end == (j + 1) * NT;
+            int uf_;
+            sk.dist = end - pos != NT && sk_contributors(sk, j, NT, uf_) >= SK_DIST_MIN;
             tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
             MXQ_LANE_ID(ln);
             if (!pre) xdma_setup(cur, x, M, K, tm * BM, pos - j * NT, wave, ln);
@@ -907,6 +997,18 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             MXQ_LANE_ID(ln);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             sk_bump_pending(sk, wave, ln);
+        }
+        // tiles with many contributors are reduced by all of them, after every piece of this unit is parked and counted
+        // (ascending: the tile this unit ENDS first -- its other contributors parked long ago)
+        for (int j = j_lo; j <= j_hi; ++j) {
+            int pos, end, uf_, tm, tn;
+            piece(j, pos, end);
+            if (end - pos == NT) continue;
+            const int C = sk_contributors(sk, j, NT, uf_);
+            if (C < SK_DIST_MIN) continue;
+            tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
+            MXQ_LANE_ID(ln);
+            sk_reduce_distributed(sk, j, C, uf_, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
         }
     } else if constexpr (LAYOUT == LAYOUT_DENSE16) {
         if (has_dp) {
@@ -1018,7 +1120,7 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     const int cus = cu_count() / 8 * 8;
     int units = cus / 8;
     int dp_tiles = tiles, tail = 0;
-    if (workspace && tiles % cus != 0 && units * 8 * N_MMA * sizeof(int) <= CNT_BYTES &&
+    if (workspace && tiles % cus != 0 && units * 8 * N_MMA <= SK_DONE_OFF && (SK_DONE_OFF + units * 8) * sizeof(int) <= CNT_BYTES &&
         ws_bytes >= CNT_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
         const int t8 = (tiles % cus) / 8;   // tail tiles per XCD (the first tail % 8 XCDs hold one more)
         // Splitting the tail saves the idle share of one tile time, (1 - tail/CUs) * NT K-steps of ~1 us, and costs the
