@@ -384,6 +384,13 @@ __device__ __forceinline__ void mma_prologue_issue(const XDma& xd, char* smem, i
 
 // contributors of tail tile j of this XCD (units whose K range meets it, in unit order): their number, and this unit's
 // place among them (-1: none of its steps)
+// timing-only ablation (WRONG results): every stream-K piece reads its operands from K-step 0 on, i.e. all units of an XCD
+// walk the same K window at the same time -- the upper bound of what K-aligned pieces could share through L2
+#ifdef MXQ_SK_ABL_KOFF0
+#define SK_KOFF(k) 0
+#else
+#define SK_KOFF(k) (k)
+#endif
 constexpr int SK_SPIN_BOUND = 1 << 22;
 #ifndef MXQ_SK_DIST_MIN
 #define MXQ_SK_DIST_MIN 6
@@ -950,7 +957,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             int pos, end, tm, tn;
             piece(j, pos, end);
             tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
-            xdma_setup(nxt, x, M, K, tm * BM, pos - j * NT, wave, ln);
+            xdma_setup(nxt, x, M, K, tm * BM, SK_KOFF(pos - j * NT), wave, ln);
             mma_prologue_issue<ABL>(nxt, smem, wave, end - pos);
         };
         if (has_dp) {
@@ -986,7 +993,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             sk.dist = end - pos != NT && sk_contributors(sk, j, NT, uf_) >= SK_DIST_MIN;
             tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
             MXQ_LANE_ID(ln);
-            if (!pre) xdma_setup(cur, x, M, K, tm * BM, pos - j * NT, wave, ln);
+            if (!pre) xdma_setup(cur, x, M, K, tm * BM, SK_KOFF(pos - j * NT), wave, ln);
             mma_segment<ABL, LAYOUT == LAYOUT_DENSE16>(smem, wave, ln, end - pos, cur, pre, y, M, N, tm * BM, tn * BN, NT, sk, [&] {
                 if (j > j_lo) issue_piece(j - 1);
             });
@@ -1053,7 +1060,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             piece(j, pos, end);
             tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
             n0 = tn * BN;
-            deq_setup<LAYOUT>(d, smem, wave, ln, qweight, N, K, n0, pos - j * NT, end - pos);
+            deq_setup<LAYOUT>(d, smem, wave, ln, qweight, N, K, n0, SK_KOFF(pos - j * NT), end - pos);
         };
         int n0_sk = 0;
         if (has_dp) {
