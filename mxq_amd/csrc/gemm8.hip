@@ -275,23 +275,6 @@ __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, in
     }
 }
 
-__device__ __forceinline__ void store_tile(const f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N, int m0,
-                                           int n0, int wm, int wn, int fr, int fq) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + fr;
-        if (m >= M) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fq * 4;
-            if (n >= N) continue;
-            half4 h = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2],
-                       (_Float16)acc[i][j][3]};
-            *(half4*)(y + (int64_t)m * N + n) = h;
-        }
-    }
-}
-
 // The tile WITHOUT an LDS round trip: a lane's accumulators are 4 channels (8 B as fp16) of W-fragment block i for
 // each of 4 token blocks j; the 4 lanes {fr, fr+16, fr+32, fr+48} hold one token's 64 channels as a 4 x 4 grid of
 // 8-byte cells (block i, quarter fq).  Two butterfly stages of lane swaps (v_permlane32_swap: lanes +-32 <-> blocks
@@ -332,32 +315,6 @@ __device__ __forceinline__ void store_tile_xpose(const f32x4 (&acc)[4][4], uint1
     for (int j = 0; j < 4; ++j) {
         const f32x4 c4[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
         store_block_xpose(c4, y, M, N, m0, n0, wm, wn, j, fr, fq);
-    }
-}
-
-// The tile through LDS (the wave's own 9 KB of the idle x ring) so that it leaves as full 128-B lines, 16 B per
-// lane; only for workgroups that run a single whole tile (a stream-K unit's next segment may already be
-// refilling the ring).
-__device__ __forceinline__ void store_tile_staged(const f32x4 (&acc)[4][4], char* smem, uint16_t* __restrict__ y, int M,
-                                                  int N, int m0, int n0, int wave, int lane) {
-    constexpr int ROW = 144;   // 128 B of channels + 16 B: keeps the b128 reads aligned and spreads the banks
-    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
-    char* st = smem + OFF_A + wave * (64 * ROW);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            half4 h = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2],
-                       (_Float16)acc[i][j][3]};
-            *(half4*)(st + (j * 16 + fr) * ROW + (i * 16 + fq * 4) * 2) = h;
-        }
-    const int n = n0 + wn * 64 + (lane & 7) * 8;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int row = it * 8 + (lane >> 3);
-        const u32x4 v = *(const u32x4*)(st + row * ROW + (lane & 7) * 16);
-        const int m = m0 + wm * 64 + row;
-        if (m < M && n < N) *(u32x4*)(y + (int64_t)m * N + n) = v;
     }
 }
 

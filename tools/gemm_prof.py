@@ -8,7 +8,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mxq_amd import packing  # noqa: E402
+from mxq_amd import _lib, packing  # noqa: E402
+
+if os.environ.get("MXQ_PROF_LIB"):      # a variant build of the library (tools/build_variant.sh), for counter runs of an A/B
+    _lib.LIB_PATH = os.path.abspath(os.environ["MXQ_PROF_LIB"])
 
 variant, M, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10
