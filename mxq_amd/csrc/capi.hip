@@ -243,6 +243,15 @@ static const int MIDM_MAX_TOKENS = 256;
 // L2) still beats it: its time grows with tokens x weight size, the split-K kernel's is flat up to 64 tokens.  Measured
 // crossovers (profiles/r03_midM.txt): ~44 tokens at 4096^2, ~22 at 11008 x 4096 and 4096 x 11008.
 static int skinny_max_tokens(int N, int K) { return (int64_t)N * K > ((int64_t)24 << 20) ? 20 : 40; }
+// ... and where the fused kernel's 128-token build (gemm8h.hip: 128 x 128 tiles, stream-K over the idle CUs, ONE launch)
+// beats both neighbours: launches of 64 .. 176 such tiles -- enough of them that a tile is shared by at most 4 CUs, too few
+// for the 256-token tile to fill the chip without splitting every tile 3-4 ways.  Same-process A/B on the Llama shapes
+// (profiles/r04_gemm8h.txt): 128-256 tokens x 11008 x 4096 26.0 / 34.6 / 36.3 us against 30.7 / 46.2 / 47.0 (mid-M kernel);
+// 384 / 512 tokens x 4096^2 27.2 / 29.0 against 34.6 / 35.8 (256-token tile).
+static bool gemm8h_pays(int M, int N, size_t ws_bytes) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    return M > 64 && tiles >= 64 && tiles <= 176 && ws_bytes >= mxq_gemm8h_workspace_bytes();
+}
 
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream) {
@@ -282,6 +291,8 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
     if (M <= skinny_max_tokens(N, K))
         return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
+    if (gemm8h_pays(M, N, workspace_bytes))
+        return mxq_launch_gemm8h_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, 0, (hipStream_t)stream);
     if (M <= MIDM_MAX_TOKENS && midm_ws_ok(M, N, workspace_bytes)) {
         const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
                                           (hipStream_t)stream);
@@ -301,6 +312,9 @@ int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* row
     // every layout: the skinny MFMA kernel up to the token count where the split-K / prefill kernels overtake it
     if (M <= (workspace && layout == MXQ_LAYOUT_MIXEDC ? skinny_max_tokens(N, K) : layout == MXQ_LAYOUT_MIXEDC ? 64 : 48))
         return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
+    if (workspace && gemm8h_pays(M, N, workspace_bytes))
+        return mxq_launch_gemm8h_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes,
+                                            (hipStream_t)stream);
     if (layout == MXQ_LAYOUT_MIXEDC) {
         if (M <= MIDM_MAX_TOKENS && (!workspace || midm_ws_ok(M, N, workspace_bytes))) {
             const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, 0, 0,
@@ -336,6 +350,9 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (variant == 10)   // the mid-M split-K kernel at any token count (tests, tools)
         return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
                                    (hipStream_t)stream);
+    if (variant == 12 || variant == 13)   // the 128-token tile of the fused kernel (13: tail always split)
+        return mxq_launch_gemm8h_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 13,
+                                     (hipStream_t)stream);
     if (variant == 8 || variant == 9)
         return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 9,
                                     (hipStream_t)stream);

@@ -56,8 +56,35 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 256, BN = 128, BK = 64;
-constexpr int N_MMA = 8, N_DEQ = 4, THREADS = (N_MMA + N_DEQ) * 64;
+// The token height of the tile is a build parameter: this file is compiled twice.  gemm8.hip itself: 256 tokens, 8 MFMA
+// waves (2 per SIMD) -- the prefill kernel.  gemm8h.hip (#defines MXQ_G8_BM 128 and includes this file): 128 tokens, 4 MFMA
+// waves (one per SIMD, next to the SIMD's dequant wave) -- twice the conversion work per flop, half the tile: for launches
+// whose 256-token tiles would leave most of the chip to the stream-K fix-up (<= ~1k tokens; profiles/r04_gemm8h.txt).
+// Everything else -- the dequant waves, the 128-channel W tile, the K pipeline, the stream-K protocol -- is the same code.
+#ifndef MXQ_G8_BM
+#define MXQ_G8_BM 256
+#endif
+#if MXQ_G8_BM == 256
+#define G8_NAME(stem) mxq_##stem##gemm8
+#else
+#define G8_NAME(stem) mxq_##stem##gemm8h
+#endif
+#define G8_CAT_(a, b) a##b
+#define G8_CAT(a, b) G8_CAT_(a, b)
+#define G8_SYM(stem, suffix) G8_CAT(G8_NAME(stem), suffix)
+#define G8_KERNEL G8_SYM(, _f16_kernel)
+constexpr int BM = MXQ_G8_BM, BN = 128, BK = 64;
+static_assert(BM == 256 || BM == 128, "tile height");
+// Dequant waves: a thread converts one PART of one row of the 128 x 64 weight tile per K-step.  256-token tile: 4 waves,
+// parts = column halves (32 weights).  128-token tile: the MFMA side of a K-step is half as long, and the MFMA waves were
+// found waiting ~30 % of it for the conversion (tools/gemm_stamps.py --half: 1261 cycles per step, 922 with the conversion
+// switched off) -- so there the tile is converted by 8 waves, parts = 16-column quarters (3 waves per SIMD, as gemm8).
+#ifndef MXQ_G8_NDEQ
+#define MXQ_G8_NDEQ (MXQ_G8_BM == 256 ? 4 : 8)
+#endif
+constexpr int N_MMA = BM / 32, N_DEQ = MXQ_G8_NDEQ, THREADS = (N_MMA + N_DEQ) * 64;
+constexpr int DEQ_PARTS = N_DEQ / 2;          // 2 (halves) or 4 (quarters)
+constexpr int DEQ_NRES = 8 / DEQ_PARTS;       // 16-byte W16 slots a thread writes per chunk
 constexpr int A_STAGE = BM * BK * 2, A_SLOTS = 3;
 constexpr int W_STAGE = BN * BK * 2;
 constexpr int OFF_A = 0;
@@ -82,6 +109,10 @@ constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K
 // slot keep an earlier step's x); 8192 = a burst converts only the first of its 3 chunks (the other two W16 writes carry
 // the previous burst's weights)
 [[maybe_unused]] constexpr int ABL_HALF_XDMA = 512, ABL_THIRD_DEQ = 8192;
+// stream-K diagnostics (profiling builds, correct results): 16384 = wall-clock stamps of the fix-up phases (100 MHz
+// s_memrealtime, MFMA wave 0 of every workgroup -> 8 u64 per workgroup at byte 32768 of the workspace head);
+// 32768 = the all-contributors reduction from 3 contributors per tile on (product: SK_DIST_MIN)
+[[maybe_unused]] constexpr int EXP_SKSTAMPS = 16384, EXP_SK_DIST3 = 32768;
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
@@ -221,6 +252,22 @@ __device__ __forceinline__ u64t stamp() {
 __device__ __forceinline__ u64t stamp() { return 0; }
 #define MXQ_STAMPS(ABL) false      /* the product build carries no stamp code */
 #endif
+#ifdef MXQ_PROFILING
+#define MXQ_SKSTAMPS(ABL) (((ABL) & EXP_SKSTAMPS) != 0)
+#else
+#define MXQ_SKSTAMPS(ABL) false
+#endif
+// phase stamp i of this workgroup (wave 0, lane 0 only; overwritten by later pieces: the LAST piece's phases remain)
+template <int ABL>
+__device__ __forceinline__ void sk_stamp(int* cnt, int wave, int lane, int i) {
+    if constexpr (MXQ_SKSTAMPS(ABL)) {
+        u64t t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave == 0 && lane == 0 && cnt) ((u64t*)((char*)cnt + 32768))[(int64_t)blockIdx.x * 8 + i] = t;
+    }
+}
 
 // One K-step t >= 1: MFMAs of (t-1, kk=1) and (t, kk=0), fragment reads of step t, and -- ISSUE -- the x DMAs of
 // step t+2 (slot (t+2) % 3 was last read in step t-1), spread behind groups of MFMAs.
@@ -377,6 +424,7 @@ __device__ __forceinline__ int sk_contributors(const SkSeg& sk, int j, int NT_ti
 // their slots one round trip after the other -- 7 of them at 640 tokens x 11008 (258 tiles: 2 tail tiles over 8 units
 // each): 84.9 us against 65 of K-steps.  Any contributor may have to wait for any other here: every workgroup of the launch
 // is resident (grid <= CUs, one per CU) and the spin is bounded.
+template <int ABL>
 __device__ __forceinline__ void sk_reduce_distributed(const SkSeg& sk, int j, int C, int uf, int NT_tile, int wave, int lane,
                                                       char* smem, uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
     const int lo = j * NT_tile, self = sk.u - uf;
@@ -393,6 +441,7 @@ __device__ __forceinline__ void sk_reduce_distributed(const SkSeg& sk, int j, in
             __builtin_amdgcn_s_sleep(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler ordering only: the slot loads are sc1
+        sk_stamp<ABL>(sk.cnt, wave, lane, 4);
         f32x4 c4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         int staged = 0;
         auto flush = [&]() {                                     // (sums start from +0: unit order, fixed)
@@ -416,6 +465,7 @@ __device__ __forceinline__ void sk_reduce_distributed(const SkSeg& sk, int j, in
         if (staged) flush();
         store_block_xpose(c4, y, M, N, m0, n0, ws >> 1, ws & 1, jj, lane & 15, lane >> 4);
     }
+    sk_stamp<ABL>(sk.cnt, wave, lane, 5);
     // this wave is through with the tile; the last of the contributors' 8 C waves re-zeroes its counters for the next launch
     if (lane == 0) {
         int* done = sk.cnt + SK_DONE_OFF + j * 8 + sk.e;
@@ -439,11 +489,13 @@ __device__ __forceinline__ void sk_bump_pending(SkSeg& sk, int wave, int lane) {
 // The owner of tile sk.j (the unit whose piece holds the tile's last K-step; `own` steps, accumulators in registers): wait
 // until the wave's counter shows the other NT_tile - own steps, add the contributors' slots in unit order, write y and
 // re-zero the counter.  Contributors are units with a lower index; their piece of this tile is the FIRST thing they run.
+template <int ABL>
 __device__ __forceinline__ void sk_finish_owner(const SkSeg& sk, int own, int NT_tile, int wave, int lane, char* smem,
                                                 f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
     const int j = sk.j, lo = j * NT_tile;
     int* c = sk.cnt + (j * 8 + sk.e) * N_MMA + wave;
     const int need = NT_tile - own;
+    sk_stamp<ABL>(sk.cnt, wave, lane, 7);   // (marks the workgroup as an owner)
     for (int spin = 0; spin < SK_SPIN_BOUND; ++spin) {
         int v = 0;
         if (lane == 0) v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -451,6 +503,7 @@ __device__ __forceinline__ void sk_finish_owner(const SkSeg& sk, int own, int NT
         __builtin_amdgcn_s_sleep(4);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler ordering only: the slot loads are agent-scope themselves
+    sk_stamp<ABL>(sk.cnt, wave, lane, 2);
     int uf;
     sk_contributors(sk, j, NT_tile, uf);
     // A contributor's slot comes through LDS, not through registers: 16 LDS-DMA pieces (sc1: the bytes were written by
@@ -474,6 +527,7 @@ __device__ __forceinline__ void sk_finish_owner(const SkSeg& sk, int own, int NT
             for (int jj = 0; jj < 4; ++jj) acc[i][jj] = acc[i][jj] + *(const f32x4*)(stage + (i * 4 + jj) * 1024 + lane * 16);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next slot's DMA overwrites the stage
     }
+    sk_stamp<ABL>(sk.cnt, wave, lane, 3);
     if (lane == 0)   // ready for the next launch
         __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     store_tile_xpose(acc, y, M, N, m0, n0, wave >> 1, wave & 1, lane & 15, lane >> 4);
@@ -542,8 +596,9 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
 
     if (NT != NT_tile) {
+        sk_stamp<ABL>(sk.cnt, wave, lane, 1);
         if (sk.owner && !sk.dist) {   // the piece that ends its tile: the others' pieces were parked long ago (they run first)
-            sk_finish_owner(sk, NT, NT_tile, wave, lane, smem, acc, y, M, N, m0, n0);
+            sk_finish_owner<ABL>(sk, NT, NT_tile, wave, lane, smem, acc, y, M, N, m0, n0);
             return;
         }
         // a piece that starts its tile: park the accumulators in this unit's slot; the count moves once the stores retired
@@ -554,6 +609,7 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
             for (int j = 0; j < 4; ++j) st_agent(mine, i * 4 + j, lane, acc[i][j]);
         sk.pend_j = sk.j;
         sk.pend_n = NT;
+        sk_stamp<ABL>(sk.cnt, wave, lane, 2);
         return;
     }
     if constexpr (!(ABL & ABL_NO_STORE)) {
@@ -611,7 +667,7 @@ struct PkOf<MXQ_LAYOUT_W4ROW> { typedef Pk4 type; };
 // first had them copied into a 4-slot LDS ring by LDS-DMA and read back from there: the two DMA pieces per wave and
 // step cost their issuer 100-185 cycles apiece next to MFMAs, on the one wave per SIMD whose ~90-op chain is the
 // critical path of a K-step (-2..4 % per launch without them; bit-identical results).
-template <int LAYOUT, int H, bool NOQ4 = false>
+template <int LAYOUT, int H, bool NOQ4 = false, int PARTS = DEQ_PARTS>   // (PARTS a parameter: the other mode's branches are not instantiated)
 __device__ __forceinline__ void load_pk(const Deq& c, int t, typename PkOf<LAYOUT>::type& k) {
     constexpr int BYTES = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : LAYOUT == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
     // wave-uniform by construction; said explicitly, or a K offset selected between two tiles' descriptors counts as
@@ -620,8 +676,29 @@ __device__ __forceinline__ void load_pk(const Deq& c, int t, typename PkOf<LAYOU
     auto dw = [&](int idx) { return __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, c.voff_blk + (uint32_t)idx * 4u, so, 0); };
     auto hw = [&](int idx) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(c.rsrc, c.voff_blk + (uint32_t)idx * 2u, so, 0); };
     if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
+        if constexpr (PARTS == 4) {
+            k.c[0] = dw(mxq_w4_c4(H, 0, c.r));
+            k.c[1] = dw(mxq_w4_c4(H, 1, c.r));
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) k.c[i] = dw(mxq_w4_c4(H * 2 + (i >> 1), i & 1, c.r));
+            for (int i = 0; i < 4; ++i) k.c[i] = dw(mxq_w4_c4(H * 2 + (i >> 1), i & 1, c.r));
+        }
+    } else if constexpr (PARTS == 4) {
+        // quarter H: 2-bit group H (mixed: H < 3; W2G16: any H), or the 4-bit quarter (mixed, H = 3)
+        constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC, COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
+        if constexpr (MIXED && H == 3) {
+            if constexpr (!NOQ4) {
+                k.c[2] = dw(mxq_c4(0, c.r));
+                k.c[3] = dw(mxq_c4(1, c.r));
+            }
+        } else {
+            constexpr int QQ0 = COMPACT ? MXQC_OFF_QQ : MXQ_OFF_QQ;
+            k.scw = hw(COMPACT ? mxqc_sc_u16(c.r) : mxq_sc_u16(c.r));
+            k.c[0] = dw((MIXED ? mxq_c2(0, c.r) : mxq_w2_c2(0, c.r)) + H * 16);
+            if constexpr (COMPACT) k.z[0] = hw(mxqc_z2_u16(0, c.r) + H * 16);
+            else k.z[0] = dw((MIXED ? mxq_z2(0, c.r) : mxq_w2_z2(0, c.r)) + H * 16);
+            k.qq[0] = (f32x2){__uint_as_float(dw(QQ0 + H * 2)), __uint_as_float(dw(QQ0 + H * 2 + 1))};
+        }
     } else {
     constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC, COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
     k.scw = hw(COMPACT ? mxqc_sc_u16(c.r) : mxq_sc_u16(c.r));
@@ -655,10 +732,25 @@ __device__ __forceinline__ void widen_pk(typename PkOf<LAYOUT>::type& k) {   // 
 
 // chunk t: preloaded packed words -> fp16 W16[t & 1]
 // chunk's packed words -> the thread's 32 fp16 weights (4 x 16 bytes: W16 slots s0 .. s0+3 of its row)
-template <int LAYOUT, int H, bool NOQ4 = false>
-__device__ __forceinline__ void convert_pk(const Deq& c, const typename PkOf<LAYOUT>::type& k, u32x4 (&res)[4]) {
+template <int LAYOUT, int H, bool NOQ4 = false, int PARTS = DEQ_PARTS>
+__device__ __forceinline__ void convert_pk(const Deq& c, const typename PkOf<LAYOUT>::type& k, u32x4 (&res)[8 / PARTS]) {
     uint32_t o[8];
-    if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
+    if constexpr (PARTS == 4) {
+        constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC;
+        if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
+            mxq_deq4x8(k.c[0], c.s4, c.z4, o);
+            mxq_deq4x8(k.c[1], c.s4, c.z4, o + 4);
+        } else if constexpr (MIXED && H == 3) {
+            if constexpr (!NOQ4) {
+                mxq_deq4x8(k.c[2], c.s4, c.z4, o);
+                mxq_deq4x8(k.c[3], c.s4, c.z4, o + 4);
+            }
+        } else {
+            mxq_deq2x16(k.c[0], mxq_scale(k.qq[0][0], k.qq[0][1], (k.scw >> (4 * H)) & 15u), __uint_as_float(k.z[0]), o);
+        }
+        res[0] = (u32x4){o[0], o[1], o[2], o[3]};
+        res[1] = (u32x4){o[4], o[5], o[6], o[7]};
+    } else if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             mxq_deq4x8(k.c[2 * q], c.s4, c.z4, o);
@@ -683,10 +775,10 @@ __device__ __forceinline__ void convert_pk(const Deq& c, const typename PkOf<LAY
 }
 // ... into W16[t & 1]: the thread's column half H = slots 4 H .. 4 H + 3
 template <int H>
-__device__ __forceinline__ void store_pk(const Deq& c, int t, const u32x4 (&res)[4]) {
+__device__ __forceinline__ void store_pk(const Deq& c, int t, const u32x4 (&res)[DEQ_NRES]) {
     char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(wt + swz(c.row, H * 4 + i)) = res[i];
+    for (int i = 0; i < DEQ_NRES; ++i) *(u32x4*)(wt + swz(c.row, H * DEQ_NRES + i)) = res[i];
 }
 
 template <int LAYOUT>
@@ -701,9 +793,9 @@ __device__ __forceinline__ void deq_setup(Deq& c, char* smem, int wave, int lane
     const uint32_t blk_stride = (uint32_t)NT_tile * BLK_B;   // bytes between consecutive row-blocks
     c.rsrc = make_rsrc(qweight, (uint32_t)(N >> 4) * blk_stride);
     c.k0 = (uint32_t)kt0 * BLK_B;
-    const int dt = c.d * 64 + lane;   // 0..255
+    const int dt = c.d * 64 + lane;   // 0 .. 64 N_DEQ - 1
     c.row = dt & 127;
-    c.h = __builtin_amdgcn_readfirstlane(dt >> 7);   // wave-uniform: dequant waves 0,1 -> 0; 2,3 -> 1
+    c.h = __builtin_amdgcn_readfirstlane(dt >> 7);   // wave-uniform part: dequant waves 0,1 -> 0; 2,3 -> 1; (4,5 -> 2; 6,7 -> 3)
     c.r = c.row & 15;
     c.voff_blk = (uint32_t)((n0 >> 4) + (c.row >> 4)) * blk_stride;
 }
@@ -726,7 +818,7 @@ template <int ABL, int LAYOUT, int H, int R>
 __device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const float4* __restrict__ rowmeta, int N, int n0,
                                               bool pre, typename PkOf<LAYOUT>::type (&S)[R]) {
     const int NT = c.NT;
-    u32x4 res[R][4];
+    u32x4 res[R][DEQ_NRES];
     auto load_group = [&](int base) {          // chunks base .. base+R-1 of this segment, or group 0 of nxt past its end
         if constexpr (ABL & ABL_NO_DEQ) return;
         const bool over = base >= NT;
@@ -751,7 +843,7 @@ __device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const floa
         }
         load_group(base + R);
     };
-    auto put = [&](int q, const u32x4 (&r4)[4]) {   // chunk q -> W16[q & 1], then the step's barrier
+    auto put = [&](int q, const u32x4 (&r4)[DEQ_NRES]) {   // chunk q -> W16[q & 1], then the step's barrier
         if constexpr (!(ABL & ABL_NO_DEQ)) store_pk<H>(c, q, r4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -779,12 +871,22 @@ __device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const floa
 }
 
 // the column half a dequant wave works on is wave-uniform but not a constant: dispatch once, outside the loops
-constexpr int DEQ_R = 3;    // measured: R = 2 -5 %, 3 and 4 +2 % over per-step dequant; R = 4 spills at the 168-VGPR cap
+#ifndef MXQ_DEQ_R
+#define MXQ_DEQ_R (MXQ_G8_BM == 256 ? 3 : 1)
+#endif
+constexpr int DEQ_R = MXQ_DEQ_R;    // measured: R = 2 -5 %, 3 and 4 +2 % over per-step dequant; R = 4 spills at the 168-VGPR cap
 template <int ABL, int LAYOUT>
 __device__ __forceinline__ void deq_segment(Deq& c, const Deq& nxt, int wave, int lane, const float4* __restrict__ rowmeta,
                                             int N, int n0, bool pre, typename PkOf<LAYOUT>::type (&S)[DEQ_R]) {
-    if (c.h == 0) deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
-    else deq_segment_h<ABL, LAYOUT, 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+    if constexpr (DEQ_PARTS == 4) {
+        if (c.h == 0) deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+        else if (c.h == 1) deq_segment_h<ABL, LAYOUT, 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+        else if (c.h == 2) deq_segment_h<ABL, LAYOUT, 2, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+        else deq_segment_h<ABL, LAYOUT, DEQ_PARTS - 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+    } else {
+        if (c.h == 0) deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+        else deq_segment_h<ABL, LAYOUT, 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -852,7 +954,7 @@ __device__ __forceinline__ void wdma_segment(const WDma& w, char* smem, bool pre
 // workgroup's tiles keep its XCD's label) and overlap one tile's output with the next one's first DMAs; the first
 // 8 * units then run, as stream-K units, their shares of the `tail` tiles beyond them.
 template <int ABL, int LAYOUT>
-__global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* __restrict__ x,
+__global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict__ x,
                                                                const uint32_t* __restrict__ qweight,
                                                                const float4* __restrict__ rowmeta,
                                                                uint16_t* __restrict__ y, int M, int N, int K,
@@ -878,6 +980,8 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
         if constexpr (!(ABL & (EXP_NO_PRIO | EXP_MMA_PRIO))) __builtin_amdgcn_s_setprio(3);
     }
 
+    constexpr int DIST_MIN = (ABL & EXP_SK_DIST3) ? 3 : SK_DIST_MIN;
+    if (wave < N_MMA) sk_stamp<ABL>(cnt, wave, (int)(threadIdx.x & 63), 0);
     sk.owner = 0;
     sk.dist = 0;
     sk.pend_j = -1;
@@ -947,7 +1051,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             sk.first = pos == b0;
             sk.owner = end - pos != NT && end == (j + 1) * NT;
             int uf_;
-            sk.dist = end - pos != NT && sk_contributors(sk, j, NT, uf_) >= SK_DIST_MIN;
+            sk.dist = end - pos != NT && sk_contributors(sk, j, NT, uf_) >= DIST_MIN;
             tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
             MXQ_LANE_ID(ln);
             if (!pre) xdma_setup(cur, x, M, K, tm * BM, SK_KOFF(pos - j * NT), wave, ln);
@@ -961,6 +1065,7 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             MXQ_LANE_ID(ln);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             sk_bump_pending(sk, wave, ln);
+            sk_stamp<ABL>(cnt, wave, ln, 3);
         }
         // tiles with many contributors are reduced by all of them, after every piece of this unit is parked and counted
         // (ascending: the tile this unit ENDS first -- its other contributors parked long ago)
@@ -969,10 +1074,15 @@ __global__ __launch_bounds__(THREADS) void mxq_gemm8_f16_kernel(const uint16_t* 
             piece(j, pos, end);
             if (end - pos == NT) continue;
             const int C = sk_contributors(sk, j, NT, uf_);
-            if (C < SK_DIST_MIN) continue;
+            if (C < DIST_MIN) continue;
             tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
             MXQ_LANE_ID(ln);
-            sk_reduce_distributed(sk, j, C, uf_, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
+            sk_reduce_distributed<ABL>(sk, j, C, uf_, NT, wave, ln, smem, y, M, N, tm * BM, tn * BN);
+        }
+        if constexpr (MXQ_SKSTAMPS(ABL)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MXQ_LANE_ID(ln);
+            sk_stamp<ABL>(cnt, wave, ln, 6);
         }
     } else if constexpr (LAYOUT == LAYOUT_DENSE16) {
         if (has_dp) {
@@ -1076,7 +1186,7 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     // 32-bit offsets: 256 rows of x per DMA descriptor; the whole packed weight behind one (offsets < 2^31)
     if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(N / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 31))
         return -1;   // MXQ_E_SHAPE
-    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm8_f16_kernel<ABL, LAYOUT>,
+    hipError_t e = hipFuncSetAttribute((const void*)G8_KERNEL<ABL, LAYOUT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
@@ -1115,7 +1225,7 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     // workgroup 8u + e runs its whole tiles and then, as unit u of XCD e, its share of the tail: never more than one
     // workgroup per CU, all of them resident (an owner may wait for lower-numbered units: header)
     const int grid = tail && 8 * units > dp_grid ? 8 * units : dp_grid;
-    mxq_gemm8_f16_kernel<ABL, LAYOUT><<<grid, THREADS, SMEM_BYTES, stream>>>(
+    G8_KERNEL<ABL, LAYOUT><<<grid, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
         dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace);
     return (int)hipGetLastError();
@@ -1123,14 +1233,14 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
 
 }   // namespace
 
-size_t mxq_gemm8_workspace_bytes() { return CNT_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
+size_t G8_SYM(, _workspace_bytes)() { return CNT_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
 
-int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+int G8_SYM(launch_, _f16)(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                          void* workspace, size_t ws_bytes, int force, hipStream_t stream) {
     return launch8<0>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, force != 0, stream);
 }
 
-int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+int G8_SYM(launch_, _layout_f16)(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream) {
     switch (layout) {
         case MXQ_LAYOUT_MIXED: return launch8<0, MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, false, stream);
@@ -1141,16 +1251,18 @@ int mxq_launch_gemm8_layout_f16(const void* x, const void* qweight, const void* 
     return -1;
 }
 
+#if MXQ_G8_BM == 256   // (the dense mode's four DMA waves belong to the 256-token build)
 // hoisted-dequant mode: w16 = dense fp16 [N, K] weight (the dequant kernel's output); same tiles, no stream-K tail
-int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, hipStream_t stream) {
+int G8_SYM(launch_, _dense_f16)(const void* x, const void* w16, void* y, int M, int N, int K, hipStream_t stream) {
     return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, false, stream);
 }
+#endif
 
 #ifdef MXQ_PROFILING
 // Built only into libmxq_hip_prof.so (make prof; tools/): parts of the kernel removed to time the rest.
 // WRONG RESULTS by construction -- never part of libmxq_hip.so or of include/mxq_hip.h.
 // 1 = no x DMAs, 2 = no MFMA, 4 = no dequant, 256 = no output stores (sums)
-extern "C" int mxq_prof_gemm8_ablate_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+extern "C" int G8_SYM(prof_, _ablate_f16)(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
                                          int K, int abl, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     switch (abl) {
@@ -1180,26 +1292,28 @@ extern "C" int mxq_prof_gemm8_ablate_f16(const void* x, const void* qweight, con
     return -1;   // MXQ_E_SHAPE: not an ablation this build carries
 }
 
+#if MXQ_G8_BM == 256
 // the hoisted mode's MFMA kernel alone on an already dequantised fp16 weight (the dense yardstick of tools/ab_gemm.py)
-extern "C" int mxq_prof_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, void* stream_) {
+extern "C" int G8_SYM(prof_, _dense_f16)(const void* x, const void* w16, void* y, int M, int N, int K, void* stream_) {
     return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, false, (hipStream_t)stream_);
 }
+#endif
 
 // Diagnostic build with cycle stamps (cdna guide section 7, "In-kernel stamps"): dbg receives, per workgroup and wave,
 // {work, wait, barrier, steps} cycle sums over the steady-state K-steps (u64 x 4 x 12 waves x grid).  Never timed.
 template <int ABL>
 static int launch8_stamps(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                           void* dbg, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)mxq_gemm8_f16_kernel<ABL, MXQ_LAYOUT_MIXED>,
+    hipError_t e = hipFuncSetAttribute((const void*)G8_KERNEL<ABL, MXQ_LAYOUT_MIXED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    mxq_gemm8_f16_kernel<ABL, MXQ_LAYOUT_MIXED><<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
+    G8_KERNEL<ABL, MXQ_LAYOUT_MIXED><<<tiles_m * tiles_n, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
         tiles_m * tiles_n, tiles_m * tiles_n, 0, 32, (float*)dbg, nullptr);
     return (int)hipGetLastError();
 }
-extern "C" int mxq_prof_gemm8_stamps_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+extern "C" int G8_SYM(prof_, _stamps_f16)(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
                                          int K, int abl, void* dbg, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     switch (abl) {
@@ -1210,5 +1324,13 @@ extern "C" int mxq_prof_gemm8_stamps_f16(const void* x, const void* qweight, con
         case 2: return launch8_stamps<4096 + 2>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
     }
     return -1;
+}
+// stream-K fix-up phases (tools/sk_stamps.py): the product dispatch (force = 0) or the tail always split, with the owner
+// protocol as shipped (dist3 = 0) or the all-contributors reduction from 3 contributors on; correct results
+extern "C" int G8_SYM(prof_, _skstamps_f16)(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+                                           int K, int dist3, void* workspace, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (dist3) return launch8<EXP_SKSTAMPS | EXP_SK_DIST3>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, true, stream);
+    return launch8<EXP_SKSTAMPS>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, true, stream);
 }
 #endif   // MXQ_PROFILING

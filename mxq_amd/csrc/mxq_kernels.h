@@ -31,6 +31,13 @@ int mxq_launch_gemm8_f16(const void* x, const void* qweight, const void* rowmeta
                          hipStream_t stream);   // 256x128 tile: MFMA waves stream x, dedicated waves dequantise; stream-K tail with a workspace (gemm8.hip); force: split even when it does not pay
 int mxq_launch_gemm8_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K,
                                hipStream_t stream);   // hoisted-dequant mode: w16 = dense fp16 [N, K] weight
+// the same kernel with a 128-token tile (gemm8h.hip = gemm8.hip at MXQ_G8_BM 128); the workspace of mxq_gemm8_workspace_bytes
+// serves both
+size_t mxq_gemm8h_workspace_bytes();
+int mxq_launch_gemm8h_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                          void* workspace, size_t ws_bytes, int force, hipStream_t stream);
+int mxq_launch_gemm8h_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
 // internal "take the other kernel" return of a launcher that declines a shape (never leaves capi.hip; distinct from
 // every MXQ_E_* code and every hipError_t)
 #define MXQ_NOT_MY_SHAPE (-1000)

@@ -329,7 +329,7 @@ def linear_dense(x: torch.Tensor, w16: torch.Tensor, out: Optional[torch.Tensor]
     return out.reshape(*x.shape[:-1], N)
 
 
-GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
+GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10, "gemm8h": 12, "gemm8h_split": 13}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
 
 
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
@@ -364,7 +364,8 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         # ONE C call for the whole dispatch (include/mxq_hip.h: mxq_linear_f16_auto): skinny / mid-M split-K / fused
         # prefill kernel with its stream-K tail / hoisted-dequant mode, chosen inside the library by token count
         hoists = M >= HOIST_MIN_TOKENS
-        ws = gemm_workspace(x2.device, counters=M > MIDM_MAX_TOKENS and not hoists)
+        # (counters: any non-hoisted launch beyond the skinny kernel's range may be a stream-K one -- the library decides)
+        ws = gemm_workspace(x2.device, counters=not hoists)
         scratch = hoist_scratch(x2.device, lib.mxq_hoist_scratch_bytes(p.N, p.K)) if hoists else None
         with torch.cuda.device(x.device):
             _lib.check(lib.mxq_linear_f16_auto(*args, _layout_code(p), ws.data_ptr(), ws.numel(),
@@ -396,9 +397,9 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         elif path == "auto" and M <= 4:                          # GEMV: no workspace involved
             rc = lib.mxq_linear_f16(*args, _stream(x2))
         else:
-            midm = path == "midm" or (path == "auto" and M <= MIDM_MAX_TOKENS)
+            midm = path == "midm"
             ws = (gemm_workspace(x2.device, counters=not midm)
-                  if path in ("auto", "gemm", "fused", "gemm8", "gemm9", "midm") else None)
+                  if path in ("auto", "gemm", "fused", "gemm8", "gemm9", "midm", "gemm8h", "gemm8h_split") else None)
             wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
             if path == "auto":
                 rc = lib.mxq_linear_f16_ws(*args, wsp, wsn, _stream(x2))

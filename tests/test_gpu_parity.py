@@ -342,7 +342,7 @@ def test_quantizer_reproduces_fasterquant_loop_g1(dev, g1):
 # ----------------------------------------------------------------------------------------
 # dequant-GEMM / GEMV
 # ----------------------------------------------------------------------------------------
-GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm"]      # packing.GEMM_PATHS: every kernel the product library ships
+GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm", "gemm8h", "gemm8h_split"]      # packing.GEMM_PATHS: every kernel the product library ships
 
 
 def _packed_case(dev, N, K, seed):
@@ -414,7 +414,7 @@ def test_gemm_integer_exact_layout(dev):
                                    (1024, 4224, 2048),    # 132 tiles: XCDs 0-3 hold 17 tail tiles, 4-7 hold 16
                                    (100, 1152, 8192),     # 9 tiles: XCD 0 holds two, the others one; half-empty 256-row tile
                                    (2048, 5120, 1024)])   # 320 tiles = one full round + a 64-tile tail
-@pytest.mark.parametrize("sk", ["gemm9"])
+@pytest.mark.parametrize("sk", ["gemm9", "gemm8h_split"])
 def test_gemm_stream_k_tail(dev, M, N, K, sk):
     """csrc/gemm8.hip: tiles beyond the last full round of CUs are split along K over all CUs and
     reduced through the workspace.  Checks (1) against the oracle matmul, (2) that the workspace
@@ -436,6 +436,10 @@ def test_gemm_stream_k_tail(dev, M, N, K, sk):
     yd = packing.linear(xd, p, path="gemm")
     assert ((y.float() - yd.float()).abs().max() / y5.float().abs().max()).item() <= 1e-3
     assert torch.equal(packing.linear(xd, p, path="gemm8"), yd)
+    if sk == "gemm8h_split":      # the 128-token build of the same kernel, splitting only where it pays
+        yh = packing.linear(xd, p, path="gemm8h")
+        assert ((y.float() - yh.float()).abs().max() / y5.float().abs().max()).item() <= 1e-3
+        assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
 
 
 @pytest.mark.parametrize("M,N,K", [(640, 11008, 4096),     # 258 tiles: a 2-tile tail on 256 CUs (Llama gate/up at 640-768 tokens)
@@ -467,7 +471,7 @@ def test_gemm_small_tail_stream_k_through_the_dispatch(dev, M, N, K):
     assert ((y.float() - yw.float()).abs().max() / yw.float().abs().max()).item() <= REL_TOL
 
 
-@pytest.mark.parametrize("sk", ["gemm9"])
+@pytest.mark.parametrize("sk", ["gemm9", "gemm8h_split"])
 def test_stream_k_partition_fuzz(dev, sk):
     """Random (tokens, out, in) shapes through the forced stream-K schedule against the single-tile kernel:
     exercises unit ranges that start / end anywhere inside tiles, XCDs with unequal tail lengths, units with
@@ -489,6 +493,40 @@ def test_stream_k_partition_fuzz(dev, sk):
         assert torch.equal(packing.linear(x, p, path=sk).float(), y), (M, N, K)
     ws = packing.gemm_workspace(torch.device(dev))
     assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(192, 11008, 4096),     # 2 x 86 = 172 tiles of 128 x 128: Llama gate/up, 129-256 tokens
+                                   (128, 11008, 4096),     # 86 tiles: 3 CUs per tile
+                                   (384, 4096, 4096),      # 96 tiles
+                                   (512, 4096, 11008),     # 128 tiles, 172 K-steps each
+                                   (300, 4224, 2048)])     # 99 tiles, ragged token edge, XCDs hold 13 / 12 tiles
+@pytest.mark.parametrize("layout", ["mixed", "mixedc", "w2g16", "w4row"])
+def test_half_height_tile_through_the_dispatch(dev, M, N, K, layout):
+    """capi.hip gemm8h_pays: launches of 64..176 tiles of 128 x 128 run the fused kernel's 128-token build (gemm8h.hip, one
+    launch, stream-K over the idle CUs) -- every weight layout, through the product dispatch: against the fp32 product on
+    the bit-exact dequantised weight, twice with identical bits, counters left zero; for the mixed layout the dispatch's
+    result IS the explicit path's."""
+    from mxq_amd import packing
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
+    if layout in ("mixed", "mixedc"):
+        p = packing.quantize_pack(W)
+        if layout == "mixedc":
+            p = packing.compact(p)
+    else:
+        p = packing.quantize_pack_uniform(W, layout)
+    x = torch.randn(M, K, generator=g, device=dev).half()
+    wd = packing.dequant(p) if layout in ("mixed", "mixedc") else packing.expand_uniform(p, codes=False)[0]
+    ws = packing.gemm_workspace(torch.device(dev))
+    y = packing.linear_layout(x, p, path="auto")
+    r = x.float() @ wd.float().t()
+    assert ((y.float() - r).abs().max() / r.abs().max()).item() <= REL_TOL
+    assert torch.equal(packing.linear_layout(x, p, path="auto"), y)
+    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
+    if layout == "mixed":
+        assert torch.equal(packing.linear(x, p, path="gemm8h"), y)
+        ym = packing.linear(x, p, path="midm")           # the neighbour it replaced here: equal up to summation order
+        assert ((y.float() - ym.float()).abs().max() / r.abs().max()).item() <= REL_TOL
 
 
 def test_linear_auto_c_entry_takes_the_fastest_path(dev):

@@ -25,9 +25,11 @@ def main():
     ap.add_argument("--lib", default="mxq_amd/libmxq_hip_prof.so")
     ap.add_argument("--launches", type=int, default=200)
     ap.add_argument("--per-wave", action="store_true")
+    ap.add_argument("--half", action="store_true", help="the 128-token tile build of the kernel (gemm8h: 4 MFMA waves)")
     args = ap.parse_args()
     lib = ctypes.CDLL(os.path.join(ROOT, args.lib))
-    fn = lib.mxq_prof_gemm8_stamps_f16
+    fn = lib.mxq_prof_gemm8h_stamps_f16 if args.half else lib.mxq_prof_gemm8_stamps_f16
+    bm, nm = (128, 4) if args.half else (256, 8)
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
     dev = torch.device("cuda:0")
@@ -36,27 +38,27 @@ def main():
     p = packing.quantize_pack((torch.randn(N, K, generator=g, device=dev) * 0.02).half())
     x = torch.randn(M, K, generator=g, device=dev).half()
     y = torch.empty(M, N, device=dev, dtype=torch.float16)
-    grid = ((M + 255) // 256) * ((N + 127) // 128)
+    grid = ((M + bm - 1) // bm) * ((N + 127) // 128)
     for abl in [int(a) for a in args.abl.split(",")]:
-        dbg = torch.zeros(grid * 12 * 4, dtype=torch.int64, device=dev)
+        dbg = torch.zeros(grid * 12 * 4, dtype=torch.int64, device=dev)   # 8 + 4 or 4 + 8 waves
         for _ in range(args.launches):   # sustained load; the last launch's sums are read
             rc = fn(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), y.data_ptr(), M, N, K, abl, dbg.data_ptr(),
                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0, rc
         torch.cuda.synchronize()
         raw = dbg.view(grid, 12, 4).cpu()
-        rt = (raw[:, :8, 3] >> 32).double()                     # 100 MHz ticks over the stamped K-steps
+        rt = (raw[:, :nm, 3] >> 32).double()                     # 100 MHz ticks over the stamped K-steps
         d = raw.double()
         d[:, :, 3] = (raw[:, :, 3] & 0xFFFFFFFF).double()
         steps = d[:, :, 3].clamp(min=1)
         per = d[:, :, :3] / steps[:, :, None]            # cycles per K-step
-        for name, sl in (("MFMA waves 0-7", slice(0, 8)),):
+        for name, sl in ((f"MFMA waves 0-{nm - 1}", slice(0, nm)),):
             w = per[:, sl, :].mean(dim=(0, 1))
             ghz = (d[:, sl, :3].sum(dim=2) / rt.clamp(min=1) / 10.0).mean().item()
             print(f"abl {abl:5d} {name:28s} work {w[0]:7.0f}  wait {w[1]:6.0f}  barrier {w[2]:6.0f}  total {w.sum():7.0f} cycles/step"
                   f"   core clock held {ghz:.2f} GHz", flush=True)
         if args.per_wave:      # the two MFMA waves of a SIMD (w and w + 4) are not served alike: the older one goes first
-            for wv in range(8):
+            for wv in range(nm):
                 w = per[:, wv, :].mean(dim=0)
                 print(f"          MFMA wave {wv} (SIMD {wv % 4})       work {w[0]:7.0f}  wait {w[1]:6.0f}  barrier {w[2]:6.0f}", flush=True)
 
