@@ -31,9 +31,10 @@ def main():
     ap.add_argument("--m", type=int, default=512)
     ap.add_argument("--shapes", default="4096x4096")
     ap.add_argument("--dist3", action="store_true", help="all-contributors reduction from 3 contributors per tile on")
+    ap.add_argument("--half", action="store_true", help="the 128-token build (gemm8h)")
     args = ap.parse_args()
     lib = ctypes.CDLL(os.path.join(ROOT, "mxq_amd/libmxq_hip_prof.so"))
-    fn = lib.mxq_prof_gemm8_skstamps_f16
+    fn = lib.mxq_prof_gemm8h_skstamps_f16 if args.half else lib.mxq_prof_gemm8_skstamps_f16
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     dev = torch.device("cuda:0")
@@ -72,7 +73,7 @@ def main():
         live = s[:, 0] > 0
         s = s[live]
         t0 = s[:, 0].min()
-        print(f"M={M} N={N} K={K} dist3={int(args.dist3)}: {us:.1f} us per launch (stream-ordered, stamps on), "
+        print(f"M={M} N={N} K={K} {'128' if args.half else '256'}-token tile dist3={int(args.dist3)}: {us:.1f} us per launch (stream-ordered, stamps on), "
               f"{int(live.sum())} workgroups, max rel err {err:.1e}")
         split = s[:, 1] > 0
         print(f"  workgroups with a split piece: {int(split.sum())}; kernel start spread {pct(s[:, 0] - t0, 50):.2f} / "
