@@ -243,14 +243,25 @@ static const int MIDM_MAX_TOKENS = 256;
 // L2) still beats it: its time grows with tokens x weight size, the split-K kernel's is flat up to 64 tokens.  Measured
 // crossovers (profiles/r03_midM.txt): ~44 tokens at 4096^2, ~22 at 11008 x 4096 and 4096 x 11008.
 static int skinny_max_tokens(int N, int K) { return (int64_t)N * K > ((int64_t)24 << 20) ? 20 : 40; }
-// ... and where the fused kernel's 128-token build (gemm8h.hip: 128 x 128 tiles, stream-K over the idle CUs, ONE launch)
-// beats both neighbours: launches of 64 .. 176 such tiles -- enough of them that a tile is shared by at most 4 CUs, too few
-// for the 256-token tile to fill the chip without splitting every tile 3-4 ways.  Same-process A/B on the Llama shapes
-// (profiles/r04_gemm8h.txt): 128-256 tokens x 11008 x 4096 26.0 / 34.6 / 36.3 us against 30.7 / 46.2 / 47.0 (mid-M kernel);
-// 384 / 512 tokens x 4096^2 27.2 / 29.0 against 34.6 / 35.8 (256-token tile).
-static bool gemm8h_pays(int M, int N, size_t ws_bytes) {
+// ... and where the fused kernel's 128-token build (gemm8h.hip: 128 x 128 tiles) beats both neighbours, beyond 64 tokens:
+//   * launches of <= 64 such tiles (a tile would be shared by >= 4 CUs): SLICES mode -- K cut into one slice per idle CU,
+//     fp32 slabs through the workspace, a combine launch: the mid-M kernel's schedule with the fused kernel's wave roles.
+//     128 tokens x 4096^2 19.3 us (mid-M kernel 21.1, hipBLASLt fp16 19.5), 256 tokens 22.4 (26.6), 4096 x 11008 at
+//     128 / 256 tokens 23.8 / 34.8 (25.5 / 40.7);
+//   * launches of 65 .. 176 tiles: ONE launch, stream-K over the otherwise idle CUs (at most 4 CUs per tile): gate/up
+//     (11008 x 4096) at 128 / 192 / 256 tokens 25.2 / 33.4 / 34.8 us against 30.7 / 46.2 / 47.2 (mid-M kernel); 4096^2 at
+//     384 / 512 tokens 26.2 / 28.8 against 34.9 / 35.7 (256-token tile).
+// Same-process A/B on the Llama shapes: profiles/r04_gemm8h.txt.  Returns 0 (neither), 1 (stream-K), 2 (slices).
+static int gemm8h_mode(int M, int N, size_t ws_bytes) {
+    if (M <= 64 || ws_bytes < mxq_gemm8h_workspace_bytes()) return 0;
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    return M > 64 && tiles >= 64 && tiles <= 176 && ws_bytes >= mxq_gemm8h_workspace_bytes();
+    return tiles <= 64 ? 2 : tiles <= 176 ? 1 : 0;
+}
+static int gemm8h_launch(int mode, const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                         int layout, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (mode == 2)
+        return mxq_launch_gemm8h_slices_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, 0, stream);
+    return mxq_launch_gemm8h_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, stream);
 }
 
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -291,8 +302,9 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
     if (M <= skinny_max_tokens(N, K))
         return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
-    if (gemm8h_pays(M, N, workspace_bytes))
-        return mxq_launch_gemm8h_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, 0, (hipStream_t)stream);
+    if (const int mode = gemm8h_mode(M, N, workspace_bytes))
+        return gemm8h_launch(mode, x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes,
+                             (hipStream_t)stream);
     if (M <= MIDM_MAX_TOKENS && midm_ws_ok(M, N, workspace_bytes)) {
         const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
                                           (hipStream_t)stream);
@@ -312,9 +324,8 @@ int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* row
     // every layout: the skinny MFMA kernel up to the token count where the split-K / prefill kernels overtake it
     if (M <= (workspace && layout == MXQ_LAYOUT_MIXEDC ? skinny_max_tokens(N, K) : layout == MXQ_LAYOUT_MIXEDC ? 64 : 48))
         return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
-    if (workspace && gemm8h_pays(M, N, workspace_bytes))
-        return mxq_launch_gemm8h_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes,
-                                            (hipStream_t)stream);
+    if (const int mode = workspace ? gemm8h_mode(M, N, workspace_bytes) : 0)
+        return gemm8h_launch(mode, x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, (hipStream_t)stream);
     if (layout == MXQ_LAYOUT_MIXEDC) {
         if (M <= MIDM_MAX_TOKENS && (!workspace || midm_ws_ok(M, N, workspace_bytes))) {
             const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, 0, 0,
@@ -350,6 +361,9 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (variant == 10)   // the mid-M split-K kernel at any token count (tests, tools)
         return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
                                    (hipStream_t)stream);
+    if (variant == 14)   // ... in slices mode (K cut into one slice per idle CU, combine launch)
+        return mxq_launch_gemm8h_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0,
+                                            (hipStream_t)stream);
     if (variant == 12 || variant == 13)   // the 128-token tile of the fused kernel (13: tail always split)
         return mxq_launch_gemm8h_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 13,
                                      (hipStream_t)stream);

@@ -160,6 +160,7 @@ struct SkSeg {
     int owner;        // 1: a partial segment that ENDS its tile: finish the tile here (sk_finish_owner) ...
     int dist;         // ... unless the tile has >= SK_DIST_MIN contributors: then every piece is parked (sk_reduce_distributed)
     int pend_j, pend_n;   // a parked piece whose counter bump is due as soon as its stores have retired (-1: none)
+    float* park;      // slices mode (below): this workgroup's slab -- every piece is parked there, nothing is counted
 };
 // A wave's 16 KB slot, 16 bytes per lane and fragment: ONE sc1 (write-through / L1-bypassing) 16-byte access per fragment,
 // 1 KB contiguous per instruction.  (Round 2 began with two 8-byte agent-scope atomics per fragment: 8-byte accesses run at
@@ -602,12 +603,12 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
             return;
         }
         // a piece that starts its tile: park the accumulators in this unit's slot; the count moves once the stores retired
-        float* mine = sk.ws + ((int64_t)((sk.u * 8 + sk.e) * 2 + (sk.first ? 0 : 1)) * (BM * BN)) + wave * 4096;
+        float* mine = (sk.park ? sk.park : sk.ws + (int64_t)((sk.u * 8 + sk.e) * 2 + (sk.first ? 0 : 1)) * (BM * BN)) + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) st_agent(mine, i * 4 + j, lane, acc[i][j]);
-        sk.pend_j = sk.j;
+        sk.pend_j = sk.park ? -1 : sk.j;
         sk.pend_n = NT;
         sk_stamp<ABL>(sk.cnt, wave, lane, 2);
         return;
@@ -987,11 +988,23 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
     sk.dist = 0;
     sk.pend_j = -1;
     sk.pend_n = 0;
-    const bool has_dp = bid < dp_grid;
-    const bool has_sk = tail > 0 && bid < 8 * units;
+    // ---- slices mode (tail = -S; launcher: launch8_slices): workgroup b runs slice b % S of tile b / S -- K-steps
+    // [NT s / S, NT (s + 1) / S) -- and parks its fp32 partial tile in slab b of the workspace; a combine launch sums the
+    // slabs in slice order.  No counters, no waiting: for launches so small that every tile is cut 4-8 ways, where the
+    // stream-K fix-up's chain (park -> count -> poll -> read) costs more than a second launch does.
+    const bool slices = tail < 0;
+    const bool has_dp = !slices && bid < dp_grid;
+    const bool has_sk = slices || (tail > 0 && bid < 8 * units);
     // ---- stream-K unit u of XCD e (= this workgroup): K-steps [b0, b1) of that XCD's tail tiles laid end to end
     int b0 = 0, b1 = 0, base = 0;
-    if (has_sk) {
+    sk.park = nullptr;
+    if (slices) {
+        const int SL = -tail, sl = bid % SL;
+        base = bid / SL;
+        b0 = sk_bound(sl, NT, SL);
+        b1 = sk_bound(sl + 1, NT, SL);
+        sk.park = ws + (int64_t)bid * (BM * BN);
+    } else if (has_sk) {
         sk.e = bid & 7;
         sk.u = bid >> 3;
         base = dp_tiles + sk.e;
@@ -1050,9 +1063,9 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
             piece(j, pos, end);
             sk.j = j;
             sk.first = pos == b0;
-            sk.owner = end - pos != NT && end == (j + 1) * NT;
+            sk.owner = !slices && end - pos != NT && end == (j + 1) * NT;
             int uf_;
-            sk.dist = end - pos != NT && sk_contributors(sk, j, NT, uf_) >= DIST_MIN;
+            sk.dist = !slices && end - pos != NT && sk_contributors(sk, j, NT, uf_) >= DIST_MIN;
             tile_of_block(base + j * 8, tiles_m, tiles_n, tm, tn);
             MXQ_LANE_ID(ln);
             if (!pre) xdma_setup(cur, x, M, K, tm * BM, SK_KOFF(pos - j * NT), wave, ln);
@@ -1070,7 +1083,7 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
         }
         // tiles with many contributors are reduced by all of them, after every piece of this unit is parked and counted
         // (ascending: the tile this unit ENDS first -- its other contributors parked long ago)
-        for (int j = j_lo; j <= j_hi; ++j) {
+        for (int j = j_lo; j <= j_hi && !slices; ++j) {
             int pos, end, uf_, tm, tn;
             piece(j, pos, end);
             if (end - pos == NT) continue;
@@ -1165,6 +1178,36 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
     }
 }
 
+// slices mode, second launch: y = the S slabs of every tile summed in slice order (from +0: fixed).  One wave per (tile,
+// producing wave, token block): the slabs' four fragments of up to four slices in flight together, then the fp16 block.
+__global__ __launch_bounds__(64) void G8_SYM(, _combine_kernel)(const float* __restrict__ slab, uint16_t* __restrict__ y, int M,
+                                                                int N, int tiles_m, int tiles_n, int S) {
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x / (N_MMA * 4), rem = blockIdx.x % (N_MMA * 4);
+    const int ws = rem >> 2, jj = rem & 3;
+    int tm, tn;
+    tile_of_block(tile, tiles_m, tiles_n, tm, tn);
+    const float* src = slab + (int64_t)tile * S * (BM * BN) + ws * 4096 + lane * 4;
+    f32x4 c4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int s0 = 0; s0 < S; s0 += 4) {
+        f32x4 v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int sc = s0 + u < S ? s0 + u : S - 1;      // clamped, never branched around
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[u][i] = *(const f32x4*)(src + (int64_t)sc * (BM * BN) + (i * 4 + jj) * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (s0 + u < S) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c4[i] = c4[i] + v[u][i];
+            }
+    }
+    store_block_xpose(c4, y, M, N, tm * BM, tn * BN, ws >> 1, ws & 1, jj, lane & 15, lane >> 4);
+}
+
 int cu_count() {
     static int cus = 0;   // one device model per process on this platform
     if (!cus) {
@@ -1232,7 +1275,42 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     return (int)hipGetLastError();
 }
 
+// slices mode: every tile's K range cut into S equal slices (S <= 0: one workgroup per CU), partial tiles through the
+// workspace beyond its counter head (untouched), a combine launch.  S = 1 (or no room): the ordinary whole-tile launch.
+template <int LAYOUT>
+static int launch8_slices(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                          void* workspace, size_t ws_bytes, int S, hipStream_t stream) {
+    const int NT = K / BK, tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
+    if (S <= 0) S = cu_count() / tiles;
+    if (S > NT / 4) S = NT / 4;                       // at least 4 K-steps per slice
+    const size_t room = workspace && ws_bytes > CNT_BYTES ? (ws_bytes - CNT_BYTES) / ((size_t)tiles * BM * BN * sizeof(float)) : 0;
+    if ((size_t)S > room) S = (int)room;
+    if (S <= 1) return launch8<0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
+    if (M <= 0 || N <= 0 || K < BK || K % BK != 0 || N % 16 != 0) return -1;
+    if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(N / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 31))
+        return -1;
+    hipError_t e = hipFuncSetAttribute((const void*)G8_KERNEL<0, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    float* slab = (float*)((char*)workspace + CNT_BYTES);
+    G8_KERNEL<0, LAYOUT><<<tiles * S, THREADS, SMEM_BYTES, stream>>>(
+        (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n, 0, 0,
+        -S, 0, slab, nullptr);
+    G8_SYM(, _combine_kernel)<<<tiles * N_MMA * 4, 64, 0, stream>>>(slab, (uint16_t*)y, M, N, tiles_m, tiles_n, S);
+    return (int)hipGetLastError();
+}
+
 }   // namespace
+
+int G8_SYM(launch_, _slices_f16)(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                 int layout, void* workspace, size_t ws_bytes, int S, hipStream_t stream) {
+    switch (layout) {
+        case MXQ_LAYOUT_MIXED: return launch8_slices<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, S, stream);
+        case MXQ_LAYOUT_W2G16: return launch8_slices<MXQ_LAYOUT_W2G16>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, S, stream);
+        case MXQ_LAYOUT_W4ROW: return launch8_slices<MXQ_LAYOUT_W4ROW>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, S, stream);
+        case MXQ_LAYOUT_MIXEDC: return launch8_slices<MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, S, stream);
+    }
+    return -1;
+}
 
 size_t G8_SYM(, _workspace_bytes)() { return CNT_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
 

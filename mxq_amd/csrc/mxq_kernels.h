@@ -38,6 +38,10 @@ int mxq_launch_gemm8h_f16(const void* x, const void* qweight, const void* rowmet
                           void* workspace, size_t ws_bytes, int force, hipStream_t stream);
 int mxq_launch_gemm8h_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                  int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
+// ... in slices mode: every tile's K range cut into S equal slices (S <= 0: one workgroup per CU), fp32 partial tiles through
+// the workspace beyond its 64-KiB head (counters untouched), summed in slice order by a combine launch
+int mxq_launch_gemm8h_slices_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                 int layout, void* workspace, size_t ws_bytes, int S, hipStream_t stream);
 // internal "take the other kernel" return of a launcher that declines a shape (never leaves capi.hip; distinct from
 // every MXQ_E_* code and every hipError_t)
 #define MXQ_NOT_MY_SHAPE (-1000)

@@ -342,7 +342,7 @@ def test_quantizer_reproduces_fasterquant_loop_g1(dev, g1):
 # ----------------------------------------------------------------------------------------
 # dequant-GEMM / GEMV
 # ----------------------------------------------------------------------------------------
-GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm", "gemm8h", "gemm8h_split"]      # packing.GEMM_PATHS: every kernel the product library ships
+GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm", "gemm8h", "gemm8h_split", "gemm8h_slices"]      # packing.GEMM_PATHS: every kernel the product library ships
 
 
 def _packed_case(dev, N, K, seed):
@@ -500,15 +500,20 @@ def test_stream_k_partition_fuzz(dev, sk):
                                    (384, 4096, 4096),      # 96 tiles
                                    (512, 4096, 11008),     # 128 tiles, 172 K-steps each
                                    (300, 4224, 2048),      # 99 tiles, ragged token edge, XCDs hold 13 / 12 tiles
-                                   (129, 4096, 1024),      # 64 tiles: the rule's lower edge (128 tokens = 32 tiles stay mid-M)
-                                   (256, 11264, 1024),     # 176 tiles: its upper edge ...
-                                   (256, 11392, 1024)])    # ... and 178: the neighbour (mid-M kernel / 256-token tile) again
+                                   (129, 4096, 1024),      # 64 tiles: the last launch in slices mode ...
+                                   (129, 4224, 1024),      # ... 66: the first in stream-K mode
+                                   (128, 4096, 4096),      # BASELINE configs[0]'s shape: 32 tiles, 8 slices each
+                                   (256, 4096, 11008),     # 64 tiles x 4 slices of 43 K-steps
+                                   (100, 2048, 1024),      # 16 tiles, one ragged; S = 16 clamped to 4 (4 K-steps per slice)
+                                   (65, 1040, 256),        # 9 tiles, ragged both ways, K too short to slice: whole tiles
+                                   (256, 11264, 1024),     # 176 tiles: stream-K mode's upper edge ...
+                                   (256, 11392, 1024)])    # ... and 178: the 256-token tile again
 @pytest.mark.parametrize("layout", ["mixed", "mixedc", "w2g16", "w4row"])
 def test_half_height_tile_through_the_dispatch(dev, M, N, K, layout):
-    """capi.hip gemm8h_pays: launches of 64..176 tiles of 128 x 128 run the fused kernel's 128-token build (gemm8h.hip, one
-    launch, stream-K over the idle CUs) -- every weight layout, through the product dispatch: against the fp32 product on
-    the bit-exact dequantised weight, twice with identical bits, counters left zero; for the mixed layout the dispatch's
-    result IS the explicit path's."""
+    """capi.hip gemm8h_mode: beyond 64 tokens, launches of up to 176 tiles of 128 x 128 run the fused kernel's 128-token
+    build (gemm8h.hip) -- up to 64 tiles in slices mode (K slices + combine launch), 65..176 in one launch with stream-K over
+    the idle CUs -- every weight layout, through the product dispatch: against the fp32 product on the bit-exact dequantised
+    weight, twice with identical bits, counters left zero; for the mixed layout the dispatch's result IS the explicit path's."""
     from mxq_amd import packing
     g = torch.Generator(device=dev).manual_seed(M + N + K)
     W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
@@ -527,8 +532,8 @@ def test_half_height_tile_through_the_dispatch(dev, M, N, K, layout):
     assert torch.equal(packing.linear_layout(x, p, path="auto"), y)
     assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
     tiles = -(-M // 128) * -(-N // 128)
-    if layout == "mixed" and 64 <= tiles <= 176:
-        assert torch.equal(packing.linear(x, p, path="gemm8h"), y)
+    if layout == "mixed" and tiles <= 176:
+        assert torch.equal(packing.linear(x, p, path="gemm8h_slices" if tiles <= 64 else "gemm8h"), y)
         ym = packing.linear(x, p, path="midm")           # the neighbour it replaced here: equal up to summation order
         assert ((y.float() - ym.float()).abs().max() / r.abs().max()).item() <= REL_TOL
 
