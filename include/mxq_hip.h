@@ -107,13 +107,15 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * different workspaces).  workspace == NULL selects the workspace-free schedule of mxq_linear_f16; a workspace too small
  * for the mid-M kernel's partial tiles hands 41..256 tokens to the prefill kernel.
  * The tail is only split where that pays (about 20 idle K-steps per CU: for 256 < M <= 1024 on the Llama shapes and for
- * gate/up at M = 2048).  Launches of 64..176 tiles of 128 x 128 (e.g. gate/up at 128-256 tokens, 4096^2 at 384-640) run the
- * same kernel built with a 128-token tile (csrc/gemm8h.hip): one launch, stream-K over the otherwise idle CUs.
+ * gate/up at M = 2048).  Beyond 64 tokens, launches of up to 176 tiles of 128 x 128 run the same kernel built with a
+ * 128-token tile (csrc/gemm8h.hip): up to 64 tiles (e.g. 4096^2 at 65-256 tokens) with K cut into one slice per idle CU, fp32
+ * slabs in the workspace beyond its first 64 KiB and a combine launch; 65..176 tiles (gate/up at 65-256 tokens, 4096^2 at
+ * 257-640) in one launch, stream-K over the otherwise idle CUs.
  * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 8 = the
  * 256x128-tile kernel (MFMA waves stream x, dedicated waves dequantise, persistent over tiles, stream-K tail;
  * csrc/gemm8.hip) at any M, 9 = the same but splitting its tail whenever that is structurally possible (tests),
  * 10 = the mid-M split-K kernel (csrc/midm.hip) at any M, 12 / 13 = the fused kernel's 128-token build (csrc/gemm8h.hip)
- * at any M, splitting its tail where that pays / whenever possible;
+ * at any M, splitting its tail where that pays / whenever possible, 14 = the same in slices mode (K slices + combine launch);
  * anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
  * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
  * used by tools/ alone: they are not part of this ABI.) */
@@ -125,8 +127,8 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
 /* mxq_linear_f16_ws for a weight in any layout (MXQ_LAYOUT_*: mixed with exact or compact metadata, W2G16, W4ROW).
  * Dispatch by token count: <= 4 the streaming GEMV, then the skinny MFMA kernel (mixed layouts: up to 40 tokens, 20 for
  * weights of more than 24 M elements, where its time has overtaken the split-K kernel's; uniform layouts: up to 48, where
- * the prefill kernel takes over), launches of 64..176 tiles of 128 x 128 the fused kernel's 128-token build (every layout),
- * and otherwise up to 256 tokens the mid-M split-K
+ * the prefill kernel takes over), beyond 64 tokens launches of up to 176 tiles of 128 x 128 the fused kernel's 128-token
+ * build (every layout; slices mode up to 64 tiles, stream-K mode beyond), and otherwise up to 256 tokens the mid-M split-K
  * kernel (csrc/midm.hip: K cut into slices over the workgroups, fp32 partial tiles in the workspace beyond its first
  * 64 KiB, summed in slice order by a second launch -- the reference launcher's split_k_iters regime,
  * gemm_cuda_gen.cu:429-475) for the mixed layouts, the prefill kernel otherwise.  The mid-M kernel does not touch

@@ -43,6 +43,8 @@
 // cross XCDs (one L2 each): slot traffic is agent-scope sc1 accesses, ordered against the counter by vmcnt.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "mxq_dequant.h"
 #include "mxq_format.h"
 #include "mxq_kernels.h"
@@ -1189,22 +1191,29 @@ __global__ __launch_bounds__(64) void G8_SYM(, _combine_kernel)(const float* __r
     tile_of_block(tile, tiles_m, tiles_n, tm, tn);
     const float* src = slab + (int64_t)tile * S * (BM * BN) + ws * 4096 + lane * 4;
     f32x4 c4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int s0 = 0; s0 < S; s0 += 4) {
-        f32x4 v[4][4];
+    // U slices' loads go out together (clamped, never branched around), then they are added in slice order: 8 slices -- the
+    // 32-tile launches -- are ONE round trip of 32 loads per lane, not two of 16
+    auto sum_slices = [&](auto Uc) __attribute__((always_inline)) {
+        constexpr int U = decltype(Uc)::value;
+        for (int s0 = 0; s0 < S; s0 += U) {
+            f32x4 v[U][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int sc = s0 + u < S ? s0 + u : S - 1;      // clamped, never branched around
+            for (int u = 0; u < U; ++u) {
+                const int sc = s0 + u < S ? s0 + u : S - 1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[u][i] = *(const f32x4*)(src + (int64_t)sc * (BM * BN) + (i * 4 + jj) * 256);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (s0 + u < S) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c4[i] = c4[i] + v[u][i];
+                for (int i = 0; i < 4; ++i) v[u][i] = *(const f32x4*)(src + (int64_t)sc * (BM * BN) + (i * 4 + jj) * 256);
             }
-    }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (s0 + u < S) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c4[i] = c4[i] + v[u][i];
+                }
+        }
+    };
+    if (S <= 4) sum_slices(std::integral_constant<int, 4>{});
+    else sum_slices(std::integral_constant<int, 8>{});
     store_block_xpose(c4, y, M, N, tm * BM, tn * BN, ws >> 1, ws & 1, jj, lane & 15, lane >> 4);
 }
 
