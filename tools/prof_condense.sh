@@ -18,7 +18,12 @@ if [ -d gpurun_out/${T}_midm_trace ]; then
   { echo "# csrc/midm.hip at 128 tokens x 4096^2 (BASELINE configs[0]'s shape): rocprofv3 --pmc passes of tools/gemm_prof.py midm 128 4096 4096 8 (tools/prof_round.sh ${T})"
     echo "# HBM-side bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction, MI355X_MICROARCH.md section HBM); algorithmic: 9.2 MB packed weight + 1 MB x + 1 MB y,"
     echo "# plus, by design, S x 2 MB of fp32 partial tiles written by the main kernel and read back by the combine kernel (S = 8 slices at 128 tokens)"
-    python3 tools/pmc_summary.py gpurun_out/${T}_midm_FETCH_SIZE midm; python3 tools/pmc_summary.py gpurun_out/${T}_midm_WRITE_SIZE midm; python3 tools/pmc_summary.py gpurun_out/${T}_midm_sq midm; } > profiles/${P}_midm_pmc.txt
+    python3 tools/pmc_summary.py gpurun_out/${T}_midm_FETCH_SIZE midm; python3 tools/pmc_summary.py gpurun_out/${T}_midm_WRITE_SIZE midm; python3 tools/pmc_summary.py gpurun_out/${T}_midm_sq midm
+    if [ -d gpurun_out/${T}_g8hs_FETCH_SIZE ]; then
+      echo "# the product dispatch's path at this shape since round 4 (capi.hip gemm8h_mode): csrc/gemm8h.hip in slices mode (32 tiles x 8 K-slices) + mxq_gemm8h_combine_kernel;"
+      echo "# tools/gemm_prof.py gemm8h_slices 128 4096 4096 8 -- the 8 x 2 MB of fp32 slabs are written by the first launch and read by the second, as in the mid-M kernel"
+      python3 tools/pmc_summary.py gpurun_out/${T}_g8hs_FETCH_SIZE gemm8h; python3 tools/pmc_summary.py gpurun_out/${T}_g8hs_WRITE_SIZE gemm8h; python3 tools/pmc_summary.py gpurun_out/${T}_g8hs_sq gemm8h
+    fi; } > profiles/${P}_midm_pmc.txt
 fi
 python3 - <<PY
 import json
