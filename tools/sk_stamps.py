@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--shapes", default="4096x4096")
     ap.add_argument("--dist3", action="store_true", help="all-contributors reduction from 3 contributors per tile on")
     ap.add_argument("--half", action="store_true", help="the 128-token build (gemm8h)")
+    ap.add_argument("--by-xcd", action="store_true")
     args = ap.parse_args()
     lib = ctypes.CDLL(os.path.join(ROOT, "mxq_amd/libmxq_hip_prof.so"))
     fn = lib.mxq_prof_gemm8h_skstamps_f16 if args.half else lib.mxq_prof_gemm8_skstamps_f16
@@ -81,6 +82,16 @@ def main():
         print(f"  last piece's K loop done at {pct(s[split, 1] - t0, 50):.2f} us after the first start (p10 "
               f"{pct(s[split, 1] - t0, 10):.2f}, p90 {pct(s[split, 1] - t0, 90):.2f}, max {(s[split, 1] - t0).max():.2f}); "
               f"last workgroup done at {(s[:, 6] - t0).max():.2f}")
+        if args.by_xcd:      # where the K loops end, by XCD label (workgroup id & 7) and by unit index (id >> 3)
+            ids = np.nonzero(live)[0]
+            d1 = s[:, 1] - t0
+            for e in range(8):
+                m = split & ((ids & 7) == e)
+                if m.any():
+                    print(f"    XCD label {e}: loop end median {pct(d1[m], 50):7.2f}  min {d1[m].min():7.2f}  max {d1[m].max():7.2f}  (n={int(m.sum())})")
+            order = np.argsort(d1)
+            print("    latest 12 workgroups (id: loop end, done):", ", ".join(f"{int(ids[i])}: {d1[i]:.1f}, {s[i, 6] - t0:.1f}" for i in order[-12:]))
+            print("    earliest 6:", ", ".join(f"{int(ids[i])}: {d1[i]:.1f}" for i in order[:6] if split[i]))
         own = split & (s[:, 7] > 0)
         park = split & ~own
         def row(name, a):
