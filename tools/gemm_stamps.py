@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--lib", default="mxq_amd/libmxq_hip_prof.so")
     ap.add_argument("--launches", type=int, default=200)
     ap.add_argument("--per-wave", action="store_true")
+    ap.add_argument("--by-xcd", action="store_true")
     ap.add_argument("--half", action="store_true", help="the 128-token tile build of the kernel (gemm8h: 4 MFMA waves)")
     args = ap.parse_args()
     lib = ctypes.CDLL(os.path.join(ROOT, args.lib))
@@ -57,6 +58,13 @@ def main():
             ghz = (d[:, sl, :3].sum(dim=2) / rt.clamp(min=1) / 10.0).mean().item()
             print(f"abl {abl:5d} {name:28s} work {w[0]:7.0f}  wait {w[1]:6.0f}  barrier {w[2]:6.0f}  total {w.sum():7.0f} cycles/step"
                   f"   core clock held {ghz:.2f} GHz", flush=True)
+        if args.by_xcd:        # clock held and cycles per step by XCD label (workgroup id & 7; whole-tile launches: id = tile)
+            ids = torch.arange(grid)
+            for e in range(8):
+                m = (ids & 7) == e
+                w = per[m][:, :nm, :].mean(dim=(0, 1))
+                g = (d[m][:, :nm, :3].sum(dim=2) / rt[m].clamp(min=1) / 10.0).mean().item()
+                print(f"          XCD label {e}: {w.sum():7.0f} cycles/step  clock {g:.3f} GHz  -> {w.sum() / g / 1e3:6.3f} us/step", flush=True)
         if args.per_wave:      # the two MFMA waves of a SIMD (w and w + 4) are not served alike: the older one goes first
             for wv in range(nm):
                 w = per[:, wv, :].mean(dim=0)
