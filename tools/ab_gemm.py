@@ -6,7 +6,8 @@ variants interleaved over several rounds (cdna guide rule 24), random data (rule
 
     python tools/ab_gemm.py --variants gemm1,gemm8,abl8:4,torch [--m 2048] [--shapes 4096x4096,...]
 
-variant names: gemmN = product kernel through mxq_gemm_f16_ws (checked against the fp32 matmul on the bit-exact
+variant names: midm:BM:S = the mid-M kernel at an explicit tile height / slice count (profiling library's entry, correct
+results); gemmN = product kernel through mxq_gemm_f16_ws (checked against the fp32 matmul on the bit-exact
 dequantised weight); ablK:B = libmxq_hip_prof.so's mxq_prof_gemmK_ablate_f16 with ablation bits B (WRONG results by
 construction, timing only; `make -C mxq_amd/csrc prof`); torch = torch.matmul on the dequantised fp16 weight
 (hipBLASLt), the dense yardstick.
@@ -45,6 +46,19 @@ def make_call(v, x, p, wd, out):
         def call():
             rc = fn(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K, int(bits),
                     torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, (v, rc)
+        return call
+    if v.startswith("midm:"):        # midm:BM:S -- the mid-M kernel with an explicit tile height (64 | 128) and slice count (0 = by CUs)
+        _, bm, sl = v.split(":")
+        fn = prof_lib().mxq_prof_midm_f16
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        ws = packing.gemm_workspace(x.device)
+        M = x.shape[0]
+
+        def call():
+            rc = fn(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K, int(bm), int(sl),
+                    ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (v, rc)
         return call
     if v == "dense":                 # the hoisted mode's MFMA kernel alone, on the dequantised weight
