@@ -257,11 +257,22 @@ static int gemm8h_mode(int M, int N, size_t ws_bytes) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     return tiles <= 64 ? 2 : tiles <= 176 ? 1 : 0;
 }
-static int gemm8h_launch(int mode, const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                         int layout, void* workspace, size_t ws_bytes, hipStream_t stream) {
-    if (mode == 2)
-        return mxq_launch_gemm8h_slices_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, 0, stream);
-    return mxq_launch_gemm8h_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, stream);
+// Up to 64 tokens the same again with a 64-token tile (gemm8q.hip), where it wins: 65 .. 176 tiles of 64 x 128 in stream-K
+// mode -- gate/up at 21-64 tokens: 20.6-20.9 us against 23.6-23.9 (skinny / mid-M kernel); with few tiles the mid-M kernel's
+// 64-token form is as fast (4096^2 at 64 tokens 13.6 against 14.5) and stays.  `no_midm`: the uniform layouts, which that
+// kernel does not serve, take the slices mode there (4096^2 at 49-64 tokens: 14.5 us against 30 on the 256-token tile).
+static int gemm8q_mode(int M, int N, size_t ws_bytes, bool no_midm) {
+    if (M > 64 || ws_bytes < mxq_gemm8q_workspace_bytes()) return 0;
+    const int tiles = (N + 127) / 128;
+    return tiles <= 64 ? (no_midm ? 2 : 0) : tiles <= 176 ? 1 : 0;
+}
+static int small_tile_launch(int M, int mode, const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                             int layout, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    if (M <= 64)
+        return mode == 2 ? mxq_launch_gemm8q_slices_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, 0, stream)
+                         : mxq_launch_gemm8q_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, stream);
+    return mode == 2 ? mxq_launch_gemm8h_slices_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, 0, stream)
+                     : mxq_launch_gemm8h_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, stream);
 }
 
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
@@ -302,9 +313,9 @@ int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, v
     if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
     if (M <= skinny_max_tokens(N, K))
         return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
-    if (const int mode = gemm8h_mode(M, N, workspace_bytes))
-        return gemm8h_launch(mode, x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes,
-                             (hipStream_t)stream);
+    if (const int mode = M > 64 ? gemm8h_mode(M, N, workspace_bytes) : gemm8q_mode(M, N, workspace_bytes, false))
+        return small_tile_launch(M, mode, x, qweight, rowmeta, y, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes,
+                                 (hipStream_t)stream);
     if (M <= MIDM_MAX_TOKENS && midm_ws_ok(M, N, workspace_bytes)) {
         const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
                                           (hipStream_t)stream);
@@ -324,8 +335,9 @@ int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* row
     // every layout: the skinny MFMA kernel up to the token count where the split-K / prefill kernels overtake it
     if (M <= (workspace && layout == MXQ_LAYOUT_MIXEDC ? skinny_max_tokens(N, K) : layout == MXQ_LAYOUT_MIXEDC ? 64 : 48))
         return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
-    if (const int mode = workspace ? gemm8h_mode(M, N, workspace_bytes) : 0)
-        return gemm8h_launch(mode, x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, (hipStream_t)stream);
+    if (const int mode = !workspace ? 0 : M > 64 ? gemm8h_mode(M, N, workspace_bytes)
+                                                : gemm8q_mode(M, N, workspace_bytes, layout != MXQ_LAYOUT_MIXEDC))
+        return small_tile_launch(M, mode, x, qweight, rowmeta, y, N, K, layout, workspace, workspace_bytes, (hipStream_t)stream);
     if (layout == MXQ_LAYOUT_MIXEDC) {
         if (M <= MIDM_MAX_TOKENS && (!workspace || midm_ws_ok(M, N, workspace_bytes))) {
             const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, 0, 0,
@@ -361,6 +373,10 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (variant == 10)   // the mid-M split-K kernel at any token count (tests, tools)
         return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
                                    (hipStream_t)stream);
+    if (variant == 16 || variant == 17)   // the 64-token tile of the fused kernel: stream-K (tail always split) / slices mode
+        return variant == 16 ? mxq_launch_gemm8q_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, 1, (hipStream_t)stream)
+                             : mxq_launch_gemm8q_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace,
+                                                            workspace_bytes, 0, (hipStream_t)stream);
     if (variant == 14)   // ... in slices mode (K cut into one slice per idle CU, combine launch)
         return mxq_launch_gemm8h_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0,
                                             (hipStream_t)stream);

@@ -68,15 +68,17 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #endif
 #if MXQ_G8_BM == 256
 #define G8_NAME(stem) mxq_##stem##gemm8
-#else
+#elif MXQ_G8_BM == 128
 #define G8_NAME(stem) mxq_##stem##gemm8h
+#else
+#define G8_NAME(stem) mxq_##stem##gemm8q
 #endif
 #define G8_CAT_(a, b) a##b
 #define G8_CAT(a, b) G8_CAT_(a, b)
 #define G8_SYM(stem, suffix) G8_CAT(G8_NAME(stem), suffix)
 #define G8_KERNEL G8_SYM(, _f16_kernel)
 constexpr int BM = MXQ_G8_BM, BN = 128, BK = 64;
-static_assert(BM == 256 || BM == 128, "tile height");
+static_assert(BM == 256 || BM == 128 || BM == 64, "tile height");
 // Dequant waves: a thread converts one PART of one row of the 128 x 64 weight tile per K-step.  256-token tile: 4 waves,
 // parts = column halves (32 weights).  128-token tile: the MFMA side of a K-step is half as long, and the MFMA waves were
 // found waiting ~30 % of it for the conversion (tools/gemm_stamps.py --half: 1261 cycles per step, 922 with the conversion

@@ -42,6 +42,14 @@ int mxq_launch_gemm8h_layout_f16(const void* x, const void* qweight, const void*
 // the workspace beyond its 64-KiB head (counters untouched), summed in slice order by a combine launch
 int mxq_launch_gemm8h_slices_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                  int layout, void* workspace, size_t ws_bytes, int S, hipStream_t stream);
+// ... and with a 64-token tile (gemm8q.hip = gemm8.hip at MXQ_G8_BM 64: 2 MFMA waves + 8 dequant waves)
+size_t mxq_gemm8q_workspace_bytes();
+int mxq_launch_gemm8q_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                          void* workspace, size_t ws_bytes, int force, hipStream_t stream);
+int mxq_launch_gemm8q_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
+int mxq_launch_gemm8q_slices_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                 int layout, void* workspace, size_t ws_bytes, int S, hipStream_t stream);
 // internal "take the other kernel" return of a launcher that declines a shape (never leaves capi.hip; distinct from
 // every MXQ_E_* code and every hipError_t)
 #define MXQ_NOT_MY_SHAPE (-1000)

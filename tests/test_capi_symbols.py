@@ -76,7 +76,7 @@ def test_argument_validation_rejects_before_any_launch(lib):
         assert fn(P, Q, P, P, 2, 64, 256, None) == E_ALIGN
     assert lib.mxq_gemv_f16(P, P, P, P, 5, 64, 256, None) == E_SHAPE   # GEMV is for <= 4 tokens
     # unknown kernel variants are rejected, not dispatched (no profiling build is reachable through this ABI)
-    for variant in (2, 3, 4, 5, 6, 7, 11, 16, 64, 999, -1):
+    for variant in (2, 3, 4, 5, 6, 7, 11, 15, 18, 64, 999, -1):
         assert lib.mxq_gemm_f16_ws(P, P, P, P, 8, 64, 256, variant, None, 0, None) == E_SHAPE
     assert lib.mxq_linear_f16_ws(P, P, P, P, 8, 64, 256, Q, 1 << 27, None) == E_ALIGN
     # the layout-aware dispatch (mid-M split-K kernel behind it): same checks, plus the layout code

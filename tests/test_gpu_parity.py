@@ -342,7 +342,7 @@ def test_quantizer_reproduces_fasterquant_loop_g1(dev, g1):
 # ----------------------------------------------------------------------------------------
 # dequant-GEMM / GEMV
 # ----------------------------------------------------------------------------------------
-GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm", "gemm8h", "gemm8h_split", "gemm8h_slices"]      # packing.GEMM_PATHS: every kernel the product library ships
+GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm", "gemm8h", "gemm8h_split", "gemm8h_slices", "gemm8q_split", "gemm8q_slices"]      # packing.GEMM_PATHS: every kernel the product library ships
 
 
 def _packed_case(dev, N, K, seed):
@@ -414,7 +414,7 @@ def test_gemm_integer_exact_layout(dev):
                                    (1024, 4224, 2048),    # 132 tiles: XCDs 0-3 hold 17 tail tiles, 4-7 hold 16
                                    (100, 1152, 8192),     # 9 tiles: XCD 0 holds two, the others one; half-empty 256-row tile
                                    (2048, 5120, 1024)])   # 320 tiles = one full round + a 64-tile tail
-@pytest.mark.parametrize("sk", ["gemm9", "gemm8h_split"])
+@pytest.mark.parametrize("sk", ["gemm9", "gemm8h_split", "gemm8q_split"])
 def test_gemm_stream_k_tail(dev, M, N, K, sk):
     """csrc/gemm8.hip: tiles beyond the last full round of CUs are split along K over all CUs and
     reduced through the workspace.  Checks (1) against the oracle matmul, (2) that the workspace
@@ -471,7 +471,7 @@ def test_gemm_small_tail_stream_k_through_the_dispatch(dev, M, N, K):
     assert ((y.float() - yw.float()).abs().max() / yw.float().abs().max()).item() <= REL_TOL
 
 
-@pytest.mark.parametrize("sk", ["gemm9", "gemm8h_split"])
+@pytest.mark.parametrize("sk", ["gemm9", "gemm8h_split", "gemm8q_split"])
 def test_stream_k_partition_fuzz(dev, sk):
     """Random (tokens, out, in) shapes through the forced stream-K schedule against the single-tile kernel:
     exercises unit ranges that start / end anywhere inside tiles, XCDs with unequal tail lengths, units with
@@ -506,13 +506,16 @@ def test_stream_k_partition_fuzz(dev, sk):
                                    (256, 4096, 11008),     # 64 tiles x 4 slices of 43 K-steps
                                    (100, 2048, 1024),      # 16 tiles, one ragged; S = 16 clamped to 4 (4 K-steps per slice)
                                    (65, 1040, 256),        # 9 tiles, ragged both ways, K too short to slice: whole tiles
+                                   (48, 11008, 4096),      # <= 64 tokens: 86 tiles of 64 x 128 -> the 64-token build, stream-K
+                                   (64, 4096, 4096),       # ... 32 tiles: mid-M kernel (mixed), 64-token build in slices mode (uniform)
+                                   (21, 11008, 1024),      # just above the skinny kernel's limit for the 45-M-element weights
                                    (256, 11264, 1024),     # 176 tiles: stream-K mode's upper edge ...
                                    (256, 11392, 1024)])    # ... and 178: the 256-token tile again
 @pytest.mark.parametrize("layout", ["mixed", "mixedc", "w2g16", "w4row"])
 def test_half_height_tile_through_the_dispatch(dev, M, N, K, layout):
-    """capi.hip gemm8h_mode: beyond 64 tokens, launches of up to 176 tiles of 128 x 128 run the fused kernel's 128-token
-    build (gemm8h.hip) -- up to 64 tiles in slices mode (K slices + combine launch), 65..176 in one launch with stream-K over
-    the idle CUs -- every weight layout, through the product dispatch: against the fp32 product on the bit-exact dequantised
+    """capi.hip gemm8h_mode / gemm8q_mode: beyond 64 tokens, launches of up to 176 tiles of 128 x 128 run the fused kernel's
+    128-token build (gemm8h.hip) -- up to 64 tiles in slices mode (K slices + combine launch), 65..176 in one launch with
+    stream-K over the idle CUs; up to 64 tokens the 64-token build (gemm8q.hip) where it wins -- every weight layout, through the product dispatch: against the fp32 product on the bit-exact dequantised
     weight, twice with identical bits, counters left zero; for the mixed layout the dispatch's result IS the explicit path's."""
     from mxq_amd import packing
     g = torch.Generator(device=dev).manual_seed(M + N + K)
@@ -532,7 +535,13 @@ def test_half_height_tile_through_the_dispatch(dev, M, N, K, layout):
     assert torch.equal(packing.linear_layout(x, p, path="auto"), y)
     assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
     tiles = -(-M // 128) * -(-N // 128)
-    if layout == "mixed" and tiles <= 176:
+    if layout == "mixed" and M <= 64:
+        if 65 <= -(-N // 128) <= 176 and M > 20:
+            yq = packing.linear(x, p, path="gemm8q_split")      # the same kernel with its tail ALWAYS split: the dispatch
+            if K >= 4096:                                        # splits where that pays (it does from ~32 K-steps per tile on)
+                assert torch.equal(yq, y)
+            assert ((y.float() - yq.float()).abs().max() / r.abs().max()).item() <= REL_TOL
+    elif layout == "mixed" and tiles <= 176:
         assert torch.equal(packing.linear(x, p, path="gemm8h_slices" if tiles <= 64 else "gemm8h"), y)
         ym = packing.linear(x, p, path="midm")           # the neighbour it replaced here: equal up to summation order
         assert ((y.float() - ym.float()).abs().max() / r.abs().max()).item() <= REL_TOL
