@@ -628,6 +628,34 @@ def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):
         assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 4096, 4096),      # slices mode: two launches (K slices, combine) per call
+                                   (192, 11008, 4096),     # the 128-token build, stream-K in one launch
+                                   (48, 11008, 4096)])     # the 64-token build, stream-K
+def test_small_tile_dispatch_in_a_graph(dev, M, N, K):
+    """The dispatch's small-tile paths under hipGraph capture: three calls per graph (the workspace's slabs / counters are
+    reused from call to call inside the graph), replayed with the workspace overwritten in between -- equal to the eager
+    result every time."""
+    from mxq_amd import packing
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    p = packing.quantize_pack((torch.randn(N, K, generator=g, device=dev) * 0.02).half())
+    xs = [torch.randn(M, K, generator=g, device=dev).half() for _ in range(3)]
+    refs = [packing.linear(x, p, path="auto") for x in xs]
+    outs = [torch.empty_like(r) for r in refs]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for x, o in zip(xs, outs):
+            packing.linear(x, p, out=o, path="auto")
+    ckeys = [k for k in packing._WORKSPACES if len(k) == 3 and k[1] == "capture"]
+    for it in range(3):
+        for o in outs:
+            o.zero_()
+        if it:
+            packing._WORKSPACES[ckeys[-1]].fill_(it)      # whatever the buffer holds before a replay must not matter
+        graph.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, r) for o, r in zip(outs, refs)), it
+
+
 def test_two_stream_k_graphs_replayed_concurrently(dev):
     """Two graphs with stream-K launches (partial tiles + counters in the workspace), replayed AT THE SAME TIME on two
     streams, many times: each graph has its own workspace, so neither corrupts the other's partial sums (round 3 shared
