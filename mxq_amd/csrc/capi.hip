@@ -235,9 +235,11 @@ int mxq_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, 
     return dense_f16(x, w16, y, M, N, K, variant, (hipStream_t)stream);
 }
 
-// Token counts served by the mid-M split-K kernel (midm.hip): above the skinny kernel's range, below the point
-// where the prefill kernel's 256 x 128 tiles win again -- beyond 256 tokens at every Llama shape
-// (tools/midm_bench.py, profiles/r03_midM.txt)
+// Token counts the mid-M split-K kernel (midm.hip) may serve: above the skinny kernel's range, below the point where the
+// prefill kernel's 256 x 128 tiles win again (profiles/r03_midM.txt).  Since round 4 the fused kernel's 128- / 64-token builds
+// (gemm8h_mode / gemm8q_mode below) take most of that range when a full workspace is given: what is left to this kernel is
+// 21 / 41 .. 64 tokens on launches of <= 64 tiles (and up to 256 tokens where the workspace is too small for those builds,
+// or absent).  The whole map against hipBLASLt: profiles/r04_dispatch_map.txt.
 static const int MIDM_MAX_TOKENS = 256;
 // ... and the token count up to which the skinny kernel (one workgroup per 16-row block, every wave reads all of x from
 // L2) still beats it: its time grows with tokens x weight size, the split-K kernel's is flat up to 64 tokens.  Measured

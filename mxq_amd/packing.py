@@ -32,7 +32,7 @@ def _stream(t: torch.Tensor) -> int:
 _WORKSPACES: Dict[tuple, torch.Tensor] = {}
 _WS_EAGER: Dict[tuple, bool] = {}    # key -> the counter head has been zeroed (eagerly, or by a memset recorded in its graph)
 _WS_HEAD = 65536      # bytes of K-step counters at the head of a workspace (include/mxq_hip.h)
-MIDM_MAX_TOKENS = 256     # capi.hip: token counts that mxq_linear_f16_ws hands to the mid-M split-K kernel (no counters)
+MIDM_MAX_TOKENS = 256     # capi.hip: the most tokens mxq_linear_f16_ws may hand to the mid-M split-K kernel (no counters)
 
 
 _CAPTURE_KEYS: list = []          # capture workspaces in order of creation (bounded: _MAX_CAPTURE_WS)
@@ -335,12 +335,16 @@ GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm":
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
     """y = x @ dequant(p).T for x [..., K] fp16 -> [..., N] fp16 (fp32 accumulation).
 
-    path: "auto" (GEMV kernel for <= 4 tokens, skinny MFMA kernel up to 40 -- 20 for weights beyond 24 M elements --,
-    mid-M split-K kernel up to 256, prefill GEMM beyond: the C dispatch of mxq_linear_f16_ws), "gemm", "gemv", "midm",
+    path: "auto" (the library's own dispatch, mxq_linear_f16_auto: GEMV kernel for <= 4 tokens, skinny MFMA kernel up to 40 --
+    20 for weights beyond 24 M elements --, then by tile count the fused kernel's 64- / 128-token builds or the mid-M split-K
+    kernel, the 256-token fused kernel beyond, the hoisted mode from 4096 tokens: profiles/r04_dispatch_map.txt), "gemm",
+    "gemv", "midm",
     "skinny" (1..64 tokens), "hoist" (dequant hoisted out of the token loop; "auto" / "gemm" take it from
     HOIST_MIN_TOKENS tokens on), "fused" (never hoist), "whole" (fused kernel, whole tiles only), or an explicit GEMM
     kernel: "gemm1" (128x128 tile), "gemm8" (256x128 tile, wave-specialised, persistent, stream-K tail), "gemm9"
-    (gemm8 splitting its tail whenever that is structurally possible: tests)."""
+    (gemm8 splitting its tail whenever that is structurally possible: tests), "gemm8h" / "gemm8h_split" / "gemm8h_slices"
+    (its 128-token build: tail split where it pays / always / K slices + combine launch), "gemm8q_split" / "gemm8q_slices"
+    (the 64-token build)."""
     _need_gpu(x, p.qweight)
     if x.dtype != torch.float16:
         raise ValueError(f"activations must be float16 (W2/4 x A16), got {x.dtype}")
