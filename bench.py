@@ -129,7 +129,7 @@ def cpu_baseline(dev, budget_s=12.0):
             "iters": len(times), "host_cpus": os.cpu_count(), "gpu_vs_cpu_max_rel_err": rel,
             "gpu_ms_per_call": round(gpu_ms, 5), "gpu_TFLOPs": round(flop / (gpu_ms * 1e-3) / 1e12, 2),
             "gpu_speedup": round(med * 1e3 / gpu_ms, 1),
-            "gpu_kernel": "fused kernel's 128-token build in slices mode (32 tiles x 8 K-slices + combine launch: the "
+            "gpu_kernel": "fused kernel's 128 x 64-tile build in slices mode (64 tiles x 4 K-slices + combine launch: the "
                           "mxq_linear_f16_auto dispatch at 128 tokens), stream-ordered launches, HIP events",
             "sample": "config 1: one 4096x4096 MXQ Linear, M=128 tokens, dequant(fp32)+F.linear per call "
                       "(4.295 GFLOP), median of the calls that fit ~12 s; the GPU runs the same call on the same inputs"}

@@ -270,6 +270,16 @@ static int gemm8q_mode(int M, int N, size_t ws_bytes, bool no_midm) {
 }
 static int small_tile_launch(int M, int mode, const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
                              int layout, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    // <= 64 tiles of 128 x 128 and a short K (<= 96 K-steps): the fp32 partial tiles are the cost, and the 128 x 64 tile
+    // (gemm8n.hip) halves them for the same number of workgroups -- 4096^2 at 65-128 tokens 16.0-16.2 us against 18.4-18.6
+    // (its slices mode: <= 64 tiles of 128 x 64), at 192 / 256 tokens 20.5 / 21.0 against 22.2 / 22.3 (stream-K mode); with
+    // K = 11008 its longer K loop costs more than the bytes save (24-25 against 22-23 us): profiles/r04_gemm8h.txt
+    if (M > 64 && mode == 2 && K <= 6144) {
+        const int tiles64 = ((M + 127) / 128) * ((N + 63) / 64);
+        return tiles64 <= 64
+                   ? mxq_launch_gemm8n_slices_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, 0, stream)
+                   : mxq_launch_gemm8n_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, stream);
+    }
     if (M <= 64)
         return mode == 2 ? mxq_launch_gemm8q_slices_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, 0, stream)
                          : mxq_launch_gemm8q_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, stream);
@@ -375,6 +385,10 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
     if (variant == 10)   // the mid-M split-K kernel at any token count (tests, tools)
         return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
                                    (hipStream_t)stream);
+    if (variant == 20 || variant == 21)   // the 128 x 64 tile of the fused kernel: stream-K (tail always split) / slices mode
+        return variant == 20 ? mxq_launch_gemm8n_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, 1, (hipStream_t)stream)
+                             : mxq_launch_gemm8n_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace,
+                                                            workspace_bytes, 0, (hipStream_t)stream);
     if (variant == 16 || variant == 17)   // the 64-token tile of the fused kernel: stream-K (tail always split) / slices mode
         return variant == 16 ? mxq_launch_gemm8q_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, 1, (hipStream_t)stream)
                              : mxq_launch_gemm8q_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace,

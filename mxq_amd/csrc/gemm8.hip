@@ -66,10 +66,15 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef MXQ_G8_BM
 #define MXQ_G8_BM 256
 #endif
+#ifndef MXQ_G8_BN
+#define MXQ_G8_BN 128
+#endif
 #if MXQ_G8_BM == 256
 #define G8_NAME(stem) mxq_##stem##gemm8
-#elif MXQ_G8_BM == 128
+#elif MXQ_G8_BM == 128 && MXQ_G8_BN == 128
 #define G8_NAME(stem) mxq_##stem##gemm8h
+#elif MXQ_G8_BM == 128
+#define G8_NAME(stem) mxq_##stem##gemm8n
 #else
 #define G8_NAME(stem) mxq_##stem##gemm8q
 #endif
@@ -77,17 +82,26 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define G8_CAT(a, b) G8_CAT_(a, b)
 #define G8_SYM(stem, suffix) G8_CAT(G8_NAME(stem), suffix)
 #define G8_KERNEL G8_SYM(, _f16_kernel)
-constexpr int BM = MXQ_G8_BM, BN = 128, BK = 64;
+constexpr int BM = MXQ_G8_BM, BN = MXQ_G8_BN, BK = 64;
+static_assert(BN == 128 || (BN == 64 && BM == 128), "tile width");
 static_assert(BM == 256 || BM == 128 || BM == 64, "tile height");
 // Dequant waves: a thread converts one PART of one row of the 128 x 64 weight tile per K-step.  256-token tile: 4 waves,
 // parts = column halves (32 weights).  128-token tile: the MFMA side of a K-step is half as long, and the MFMA waves were
 // found waiting ~30 % of it for the conversion (tools/gemm_stamps.py --half: 1261 cycles per step, 922 with the conversion
 // switched off) -- so there the tile is converted by 8 waves, parts = 16-column quarters (3 waves per SIMD, as gemm8).
 #ifndef MXQ_G8_NDEQ
-#define MXQ_G8_NDEQ (MXQ_G8_BM == 256 ? 4 : 8)
+#define MXQ_G8_NDEQ (MXQ_G8_BM == 256 ? 4 : MXQ_G8_BN == 128 ? 8 : 4)
 #endif
-constexpr int N_MMA = BM / 32, N_DEQ = MXQ_G8_NDEQ, THREADS = (N_MMA + N_DEQ) * 64;
-constexpr int DEQ_PARTS = N_DEQ / 2;          // 2 (halves) or 4 (quarters)
+// MFMA waves: a WGM (tokens) x WGN (channels) grid of sub-tiles of 16 NJ tokens x 64 channels.  128-channel tiles: 64 x 64
+// sub-tiles, 2 waves across the channels; the 64-channel tile (gemm8n.hip: 128 x 64, for launches whose fp32 partial tiles are
+// the cost) has one wave across and four of 32 x 64 down the tokens.
+constexpr int WGN = BN / 64, N_MMA = BM == 128 && BN == 64 ? 4 : BM / 32, WGM = N_MMA / WGN;
+constexpr int NJ = BM / (16 * WGM);           // 16-token blocks per MFMA wave (4 | 2)
+constexpr int FRAGS = 4 * NJ;                 // accumulator fragments per MFMA wave: f = i * NJ + j (W block i, token block j)
+constexpr int WSLOT = FRAGS * 1024;           // bytes of a wave's share of a partial-tile slot (16 B per lane and fragment)
+constexpr int N_DEQ = MXQ_G8_NDEQ, THREADS = (N_MMA + N_DEQ) * 64;
+static_assert(BM / (8 * N_MMA) == 4, "every MFMA wave stages 32 rows of the x tile per K-step");
+constexpr int DEQ_PARTS = N_DEQ * 64 / BN;    // parts of a row per thread: 2 (halves) or 4 (quarters)
 constexpr int DEQ_NRES = 8 / DEQ_PARTS;       // 16-byte W16 slots a thread writes per chunk
 constexpr int A_STAGE = BM * BK * 2, A_SLOTS = 3;
 constexpr int W_STAGE = BN * BK * 2;
@@ -97,7 +111,7 @@ constexpr int OFF_W = OFF_A + A_SLOTS * A_STAGE;
 constexpr int OFF_WD = OFF_W, WD_SLOTS = 3;
 constexpr int SMEM_BYTES = OFF_WD + WD_SLOTS * W_STAGE;
 static_assert(OFF_W + 2 * W_STAGE <= SMEM_BYTES && SMEM_BYTES <= 160 * 1024, "LDS budget");
-static_assert(N_MMA * 16384 <= SMEM_BYTES, "the stream-K owner stages a 16-KB slot per MFMA wave in the idle rings");
+static_assert(N_MMA * WSLOT <= SMEM_BYTES, "the stream-K owner stages a wave's share of a slot per MFMA wave in the idle rings");
 constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K] matrix (never part of the C ABI)
 
 // profiling-only switches (template parameter ABL; the product library instantiates ABL = 0 only, and the stamp / ballast
@@ -171,11 +185,11 @@ struct SkSeg {
 // 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md; nothing here needs atomicity -- a slot is read only after the
 // K-step count that its writer bumped behind s_waitcnt vmcnt(0) is complete.)
 __device__ __forceinline__ void st_agent(float* slot, int f, int lane, f32x4 v) {
-    const rsrc_t r = make_rsrc(slot, 16384u);
+    const rsrc_t r = make_rsrc(slot, (uint32_t)WSLOT);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (uint32_t)(f * 64 + lane) * 16u, 0u, 16);
 }
 __device__ __forceinline__ f32x4 ld_agent(const float* slot, int f, int lane) {
-    const rsrc_t r = make_rsrc(slot, 16384u);
+    const rsrc_t r = make_rsrc(slot, (uint32_t)WSLOT);
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (uint32_t)(f * 64 + lane) * 16u, 0u, 16));
 }
 __device__ __forceinline__ int sk_bound(int u, int S, int units) { return (int)((uint32_t)u * (uint32_t)S / (uint32_t)units); }
@@ -184,30 +198,32 @@ __device__ __forceinline__ int sk_bound(int u, int S, int units) { return (int)(
 // MFMA waves
 // ------------------------------------------------------------------------------------------------
 typedef half8 Frag4[4];
+typedef half8 FragX[NJ];
+typedef f32x4 AccT[4][NJ];
 
 // DENSE: the weight tile is a 3-slot ring of fp16 tiles filled by LDS-DMA (hoisted-dequant mode, below) instead of the
 // double buffer the dequant waves write
 template <bool DENSE>
 __device__ __forceinline__ void load_frags(const char* smem, int t, int kk, int wm, int wn, int fr, int fq, Frag4& wf,
-                                           Frag4& xf) {
+                                           FragX& xf) {
     const char* a_base = smem + OFF_A + (t % A_SLOTS) * A_STAGE;
     const char* w_base = DENSE ? smem + OFF_WD + (t % WD_SLOTS) * W_STAGE : smem + OFF_W + (t & 1) * W_STAGE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(w_base + swz(wn * 64 + i * 16 + fr, kk * 4 + fq));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xf[j] = *(const half8*)(a_base + swz(wm * 64 + j * 16 + fr, kk * 4 + fq));
+    for (int j = 0; j < NJ; ++j) xf[j] = *(const half8*)(a_base + swz(wm * (16 * NJ) + j * 16 + fr, kk * 4 + fq));
 }
 
 // ABL_FILL (profiling builds): FILLN independent v_add_f32 behind every MFMA, pinned there by sched_group_barrier -- what
 // vector-ALU work costs when it sits IN the MFMA waves' own streams, one or two ops per MFMA gap (r04 probe)
 struct Fill { float f[4]; };
 template <int I0, int I1, int ABL>
-__device__ __forceinline__ void mfma_rows(f32x4 (&acc)[4][4], const Frag4& wf, const Frag4& xf, Fill* fl = nullptr) {
+__device__ __forceinline__ void mfma_rows(AccT& acc, const Frag4& wf, const FragX& xf, Fill* fl = nullptr) {
     constexpr int FILLN = (ABL >> 6) & 3;
 #pragma unroll
     for (int i = I0; i < I1; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             if constexpr (ABL & ABL_NO_MFMA) asm volatile("" ::"v"(wf[i]), "v"(xf[j]));
             else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
             if constexpr (FILLN > 0) {
@@ -217,7 +233,7 @@ __device__ __forceinline__ void mfma_rows(f32x4 (&acc)[4][4], const Frag4& wf, c
         }
     if constexpr (FILLN > 0) {
 #pragma unroll
-        for (int n = 0; n < (I1 - I0) * 4; ++n) {
+        for (int n = 0; n < (I1 - I0) * NJ; ++n) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, FILLN, 0);   // FILLN VALU ops
         }
@@ -278,7 +294,7 @@ __device__ __forceinline__ void sk_stamp(int* cnt, int wave, int lane, int i) {
 // step t+2 (slot (t+2) % 3 was last read in step t-1), spread behind groups of MFMAs.
 template <int ABL, bool ISSUE, bool DENSE>
 __device__ __forceinline__ void mma_step(char* smem, int t, int wave, int wm, int wn, int fr, int fq, const XDma& xd,
-                                         f32x4 (&acc)[4][4], Frag4& wf0, Frag4& xf0, Frag4& wf1, Frag4& xf1,
+                                         AccT& acc, Frag4& wf0, FragX& xf0, Frag4& wf1, FragX& xf1,
                                          Stamps& st) {
     u64t t0 = 0, t1 = 0, t2 = 0;
     [[maybe_unused]] Fill fl = {{(float)t, (float)t + 1.f, (float)t + 2.f, (float)t + 3.f}};
@@ -352,7 +368,7 @@ __device__ __forceinline__ void store_block_xpose(const f32x4 (&c4)[4], uint16_t
         r = __builtin_amdgcn_permlane16_swap(c[0][d], c[1][d], false, false); c[0][d] = r[0]; c[1][d] = r[1];
         r = __builtin_amdgcn_permlane16_swap(c[2][d], c[3][d], false, false); c[2][d] = r[0]; c[3][d] = r[1];
     }
-    const int m = m0 + wm * 64 + j * 16 + fr;
+    const int m = m0 + wm * (16 * NJ) + j * 16 + fr;
     if (m < M && n < N) {
         uint16_t* dst = y + (int64_t)m * N + n;
         // streaming stores: y is written once and not read by this kernel, so it should not displace x / W
@@ -361,10 +377,10 @@ __device__ __forceinline__ void store_block_xpose(const f32x4 (&c4)[4], uint16_t
         __builtin_nontemporal_store((u32x4){c[2][0], c[2][1], c[3][0], c[3][1]}, (u32x4*)(dst + 8));
     }
 }
-__device__ __forceinline__ void store_tile_xpose(const f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N,
+__device__ __forceinline__ void store_tile_xpose(const AccT& acc, uint16_t* __restrict__ y, int M, int N,
                                                  int m0, int n0, int wm, int wn, int fr, int fq) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const f32x4 c4[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
         store_block_xpose(c4, y, M, N, m0, n0, wm, wn, j, fr, fq);
     }
@@ -436,9 +452,9 @@ __device__ __forceinline__ void sk_reduce_distributed(const SkSeg& sk, int j, in
     // only the FIRST contributor's range can have started before the tile (its piece here is then its second: slot 1)
     const int first_slot = sk_bound(uf, sk.S, sk.units) >= lo ? 0 : 1;
     int* cw = sk.cnt + (j * 8 + sk.e) * N_MMA;
-    char* stage = smem + wave * 16384;
-    for (int t = self * N_MMA + wave; t < 4 * N_MMA; t += C * N_MMA) {
-        const int ws = t >> 2, jj = t & 3;
+    char* stage = smem + wave * WSLOT;               // room for NJ contributors' four fragments per batch
+    for (int t = self * N_MMA + wave; t < NJ * N_MMA; t += C * N_MMA) {
+        const int ws = t / NJ, jj = t % NJ;
         for (int spin = 0; spin < SK_SPIN_BOUND; ++spin) {
             int v = 0;
             if (lane == 0) v = __hip_atomic_load(cw + ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -459,16 +475,16 @@ __device__ __forceinline__ void sk_reduce_distributed(const SkSeg& sk, int j, in
         };
         for (int k = 0; k < C; ++k) {
             const int v = uf + k;
-            const float* src = sk.ws + ((int64_t)((v * 8 + sk.e) * 2 + (k == 0 ? first_slot : 0)) * (BM * BN)) + ws * 4096;
-            const rsrc_t r = make_rsrc(src, 16384u);
+            const float* src = sk.ws + ((int64_t)((v * 8 + sk.e) * 2 + (k == 0 ? first_slot : 0)) * (BM * BN)) + ws * (WSLOT / 4);
+            const rsrc_t r = make_rsrc(src, (uint32_t)WSLOT);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(stage + staged * 4096 + i * 1024),
-                                                         16, (uint32_t)lane * 16u, (uint32_t)(i * 4 + jj) * 1024u, 0, 16);
-            if (++staged == 4) flush();
+                                                         16, (uint32_t)lane * 16u, (uint32_t)(i * NJ + jj) * 1024u, 0, 16);
+            if (++staged == NJ) flush();
         }
         if (staged) flush();
-        store_block_xpose(c4, y, M, N, m0, n0, ws >> 1, ws & 1, jj, lane & 15, lane >> 4);
+        store_block_xpose(c4, y, M, N, m0, n0, ws / WGN, ws % WGN, jj, lane & 15, lane >> 4);
     }
     sk_stamp<ABL>(sk.cnt, wave, lane, 5);
     // this wave is through with the tile; the last of the contributors' 8 C waves re-zeroes its counters for the next launch
@@ -496,7 +512,7 @@ __device__ __forceinline__ void sk_bump_pending(SkSeg& sk, int wave, int lane) {
 // re-zero the counter.  Contributors are units with a lower index; their piece of this tile is the FIRST thing they run.
 template <int ABL>
 __device__ __forceinline__ void sk_finish_owner(const SkSeg& sk, int own, int NT_tile, int wave, int lane, char* smem,
-                                                f32x4 (&acc)[4][4], uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
+                                                AccT& acc, uint16_t* __restrict__ y, int M, int N, int m0, int n0) {
     const int j = sk.j, lo = j * NT_tile;
     int* c = sk.cnt + (j * 8 + sk.e) * N_MMA + wave;
     const int need = NT_tile - own;
@@ -515,27 +531,27 @@ __device__ __forceinline__ void sk_finish_owner(const SkSeg& sk, int own, int NT
     // another XCD) into this wave's 16 KB of the idle rings, all in flight together = ONE loaded-memory round trip per
     // slot and no second accumulator set (64 more VGPRs spilled at the 168-register cap).  The rings are idle: this is the
     // unit's last segment, every LDS read of it lies before its last barrier, and the dequant waves have passed theirs.
-    char* stage = smem + wave * 16384;
+    char* stage = smem + wave * WSLOT;
     for (int v = uf; v < sk.u; ++v) {
         const int vb = sk_bound(v, sk.S, sk.units);
         if (sk_bound(v + 1, sk.S, sk.units) <= (vb > lo ? vb : lo)) continue;   // empty range: no slot was written
-        const float* src = sk.ws + ((int64_t)((v * 8 + sk.e) * 2 + (vb >= lo ? 0 : 1)) * (BM * BN)) + wave * 4096;
-        const rsrc_t r = make_rsrc(src, 16384u);
+        const float* src = sk.ws + ((int64_t)((v * 8 + sk.e) * 2 + (vb >= lo ? 0 : 1)) * (BM * BN)) + wave * (WSLOT / 4);
+        const rsrc_t r = make_rsrc(src, (uint32_t)WSLOT);
 #pragma unroll
-        for (int f = 0; f < 16; ++f)
+        for (int f = 0; f < FRAGS; ++f)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(stage + f * 1024), 16,
                                                      (uint32_t)lane * 16u, (uint32_t)f * 1024u, 0, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = acc[i][jj] + *(const f32x4*)(stage + (i * 4 + jj) * 1024 + lane * 16);
+            for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = acc[i][jj] + *(const f32x4*)(stage + (i * NJ + jj) * 1024 + lane * 16);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next slot's DMA overwrites the stage
     }
     sk_stamp<ABL>(sk.cnt, wave, lane, 3);
     if (lane == 0)   // ready for the next launch
         __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    store_tile_xpose(acc, y, M, N, m0, n0, wave >> 1, wave & 1, lane & 15, lane >> 4);
+    store_tile_xpose(acc, y, M, N, m0, n0, wave / WGN, wave % WGN, lane & 15, lane >> 4);
 }
 
 // One segment = NT K-steps of one tile.  pre: its prologue DMAs are already in flight (issued by the caller behind
@@ -547,13 +563,14 @@ template <int ABL, bool DENSE, class Next>
 __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int NT, const XDma& xd, bool pre,
                                             uint16_t* __restrict__ y, int M, int N, int m0, int n0, int NT_tile,
                                             SkSeg& sk, Next&& next) {
-    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
-    f32x4 acc[4][4];
+    const int wm = wave / WGN, wn = wave % WGN, fr = lane & 15, fq = lane >> 4;
+    AccT acc;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    Frag4 wf0, xf0, wf1, xf1;
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag4 wf0, wf1;
+    FragX xf0, xf1;
 
     if (!pre) mma_prologue_issue<ABL>(xd, smem, wave, NT);
     if (NT > 1 && !pre) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -598,7 +615,7 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[i][j]));
 
     if (NT != NT_tile) {
         sk_stamp<ABL>(sk.cnt, wave, lane, 1);
@@ -607,11 +624,11 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
             return;
         }
         // a piece that starts its tile: park the accumulators in this unit's slot; the count moves once the stores retired
-        float* mine = (sk.park ? sk.park : sk.ws + (int64_t)((sk.u * 8 + sk.e) * 2 + (sk.first ? 0 : 1)) * (BM * BN)) + wave * 4096;
+        float* mine = (sk.park ? sk.park : sk.ws + (int64_t)((sk.u * 8 + sk.e) * 2 + (sk.first ? 0 : 1)) * (BM * BN)) + wave * (WSLOT / 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) st_agent(mine, i * 4 + j, lane, acc[i][j]);
+            for (int j = 0; j < NJ; ++j) st_agent(mine, i * NJ + j, lane, acc[i][j]);
         sk.pend_j = sk.park ? -1 : sk.j;
         sk.pend_n = NT;
         sk_stamp<ABL>(sk.cnt, wave, lane, 2);
@@ -624,7 +641,7 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s_ += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            for (int j = 0; j < NJ; ++j) s_ += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (s_ == 123.456f) y[0] = 1;
     }
 }
@@ -799,8 +816,8 @@ __device__ __forceinline__ void deq_setup(Deq& c, char* smem, int wave, int lane
     c.rsrc = make_rsrc(qweight, (uint32_t)(N >> 4) * blk_stride);
     c.k0 = (uint32_t)kt0 * BLK_B;
     const int dt = c.d * 64 + lane;   // 0 .. 64 N_DEQ - 1
-    c.row = dt & 127;
-    c.h = __builtin_amdgcn_readfirstlane(dt >> 7);   // wave-uniform part: dequant waves 0,1 -> 0; 2,3 -> 1; (4,5 -> 2; 6,7 -> 3)
+    c.row = dt % BN;
+    c.h = __builtin_amdgcn_readfirstlane(dt / BN);   // wave-uniform part: dequant waves 0,1 -> 0; 2,3 -> 1; (4,5 -> 2; 6,7 -> 3)
     c.r = c.row & 15;
     c.voff_blk = (uint32_t)((n0 >> 4) + (c.row >> 4)) * blk_stride;
 }
@@ -1187,11 +1204,11 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
 __global__ __launch_bounds__(64) void G8_SYM(, _combine_kernel)(const float* __restrict__ slab, uint16_t* __restrict__ y, int M,
                                                                 int N, int tiles_m, int tiles_n, int S) {
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x / (N_MMA * 4), rem = blockIdx.x % (N_MMA * 4);
-    const int ws = rem >> 2, jj = rem & 3;
+    const int tile = blockIdx.x / (N_MMA * NJ), rem = blockIdx.x % (N_MMA * NJ);
+    const int ws = rem / NJ, jj = rem % NJ;
     int tm, tn;
     tile_of_block(tile, tiles_m, tiles_n, tm, tn);
-    const float* src = slab + (int64_t)tile * S * (BM * BN) + ws * 4096 + lane * 4;
+    const float* src = slab + (int64_t)tile * S * (BM * BN) + ws * (WSLOT / 4) + lane * 4;
     f32x4 c4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // U slices' loads go out together (clamped, never branched around), then they are added in slice order: 8 slices -- the
     // 32-tile launches -- are ONE round trip of 32 loads per lane, not two of 16
@@ -1203,7 +1220,7 @@ __global__ __launch_bounds__(64) void G8_SYM(, _combine_kernel)(const float* __r
             for (int u = 0; u < U; ++u) {
                 const int sc = s0 + u < S ? s0 + u : S - 1;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[u][i] = *(const f32x4*)(src + (int64_t)sc * (BM * BN) + (i * 4 + jj) * 256);
+                for (int i = 0; i < 4; ++i) v[u][i] = *(const f32x4*)(src + (int64_t)sc * (BM * BN) + (i * NJ + jj) * 256);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1216,7 +1233,7 @@ __global__ __launch_bounds__(64) void G8_SYM(, _combine_kernel)(const float* __r
     };
     if (S <= 4) sum_slices(std::integral_constant<int, 4>{});
     else sum_slices(std::integral_constant<int, 8>{});
-    store_block_xpose(c4, y, M, N, tm * BM, tn * BN, ws >> 1, ws & 1, jj, lane & 15, lane >> 4);
+    store_block_xpose(c4, y, M, N, tm * BM, tn * BN, ws / WGN, ws % WGN, jj, lane & 15, lane >> 4);
 }
 
 int cu_count() {
@@ -1306,7 +1323,7 @@ static int launch8_slices(const void* x, const void* qweight, const void* rowmet
     G8_KERNEL<0, LAYOUT><<<tiles * S, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n, 0, 0,
         -S, 0, slab, nullptr);
-    G8_SYM(, _combine_kernel)<<<tiles * N_MMA * 4, 64, 0, stream>>>(slab, (uint16_t*)y, M, N, tiles_m, tiles_n, S);
+    G8_SYM(, _combine_kernel)<<<tiles * N_MMA * NJ, 64, 0, stream>>>(slab, (uint16_t*)y, M, N, tiles_m, tiles_n, S);
     return (int)hipGetLastError();
 }
 

@@ -50,6 +50,14 @@ int mxq_launch_gemm8q_layout_f16(const void* x, const void* qweight, const void*
                                  int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
 int mxq_launch_gemm8q_slices_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                  int layout, void* workspace, size_t ws_bytes, int S, hipStream_t stream);
+// ... and with a 128-token x 64-channel tile (gemm8n.hip = gemm8.hip at MXQ_G8_BM 128, MXQ_G8_BN 64)
+size_t mxq_gemm8n_workspace_bytes();
+int mxq_launch_gemm8n_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                          void* workspace, size_t ws_bytes, int force, hipStream_t stream);
+int mxq_launch_gemm8n_layout_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                 int layout, void* workspace, size_t ws_bytes, hipStream_t stream);
+int mxq_launch_gemm8n_slices_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
+                                 int layout, void* workspace, size_t ws_bytes, int S, hipStream_t stream);
 // internal "take the other kernel" return of a launcher that declines a shape (never leaves capi.hip; distinct from
 // every MXQ_E_* code and every hipError_t)
 #define MXQ_NOT_MY_SHAPE (-1000)

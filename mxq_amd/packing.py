@@ -329,7 +329,7 @@ def linear_dense(x: torch.Tensor, w16: torch.Tensor, out: Optional[torch.Tensor]
     return out.reshape(*x.shape[:-1], N)
 
 
-GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10, "gemm8h": 12, "gemm8h_split": 13, "gemm8h_slices": 14, "gemm8q_split": 16, "gemm8q_slices": 17}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
+GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10, "gemm8h": 12, "gemm8h_split": 13, "gemm8h_slices": 14, "gemm8q_split": 16, "gemm8q_slices": 17, "gemm8n_split": 20, "gemm8n_slices": 21}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
 
 
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
@@ -403,7 +403,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         else:
             midm = path == "midm"
             ws = (gemm_workspace(x2.device, counters=not midm)
-                  if path in ("auto", "gemm", "fused", "gemm8", "gemm9", "midm", "gemm8h", "gemm8h_split", "gemm8h_slices", "gemm8q_split", "gemm8q_slices") else None)
+                  if path in ("auto", "gemm", "fused", "gemm8", "gemm9", "midm", "gemm8h", "gemm8h_split", "gemm8h_slices", "gemm8q_split", "gemm8q_slices", "gemm8n_split", "gemm8n_slices") else None)
             wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
             if path == "auto":
                 rc = lib.mxq_linear_f16_ws(*args, wsp, wsn, _stream(x2))

@@ -342,7 +342,7 @@ def test_quantizer_reproduces_fasterquant_loop_g1(dev, g1):
 # ----------------------------------------------------------------------------------------
 # dequant-GEMM / GEMV
 # ----------------------------------------------------------------------------------------
-GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm", "gemm8h", "gemm8h_split", "gemm8h_slices", "gemm8q_split", "gemm8q_slices"]      # packing.GEMM_PATHS: every kernel the product library ships
+GEMM_KERNELS = ["gemm", "gemm1", "gemm8", "gemm9", "midm", "gemm8h", "gemm8h_split", "gemm8h_slices", "gemm8q_split", "gemm8q_slices", "gemm8n_split", "gemm8n_slices"]      # packing.GEMM_PATHS: every kernel the product library ships
 
 
 def _packed_case(dev, N, K, seed):
@@ -414,7 +414,7 @@ def test_gemm_integer_exact_layout(dev):
                                    (1024, 4224, 2048),    # 132 tiles: XCDs 0-3 hold 17 tail tiles, 4-7 hold 16
                                    (100, 1152, 8192),     # 9 tiles: XCD 0 holds two, the others one; half-empty 256-row tile
                                    (2048, 5120, 1024)])   # 320 tiles = one full round + a 64-tile tail
-@pytest.mark.parametrize("sk", ["gemm9", "gemm8h_split", "gemm8q_split"])
+@pytest.mark.parametrize("sk", ["gemm9", "gemm8h_split", "gemm8q_split", "gemm8n_split"])
 def test_gemm_stream_k_tail(dev, M, N, K, sk):
     """csrc/gemm8.hip: tiles beyond the last full round of CUs are split along K over all CUs and
     reduced through the workspace.  Checks (1) against the oracle matmul, (2) that the workspace
@@ -471,7 +471,7 @@ def test_gemm_small_tail_stream_k_through_the_dispatch(dev, M, N, K):
     assert ((y.float() - yw.float()).abs().max() / yw.float().abs().max()).item() <= REL_TOL
 
 
-@pytest.mark.parametrize("sk", ["gemm9", "gemm8h_split", "gemm8q_split"])
+@pytest.mark.parametrize("sk", ["gemm9", "gemm8h_split", "gemm8q_split", "gemm8n_split"])
 def test_stream_k_partition_fuzz(dev, sk):
     """Random (tokens, out, in) shapes through the forced stream-K schedule against the single-tile kernel:
     exercises unit ranges that start / end anywhere inside tiles, XCDs with unequal tail lengths, units with
@@ -503,7 +503,9 @@ def test_stream_k_partition_fuzz(dev, sk):
                                    (129, 4096, 1024),      # 64 tiles: the last launch in slices mode ...
                                    (129, 4224, 1024),      # ... 66: the first in stream-K mode
                                    (128, 4096, 4096),      # BASELINE configs[0]'s shape: 32 tiles, 8 slices each
-                                   (256, 4096, 11008),     # 64 tiles x 4 slices of 43 K-steps
+                                   (256, 4096, 11008),     # 64 tiles x 4 slices of 43 K-steps (long K: the 128 x 128 tile)
+                                   (256, 4096, 4096),      # short K: 128 tiles of 128 x 64, stream-K
+                                   (200, 2048, 6144),      # ... 64 tiles of 128 x 64, slices, ragged token edge
                                    (100, 2048, 1024),      # 16 tiles, one ragged; S = 16 clamped to 4 (4 K-steps per slice)
                                    (65, 1040, 256),        # 9 tiles, ragged both ways, K too short to slice: whole tiles
                                    (48, 11008, 4096),      # <= 64 tokens: 86 tiles of 64 x 128 -> the 64-token build, stream-K
@@ -541,6 +543,12 @@ def test_half_height_tile_through_the_dispatch(dev, M, N, K, layout):
             if K >= 4096:                                        # splits where that pays (it does from ~32 K-steps per tile on)
                 assert torch.equal(yq, y)
             assert ((y.float() - yq.float()).abs().max() / r.abs().max()).item() <= REL_TOL
+    elif layout == "mixed" and tiles <= 64 and K <= 6144:       # short K: the 128 x 64 tile (half the partial-tile bytes)
+        t64 = -(-M // 128) * -(-N // 64)
+        yn = packing.linear(x, p, path="gemm8n_slices" if t64 <= 64 else "gemm8n_split")
+        if t64 <= 64 or K >= 4096:                               # (stream-K: the dispatch splits only where that pays)
+            assert torch.equal(yn, y)
+        assert ((y.float() - yn.float()).abs().max() / r.abs().max()).item() <= REL_TOL
     elif layout == "mixed" and tiles <= 176:
         assert torch.equal(packing.linear(x, p, path="gemm8h_slices" if tiles <= 64 else "gemm8h"), y)
         ym = packing.linear(x, p, path="midm")           # the neighbour it replaced here: equal up to summation order
