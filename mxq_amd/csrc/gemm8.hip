@@ -75,15 +75,17 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define G8_NAME(stem) mxq_##stem##gemm8h
 #elif MXQ_G8_BM == 128
 #define G8_NAME(stem) mxq_##stem##gemm8n
-#else
+#elif MXQ_G8_BN == 128
 #define G8_NAME(stem) mxq_##stem##gemm8q
+#else
+#define G8_NAME(stem) mxq_##stem##gemm8m
 #endif
 #define G8_CAT_(a, b) a##b
 #define G8_CAT(a, b) G8_CAT_(a, b)
 #define G8_SYM(stem, suffix) G8_CAT(G8_NAME(stem), suffix)
 #define G8_KERNEL G8_SYM(, _f16_kernel)
 constexpr int BM = MXQ_G8_BM, BN = MXQ_G8_BN, BK = 64;
-static_assert(BN == 128 || (BN == 64 && BM == 128), "tile width");
+static_assert(BN == 128 || (BN == 64 && BM <= 128), "tile width");
 static_assert(BM == 256 || BM == 128 || BM == 64, "tile height");
 // Dequant waves: a thread converts one PART of one row of the 128 x 64 weight tile per K-step.  256-token tile: 4 waves,
 // parts = column halves (32 weights).  128-token tile: the MFMA side of a K-step is half as long, and the MFMA waves were
@@ -95,7 +97,7 @@ static_assert(BM == 256 || BM == 128 || BM == 64, "tile height");
 // MFMA waves: a WGM (tokens) x WGN (channels) grid of sub-tiles of 16 NJ tokens x 64 channels.  128-channel tiles: 64 x 64
 // sub-tiles, 2 waves across the channels; the 64-channel tile (gemm8n.hip: 128 x 64, for launches whose fp32 partial tiles are
 // the cost) has one wave across and four of 32 x 64 down the tokens.
-constexpr int WGN = BN / 64, N_MMA = BM == 128 && BN == 64 ? 4 : BM / 32, WGM = N_MMA / WGN;
+constexpr int WGN = BN / 64, N_MMA = BM / 32, WGM = N_MMA / WGN;
 constexpr int NJ = BM / (16 * WGM);           // 16-token blocks per MFMA wave (4 | 2)
 constexpr int FRAGS = 4 * NJ;                 // accumulator fragments per MFMA wave: f = i * NJ + j (W block i, token block j)
 constexpr int WSLOT = FRAGS * 1024;           // bytes of a wave's share of a partial-tile slot (16 B per lane and fragment)
