@@ -108,8 +108,8 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * for the mid-M kernel's partial tiles hands 41..256 tokens to the prefill kernel.
  * The tail is only split where that pays (about 20 idle K-steps per CU: for 256 < M <= 1024 on the Llama shapes and for
  * gate/up at M = 2048).  Beyond 64 tokens, launches of up to 176 tiles of 128 x 128 run the same kernel built with a
- * 128-token tile (csrc/gemm8h.hip): up to 64 tiles (e.g. 4096^2 at 65-256 tokens) with K cut into one slice per idle CU, fp32
- * slabs in the workspace beyond its first 64 KiB and a combine launch; 65..176 tiles (gate/up at 65-256 tokens, 4096^2 at
+ * 128-token tile (csrc/gemm8h.hip; csrc/gemm8n.hip, a 128 x 64 tile, where K <= 6144): up to 64 tiles (e.g. 4096^2 at 65-256
+ * tokens) with K cut into one slice per idle CU, fp32 slabs in the workspace beyond its first 64 KiB and a combine launch; 65..176 tiles (gate/up at 65-256 tokens, 4096^2 at
  * 257-640) in one launch, stream-K over the otherwise idle CUs.  Up to 64 tokens, launches of 65..176 tiles of 64 x 128
  * (gate/up) run its 64-token build (csrc/gemm8q.hip) the same way.
  * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 8 = the
@@ -118,6 +118,7 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * 10 = the mid-M split-K kernel (csrc/midm.hip) at any M, 12 / 13 = the fused kernel's 128-token build (csrc/gemm8h.hip)
  * at any M, splitting its tail where that pays / whenever possible, 14 = the same in slices mode (K slices + combine launch);
  * 16 / 17 = the 64-token build (csrc/gemm8q.hip) with its tail always split / in slices mode;
+ * 20 / 21 = the 128 x 64-tile build (csrc/gemm8n.hip) likewise;
  * anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
  * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
  * used by tools/ alone: they are not part of this ABI.) */
