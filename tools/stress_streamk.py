@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Endurance / fuzz run of every split-K schedule the library ships (GPU box): random (tokens, out, in) shapes, layouts and paths
--- the 256- / 128- / 64-token builds of the fused kernel with their stream-K tail forced or chosen, the slices modes, the mid-M
+-- the 256 x 128 / 128 x 128 / 128 x 64 / 64 x 128 builds of the fused kernel with their stream-K tail forced or chosen, the slices modes, the mid-M
 kernel, the product dispatch -- each result against the fp32 product on the bit-exact dequantised weight, launched twice for
 bit-identical output, the workspace's counter head checked to be zero again.  A progress line every 50 cases.
 
@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mxq_amd import packing  # noqa: E402
 
-PATHS = ["auto", "gemm8", "gemm9", "gemm8h", "gemm8h_split", "gemm8h_slices", "gemm8q_split", "gemm8q_slices", "midm"]
+PATHS = ["auto", "gemm8", "gemm9", "gemm8h", "gemm8h_split", "gemm8h_slices", "gemm8q_split", "gemm8q_slices", "gemm8n_split",
+         "gemm8n_slices", "midm"]
 
 
 def main():
