@@ -20,9 +20,10 @@ if [ -d gpurun_out/${T}_midm_trace ]; then
     echo "# plus, by design, S x 2 MB of fp32 partial tiles written by the main kernel and read back by the combine kernel (S = 8 slices at 128 tokens)"
     python3 tools/pmc_summary.py gpurun_out/${T}_midm_FETCH_SIZE midm; python3 tools/pmc_summary.py gpurun_out/${T}_midm_WRITE_SIZE midm; python3 tools/pmc_summary.py gpurun_out/${T}_midm_sq midm
     if [ -d gpurun_out/${T}_g8hs_FETCH_SIZE ]; then
-      echo "# the product dispatch's path at this shape since round 4 (capi.hip gemm8h_mode): csrc/gemm8h.hip in slices mode (32 tiles x 8 K-slices) + mxq_gemm8h_combine_kernel;"
-      echo "# tools/gemm_prof.py gemm8h_slices 128 4096 4096 8 -- the 8 x 2 MB of fp32 slabs are written by the first launch and read by the second, as in the mid-M kernel"
-      python3 tools/pmc_summary.py gpurun_out/${T}_g8hs_FETCH_SIZE gemm8h; python3 tools/pmc_summary.py gpurun_out/${T}_g8hs_WRITE_SIZE gemm8h; python3 tools/pmc_summary.py gpurun_out/${T}_g8hs_sq gemm8h
+      echo "# the product dispatch's path at this shape since round 4 (capi.hip small_tile_launch): csrc/gemm8n.hip (128 x 64 tile) in slices mode (64 tiles x 4 K-slices) + mxq_gemm8n_combine_kernel;"
+      echo "# tools/gemm_prof.py gemm8n_slices 128 4096 4096 8 (what path auto runs at this shape) -- 4 x 2 MB of fp32 slabs are written by the first launch and read by the second (the mid-M kernel and the 128 x 128 tile: 8 x 2 MB)"
+      python3 tools/pmc_summary.py gpurun_out/${T}_g8hs_FETCH_SIZE gemm8n; python3 tools/pmc_summary.py gpurun_out/${T}_g8hs_WRITE_SIZE gemm8n; python3 tools/pmc_summary.py gpurun_out/${T}_g8hs_sq gemm8n
+      echo "# => HBM-side bytes per call: main (2 x 5888 + 8192) KiB + combine (2 x 4119 + 1027) KiB = 29.2 MB for 11.3 MB algorithmic = 2.6 x (mid-M kernel and 128 x 128 tile: 4.0 x)"
     fi; } > profiles/${P}_midm_pmc.txt
 fi
 python3 - <<PY

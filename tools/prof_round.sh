@@ -29,11 +29,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_midm_${c} -- python3 $R/tools/gemm_prof.py midm 128 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
 done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${TAG}_midm_sq -- python3 $R/tools/gemm_prof.py midm 128 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
-# the dispatch's own path at that shape since round 4: the fused kernel's 128-token build in slices mode + its combine launch
+# the dispatch's own path at that shape since round 4 (path auto): the fused kernel's 128 x 64-tile build in slices mode + its combine launch
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_g8hs_${c} -- python3 $R/tools/gemm_prof.py gemm8h_slices 128 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_g8hs_${c} -- python3 $R/tools/gemm_prof.py gemm8n_slices 128 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${TAG}_g8hs_sq -- python3 $R/tools/gemm_prof.py gemm8h_slices 128 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/${TAG}_g8hs_sq -- python3 $R/tools/gemm_prof.py gemm8n_slices 128 4096 4096 8 > /dev/null 2>> $OUT/${TAG}_pmc.err
 echo "midm done"
 # BASELINE configs[4] arms at M = 32768: FETCH / WRITE / MFMA-busy per weight layout (4096^2 Linear)
 for lay in mixed w2g16 w4row; do
