@@ -1260,8 +1260,7 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     // 32-bit offsets: 256 rows of x per DMA descriptor; the whole packed weight behind one (offsets < 2^31)
     if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(N / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 31))
         return -1;   // MXQ_E_SHAPE
-    hipError_t e = hipFuncSetAttribute((const void*)G8_KERNEL<ABL, LAYOUT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipError_t e = mxq_set_dyn_lds_once<&G8_KERNEL<ABL, LAYOUT>>(SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
     const int NT = K / BK;
@@ -1319,7 +1318,7 @@ static int launch8_slices(const void* x, const void* qweight, const void* rowmet
     if (M <= 0 || N <= 0 || K < BK || K % BK != 0 || N % 16 != 0) return -1;
     if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(N / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 31))
         return -1;
-    hipError_t e = hipFuncSetAttribute((const void*)G8_KERNEL<0, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipError_t e = mxq_set_dyn_lds_once<&G8_KERNEL<0, LAYOUT>>(SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
     float* slab = (float*)((char*)workspace + CNT_BYTES);
     G8_KERNEL<0, LAYOUT><<<tiles * S, THREADS, SMEM_BYTES, stream>>>(

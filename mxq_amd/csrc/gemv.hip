@@ -343,8 +343,8 @@ int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, i
     const size_t smem = (size_t)MB * K * 2 + (size_t)MB * (K / 16) * 4 + (size_t)RB * W * MB * 16 * 3 * 4 + (size_t)W * 4 +
                         64 * 32 + 64 * 4;
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT, RB>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        // (the attribute is a ceiling: the CU's whole LDS, set once per kernel and device)
+        hipError_t e = mxq_set_dyn_lds_once<&mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT, RB>>(160 * 1024);
         if (e != hipSuccess) return (int)e;
     }
     const int rbs = N / 16;

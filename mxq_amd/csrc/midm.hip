@@ -478,8 +478,7 @@ int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, i
     int cps = (NC + S - 1) / S;
     cps += cps & 1;                                   // whole double-steps
     S = (NC + cps - 1) / cps;                         // no empty slice
-    hipError_t e = hipFuncSetAttribute((const void*)mxq_midm_f16_kernel<BM, COMPACT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+    hipError_t e = mxq_set_dyn_lds_once<&mxq_midm_f16_kernel<BM, COMPACT>>(G::SMEM);
     if (e != hipSuccess) return (int)e;
     float* part = S > 1 ? (float*)((char*)workspace + WS_HEAD) : nullptr;
     mxq_midm_f16_kernel<BM, COMPACT><<<tiles * S, THREADS, G::SMEM, stream>>>(

@@ -61,6 +61,25 @@ int mxq_launch_gemm8n_slices_f16(const void* x, const void* qweight, const void*
 // internal "take the other kernel" return of a launcher that declines a shape (never leaves capi.hip; distinct from
 // every MXQ_E_* code and every hipError_t)
 #define MXQ_NOT_MY_SHAPE (-1000)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) ONCE per (kernel, device) instead of in front of every launch: a call of the
+// small-token paths is 7-16 us of GPU time and was 13-16 us of host time (tools/: host issue per call), so the host side counts.
+// One process may drive several devices (device_map-style callers): the flag is a bit per device ordinal.
+#ifdef __HIPCC__
+#include <atomic>
+template <auto Kernel>
+inline hipError_t mxq_set_dyn_lds_once(int bytes) {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63)
+        return hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    const unsigned long long bit = 1ull << dev;
+    if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+    return e;
+}
+#endif
 // the same product with a 256 x 256 tile and a quadrant-phase ping-pong schedule (dense256.hip); MXQ_NOT_MY_SHAPE: odd
 // K-tile count, or -- unless force -- too few tiles to fill the chip twice: take the kernel above
 int mxq_launch_dense256_f16(const void* x, const void* w16, void* y, int M, int N, int K, int force, hipStream_t stream);

@@ -29,6 +29,24 @@ def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def _on_device(device: torch.device):
+    """Context that makes `device` current for a launch -- nothing at all when it already is (the usual case: one process
+    per GPU; torch.cuda.device() costs ~4 us of host time per call, a third of a small-token Linear's)."""
+    idx = device.index
+    return _NOCTX if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(device)
+
+
 _WORKSPACES: Dict[tuple, torch.Tensor] = {}
 _WS_EAGER: Dict[tuple, bool] = {}    # key -> the counter head has been zeroed (eagerly, or by a memset recorded in its graph)
 _WS_HEAD = 65536      # bytes of K-step counters at the head of a workspace (include/mxq_hip.h)
@@ -132,7 +150,7 @@ def linear_hoisted(x: torch.Tensor, p, out: Optional[torch.Tensor] = None) -> to
         return out.reshape(*x.shape[:-1], p.N)
     lib = _lib.load()
     scratch = hoist_scratch(x2.device, lib.mxq_hoist_scratch_bytes(p.N, p.K))
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         _lib.check(lib.mxq_linear_f16_hoisted(x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(),
                                               M, p.N, p.K, _layout_code(p), scratch.data_ptr(), scratch.numel(),
                                               _stream(x2)), "mxq_linear_f16_hoisted")
@@ -210,7 +228,7 @@ def compact(p: PackedMXQ) -> PackedMXQ:
     lib = _lib.load()
     nbytes = lib.mxq_qweight_bytes_layout(p.N, p.K, 3)
     q = torch.empty(nbytes // 4, dtype=torch.int32, device=p.device)
-    with torch.cuda.device(p.device):
+    with _on_device(p.device):
         _lib.check(lib.mxq_compact(p.qweight.data_ptr(), q.data_ptr(), p.N, p.K, _stream(q)), "mxq_compact")
     return PackedMXQ(q, p.rowmeta, p.N, p.K, True)
 
@@ -242,7 +260,7 @@ def quantize_pack(W: torch.Tensor, dead: Optional[torch.Tensor] = None, compact_
         dead_p = dead.data_ptr()
     lib = _lib.load()
     p = _alloc(N, K, W.device)
-    with torch.cuda.device(W.device):
+    with _on_device(W.device):
         _lib.check(lib.mxq_quantize_pack(W.data_ptr(), _TORCH2CODE[W.dtype], dead_p, p.qweight.data_ptr(),
                                          p.rowmeta.data_ptr(), N, K, _stream(W)), "mxq_quantize_pack")
     return compact(p) if compact_meta else p
@@ -270,7 +288,7 @@ def pack_codes(params: Dict[str, torch.Tensor], N: int, K: int) -> PackedMXQ:
         ts.append(t.contiguous())
     lib = _lib.load()
     p = _alloc(N, K, ts[0].device)
-    with torch.cuda.device(p.device):
+    with _on_device(p.device):
         _lib.check(lib.mxq_pack_codes(*[t.data_ptr() for t in ts], p.qweight.data_ptr(), p.rowmeta.data_ptr(), N, K,
                                       _stream(p.qweight)), "mxq_pack_codes")
     return p
@@ -282,7 +300,7 @@ def unpack(p: PackedMXQ) -> Dict[str, torch.Tensor]:
     out = {k: torch.empty(shape, dtype=dt, device=p.device) for k, (shape, dt) in _param_shapes(p.N, p.K).items()}
     lib = _lib.load()
     fn = lib.mxq_unpack_compact if p.compact else lib.mxq_unpack
-    with torch.cuda.device(p.device):
+    with _on_device(p.device):
         _lib.check(fn(p.qweight.data_ptr(), p.rowmeta.data_ptr(), *[out[k].data_ptr() for k in PARAM_KEYS],
                       p.N, p.K, _stream(p.qweight)), "mxq_unpack")
     return out
@@ -294,7 +312,7 @@ def dequant(p: PackedMXQ) -> torch.Tensor:
     out = torch.empty((p.N, p.K), dtype=torch.float16, device=p.device)
     lib = _lib.load()
     fn = lib.mxq_dequant_f16_compact if p.compact else lib.mxq_dequant_f16
-    with torch.cuda.device(p.device):
+    with _on_device(p.device):
         _lib.check(fn(p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), p.N, p.K, _stream(out)),
                    "mxq_dequant_f16")
     return out
@@ -323,7 +341,7 @@ def linear_dense(x: torch.Tensor, w16: torch.Tensor, out: Optional[torch.Tensor]
     elif out.shape != (M, N) or out.dtype != torch.float16 or not out.is_contiguous():
         raise ValueError("out must be a contiguous float16 [tokens, out_features] tensor")
     if M:
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             _lib.check(_lib.load().mxq_dense_f16(x2.data_ptr(), w16.data_ptr(), out.data_ptr(), M, N, K,
                                                  DENSE_VARIANTS[variant], _stream(x2)), f"mxq_dense_f16[{variant}]")
     return out.reshape(*x.shape[:-1], N)
@@ -371,7 +389,7 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         # (counters: any non-hoisted launch beyond the skinny kernel's range may be a stream-K one -- the library decides)
         ws = gemm_workspace(x2.device, counters=not hoists)
         scratch = hoist_scratch(x2.device, lib.mxq_hoist_scratch_bytes(p.N, p.K)) if hoists else None
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             _lib.check(lib.mxq_linear_f16_auto(*args, _layout_code(p), ws.data_ptr(), ws.numel(),
                                                scratch.data_ptr() if scratch is not None else None,
                                                scratch.numel() if scratch is not None else 0, _stream(x2)),
@@ -380,22 +398,22 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
     if path == "gemm" and M >= HOIST_MIN_TOKENS:
         return linear_hoisted(x, p, out=out)
     if path == "skinny":
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             _lib.check(lib.mxq_skinny_f16(*args, 3 if p.compact else 0, _stream(x2)), "mxq_skinny_f16")
         return out.reshape(*x.shape[:-1], p.N)
     if path == "whole":   # the fused prefill kernel on whole tiles only (no workspace: no stream-K split, so a tile's sums
         #                   do not depend on the launch's token count: tests compare launches of different sizes bit for bit)
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             _lib.check(lib.mxq_gemm_f16_layout(*args, _layout_code(p), _stream(x2)), "mxq_gemm_f16_layout[whole]")
         return out.reshape(*x.shape[:-1], p.N)
     if p.compact:      # compact metadata: the layout entry points (same kernels, other field offsets)
         if path not in ("auto", "gemm", "gemv", "gemm8", "fused"):
             raise ValueError(f"path {path!r} is not available for compact metadata")
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             fn = lib.mxq_gemv_f16_layout if path == "gemv" or (path == "auto" and M <= 4) else lib.mxq_gemm_f16_layout
             _lib.check(fn(*args, 3, _stream(x2)), f"mxq_linear_f16[{path}, compact]")
         return out.reshape(*x.shape[:-1], p.N)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         if path == "gemv":
             rc = lib.mxq_gemv_f16(*args, _stream(x2))
         elif path == "auto" and M <= 4:                          # GEMV: no workspace involved
@@ -432,7 +450,7 @@ def linear_fused(x: torch.Tensor, p: PackedMXQ, prologue: int = 0, norm_w: Optio
     out = torch.empty((1, p.N), dtype=torch.float16, device=x.device)
     lib = _lib.load()
     fused = lib.mxq_gemv_fused_f16_compact if p.compact else lib.mxq_gemv_fused_f16
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         _lib.check(fused(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(),
                          p.N, p.K, int(prologue), norm_w.data_ptr() if norm_w is not None else None,
                          float(eps), residual.contiguous().data_ptr() if residual is not None else None,
@@ -477,7 +495,7 @@ def quantize_pack_uniform(W: torch.Tensor, layout: str) -> PackedUniform:
     nbytes = lib.mxq_qweight_bytes_layout(N, K, LAYOUTS[layout])
     p = PackedUniform(torch.empty(nbytes // 4, dtype=torch.int32, device=W.device),
                       torch.empty((N, 4), dtype=torch.float32, device=W.device), N, K, layout)
-    with torch.cuda.device(W.device):
+    with _on_device(W.device):
         _lib.check(lib.mxq_quantize_pack_layout(W.data_ptr(), _TORCH2CODE[W.dtype], p.qweight.data_ptr(),
                                                 p.rowmeta.data_ptr(), N, K, LAYOUTS[layout], _stream(W)),
                    "mxq_quantize_pack_layout")
@@ -530,7 +548,7 @@ def linear_layout(x: torch.Tensor, p, out: Optional[torch.Tensor] = None, path: 
         return linear_hoisted(x, p, out=out)
     lib = _lib.load()
     args = (x2.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), out.data_ptr(), M, p.N, p.K, layout)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         if path == "auto" and M > 4:        # the library's own dispatch: skinny kernel / fused prefill GEMM / hoisted mode
             hoists = M >= HOIST_MIN_TOKENS
             ws = gemm_workspace(x2.device, counters=not hoists)
