@@ -74,7 +74,7 @@ def _capture_id(stream_handle: int) -> int:
     return int(cid.value)
 
 
-def gemm_workspace(device: torch.device, counters: bool = True) -> torch.Tensor:
+def gemm_workspace(device: torch.device, counters: bool = True, stream: Optional[int] = None) -> torch.Tensor:
     """Scratch buffer of the stream-K prefill GEMM and of the mid-M kernel's partial tiles (include/mxq_hip.h:
     mxq_linear_f16_ws).  Its counter head must be zero when a stream-K launch starts; the kernels leave it zeroed.
 
@@ -91,7 +91,8 @@ def gemm_workspace(device: torch.device, counters: bool = True) -> torch.Tensor:
     ``counters=False``: the caller's kernel uses the buffer beyond the head only (the mid-M kernel's partial tiles):
     no memset is recorded for it."""
     dev_index = device.index if device.index is not None else torch.cuda.current_device()
-    stream = torch.cuda.current_stream(device).cuda_stream
+    if stream is None:                      # (callers on the hot path pass the handle they already hold)
+        stream = torch.cuda.current_stream(device).cuda_stream
     capturing = torch.cuda.is_current_stream_capturing()
     key = (dev_index, "capture", _capture_id(stream)) if capturing else (dev_index, stream)
     ws = _WORKSPACES.get(key)
@@ -370,7 +371,8 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         raise ValueError(f"in_features mismatch: x has {x.shape[-1]}, weight has {p.K}")
     if x.device != p.device:
         raise ValueError("x and the packed weight live on different devices")
-    x2 = x.reshape(-1, p.K).contiguous()
+    flat = x.dim() == 2 and x.is_contiguous()          # (the usual call: no view objects made on the way in or out)
+    x2 = x if flat else x.reshape(-1, p.K).contiguous()
     M = x2.shape[0]
     if out is None:
         out = torch.empty((M, p.N), dtype=torch.float16, device=x.device)
@@ -387,14 +389,15 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         # prefill kernel with its stream-K tail / hoisted-dequant mode, chosen inside the library by token count
         hoists = M >= HOIST_MIN_TOKENS
         # (counters: any non-hoisted launch beyond the skinny kernel's range may be a stream-K one -- the library decides)
-        ws = gemm_workspace(x2.device, counters=not hoists)
+        st = _stream(x2)
+        ws = gemm_workspace(x2.device, counters=not hoists, stream=st)
         scratch = hoist_scratch(x2.device, lib.mxq_hoist_scratch_bytes(p.N, p.K)) if hoists else None
         with _on_device(x.device):
             _lib.check(lib.mxq_linear_f16_auto(*args, _layout_code(p), ws.data_ptr(), ws.numel(),
                                                scratch.data_ptr() if scratch is not None else None,
-                                               scratch.numel() if scratch is not None else 0, _stream(x2)),
+                                               scratch.numel() if scratch is not None else 0, st),
                        "mxq_linear_f16_auto")
-        return out.reshape(*x.shape[:-1], p.N)
+        return out if flat else out.reshape(*x.shape[:-1], p.N)
     if path == "gemm" and M >= HOIST_MIN_TOKENS:
         return linear_hoisted(x, p, out=out)
     if path == "skinny":
