@@ -1203,10 +1203,12 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
 
 // slices mode, second launch: y = the S slabs of every tile summed in slice order (from +0: fixed).  One wave per (tile,
 // producing wave, token block): the slabs' four fragments of up to four slices in flight together, then the fp16 block.
-__global__ __launch_bounds__(64) void G8_SYM(, _combine_kernel)(const float* __restrict__ slab, uint16_t* __restrict__ y, int M,
+__global__ __launch_bounds__(256) void G8_SYM(, _combine_kernel)(const float* __restrict__ slab, uint16_t* __restrict__ y, int M,
                                                                 int N, int tiles_m, int tiles_n, int S) {
-    const int lane = threadIdx.x;
-    const int tile = blockIdx.x / (N_MMA * NJ), rem = blockIdx.x % (N_MMA * NJ);
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= tiles_m * tiles_n * N_MMA * NJ) return;
+    const int tile = task / (N_MMA * NJ), rem = task % (N_MMA * NJ);
     const int ws = rem / NJ, jj = rem % NJ;
     int tm, tn;
     tile_of_block(tile, tiles_m, tiles_n, tm, tn);
@@ -1324,7 +1326,7 @@ static int launch8_slices(const void* x, const void* qweight, const void* rowmet
     G8_KERNEL<0, LAYOUT><<<tiles * S, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n, 0, 0,
         -S, 0, slab, nullptr);
-    G8_SYM(, _combine_kernel)<<<tiles * N_MMA * NJ, 64, 0, stream>>>(slab, (uint16_t*)y, M, N, tiles_m, tiles_n, S);
+    G8_SYM(, _combine_kernel)<<<(tiles * N_MMA * NJ + 3) / 4, 256, 0, stream>>>(slab, (uint16_t*)y, M, N, tiles_m, tiles_n, S);
     return (int)hipGetLastError();
 }
 
