@@ -125,9 +125,10 @@ def test_dense256_pair_loop_is_the_designed_schedule():
     assert not [l for l in inner if re.match(r"\s+v_(?!mfma)", l)], "VALU work (accumulator copies?) inside the pair loop"
 
 
-@pytest.mark.parametrize("src", ["gemm.hip", "gemm8.hip", "dense256.hip", "midm.hip", "gemv.hip", "skinny.hip", "fakequant.hip", "actquant.hip", "pack.hip"])
+@pytest.mark.parametrize("src", ["gemm.hip", "gemm8.hip", "gemm8h.hip", "gemm8n.hip", "gemm8q.hip", "dense256.hip", "midm.hip", "gemv.hip",
+                                 "skinny.hip", "fakequant.hip", "actquant.hip", "pack.hip"])
 def test_no_spills_no_scratch(src):
-    s = _asm(src, *(["-fno-slp-vectorize"] if src == "gemm8.hip" else []))     # the Makefile's per-file flag
+    s = _asm(src, *(["-fno-slp-vectorize", "-I" + CSRC] if src.startswith("gemm8") else []))     # the Makefile's per-file flag
     for m in re.finditer(r"\.vgpr_spill_count:\s+(\d+)", s):
         assert int(m.group(1)) == 0
     for m in re.finditer(r"\.private_segment_fixed_size:\s+(\d+)", s):
