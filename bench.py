@@ -135,31 +135,118 @@ def cpu_baseline(dev, budget_s=12.0):
                       "(4.295 GFLOP), median of the calls that fit ~12 s; the GPU runs the same call on the same inputs"}
 
 
-def long_prefill(layers, dev, tokens=32768, iters=3):
-    """Side figure, not `value`: BASELINE configs[4]'s shape -- ONE decoder layer's seven Linears at batch 8 x seq 4096
-    (32768 tokens per launch), where the dispatch hoists the dequant (dequant pass + csrc/dense256.hip inside every timed
-    launch).  HIP events around `iters` passes over the layer after one untimed pass."""
-    lin = layers[0]
-    g = torch.Generator(device=dev).manual_seed(11)
-    xs = {K: torch.randn(tokens, K, generator=g, device=dev).half() for K in (LS.HIDDEN, LS.INTERMEDIATE)}
-    ys = {N: torch.empty(tokens, N, device=dev, dtype=torch.float16) for N in (LS.HIDDEN, LS.INTERMEDIATE)}
+PEAK_HBM_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches)
 
-    def layer():
-        for _name, p in lin:
-            packing.linear(xs[p.K], p, out=ys[p.N], path="gemm")
-    layer()
-    torch.cuda.synchronize()
+
+def _events_ms(fn, iters):
+    """ms per call of `fn` over `iters` back-to-back calls between two HIP events on the launch stream."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        layer()
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    fl = sum(2.0 * tokens * p.N * p.K for _n, p in lin)
-    return {"workload": f"BASELINE configs[4] shape: one decoder layer (7 Linears), {tokens} tokens per launch, mixed 2/4-bit, "
-                        "hoisted-dequant mode (dequant pass inside the timed launches)",
-            "layer_ms": round(ms, 3), "TFLOPs": round(fl / ms / 1e9, 1), "mfma_frac": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4)}
+    return e0.elapsed_time(e1) / iters
+
+
+def decode_1gpu(dev, tokens=64, ctx=512):
+    """Side figure, not `value`: BASELINE configs[2] on ONE GPU -- greedy decode, batch 1, all 32 layers, hipGraph token
+    loop (mxq_amd/llama_decode.py), in both metadata modes.  Bytes = the packed weights a token streams (codes + group
+    metadata + row metadata of the 224 Linears; lm_head, KV cache and activations not counted): the HBM roofline's
+    algorithmic bytes per token.  The dominant kernels are the streaming GEMVs (csrc/gemv.hip,
+    csrc/decode_layer.hip)."""
+    from mxq_amd.llama_decode import decode_pipeline_figure
+    out = {"workload": f"BASELINE configs[2] on one GPU: Llama-2-7B W2/4A16 greedy decode, batch 1, {tokens} tokens from position 0 "
+                       f"(KV cache of {ctx}), hipGraph token loop; bytes = packed weight bytes per token",
+           "peak_GBps": PEAK_HBM_GBPS}
+    for mode, compact in (("exact", False), ("compact", True)):
+        fig = decode_pipeline_figure(LayerPipeline(0, 1), dev, tokens=tokens, ctx=ctx, compact=compact)
+        out[mode] = {"tokens_per_s": fig["tokens_per_s"], "ms_per_token": fig["ms_per_token"],
+                     "packed_weight_GB_per_token": fig["packed_weight_GB_per_token"],
+                     "GBps": fig["weight_stream_GBps"], "frac": round(fig["weight_stream_GBps"] / PEAK_HBM_GBPS, 4),
+                     "launches_per_layer": fig.get("launches_per_layer"), "us_per_layer": round(fig["ms_per_token"] * 1e3 / LS.N_LAYERS, 2),
+                     "first_tokens": fig["first_tokens"]}
+        torch.cuda.empty_cache()
+    return out
+
+
+def fakequant_block(dev, iters=10):
+    """Side figure, not `value`: BASELINE configs[3] -- MXAsymQuantizer forward and STE backward (csrc/fakequant.hip) over
+    the 7 weights of one decoder block in bf16, one launch per weight, HIP events around `iters` passes over the block.
+    Algorithmic bytes: forward reads + writes every element (4 B), backward reads grad and weight and writes grad (6 B)."""
+    from mxq_amd.utils_quant import mx_fake_quant, ste_clip_backward
+    g = torch.Generator(device=dev).manual_seed(3)
+    ws = [(torch.randn(N, K, generator=g, device=dev) * 0.02).bfloat16() for _n, N, K in LS.LAYER_LINEARS]
+    gs = [torch.randn(w.shape, generator=g, device=dev).bfloat16() for w in ws]
+    n = sum(w.numel() for w in ws)
+
+    def fwd():
+        for w in ws:
+            mx_fake_quant(w, 2)
+
+    def bwd():
+        for go, w in zip(gs, ws):
+            ste_clip_backward(go, w, -2.0, 2.0)
+    fwd(); bwd()
+    torch.cuda.synchronize()
+    f_us, b_us = _events_ms(fwd, iters) * 1e3, _events_ms(bwd, iters) * 1e3
+    return {"workload": "BASELINE configs[3]: MXAsymQuantizer fwd + STE bwd over one decoder block's 7 weights "
+                        f"({n} elements), bf16, w_bits 2, one launch per weight",
+            "fwd_us": round(f_us, 1), "bwd_us": round(b_us, 1),
+            "fwd_GBps": round(4.0 * n / f_us / 1e3, 1), "bwd_GBps": round(6.0 * n / b_us / 1e3, 1),
+            "fwd_frac": round(4.0 * n / f_us / 1e3 / PEAK_HBM_GBPS, 4), "bwd_frac": round(6.0 * n / b_us / 1e3 / PEAK_HBM_GBPS, 4),
+            "peak_GBps": PEAK_HBM_GBPS, "kernels": "mxq_fakequant_fwd_* / mxq_fakequant_bwd_kernel"}
+
+
+def config5(dev, tokens=32768, iters=3):
+    """Side figure, not `value`: BASELINE configs[4] -- uniform W2 (group 16), uniform W4 (per row) and the mixed 2/4 layout
+    on one decoder layer's 7 Linears.  Prefill leg: batch 8 x seq 4096 = `tokens` tokens per launch through the product
+    dispatch (hoisted-dequant mode at this size: dequant pass + csrc/dense256.hip inside every timed launch) -> TFLOP/s and
+    fraction of the fp16 MFMA peak.  Decode leg: ONE token through the same 7 Linears (streaming GEMV), replayed from a
+    hipGraph over >= 600 MB of distinct copies of the layer so that every launch streams from HBM -> GB/s of packed bytes and
+    fraction of the HBM peak."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    Ws = [(torch.randn(N, K, generator=g, device=dev) * 0.02).half() for _n, N, K in LS.LAYER_LINEARS]
+    xs = {K: torch.randn(tokens, K, generator=g, device=dev).half() for K in (LS.HIDDEN, LS.INTERMEDIATE)}
+    ys = {N: torch.empty(tokens, N, device=dev, dtype=torch.float16) for N in (LS.HIDDEN, LS.INTERMEDIATE)}
+    x1 = {K: xs[K][:1].contiguous() for K in xs}
+    y1 = {N: torch.empty(1, N, device=dev, dtype=torch.float16) for N in ys}
+    fl = 2.0 * tokens * LS.PARAMS_PER_LAYER
+    out = {"workload": f"BASELINE configs[4]: W2A16 (group 16) vs W4A16 (per row) vs mixed 2/4 on one decoder layer's 7 Linears; "
+                       f"prefill leg {tokens} tokens per launch, decode leg 1 token per launch", "arms": {}}
+    for arm in ("w2g16", "w4row", "mixed"):
+        lin = [packing.quantize_pack(W) if arm == "mixed" else packing.quantize_pack_uniform(W, arm) for W in Ws]
+
+        def layer():
+            for p in lin:
+                packing.linear_layout(xs[p.K], p, out=ys[p.N], path="auto")
+        layer()
+        torch.cuda.synchronize()
+        ms = _events_ms(layer, iters)
+        nbytes = sum(p.nbytes() for p in lin)
+        copies = [lin] + [[type(p)(p.qweight.clone(), p.rowmeta.clone(), *((p.N, p.K, p.layout) if arm != "mixed" else (p.N, p.K)))
+                           for p in lin] for _ in range(int(600e6 / nbytes))]
+
+        def tokens1():
+            for c in copies:
+                for p in c:
+                    packing.linear_layout(x1[p.K], p, out=y1[p.N], path="auto")
+        tokens1()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            tokens1()
+        gr.replay()
+        torch.cuda.synchronize()
+        us = _events_ms(gr.replay, 5) * 1e3 / len(copies)       # per layer (7 launches)
+        out["arms"][arm] = {"bits_per_weight": round(8.0 * nbytes / LS.PARAMS_PER_LAYER, 3),
+                            "prefill": {"layer_ms": round(ms, 3), "TFLOPs": round(fl / ms / 1e9, 1),
+                                        "mfma_frac": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4)},
+                            "decode_M1": {"layer_us": round(us, 2), "packed_MB": round(nbytes / 1e6, 2),
+                                          "GBps": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4)}}
+        del copies, gr, lin
+        torch.cuda.empty_cache()
+    return out
 
 
 def fused_launch_figure(layers, dev, x_h, x_i, y_h, steps=5):
@@ -371,7 +458,13 @@ def main():
             out["decode_pipeline"] = decode_fig
         if world == 1 and not args.fuse and not args.headline_only:
             out["fused_launches_figure"] = fused_launch_figure(layers, dev, x_h, x_i, y_h)
-            out["long_prefill"] = long_prefill(layers, dev)
+            del layers
+            torch.cuda.empty_cache()
+            # the other BASELINE configs, each with its own roofline fraction (side figures; `value` is configs[1])
+            out["decode_1gpu"] = decode_1gpu(dev)              # configs[2] on one GPU (HBM-bound)
+            out["fakequant_block"] = fakequant_block(dev)      # configs[3] (HBM-bound)
+            out["config5"] = config5(dev)                      # configs[4] (MFMA-bound prefill leg, HBM-bound decode leg)
+            layers = []
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             out["cpu_baseline"] = cpu_baseline(dev)
         print(json.dumps(out), flush=True)

@@ -61,6 +61,7 @@ class DecodeStage:
         # fused: RMSNorm / SwiGLU / residual folded into the GEMV launches and one RoPE + cache-append
         # + attention kernel per layer (5 launches per layer); otherwise plain torch ops around 4 GEMVs
         self.fused = fused and self.hd == 128
+        self.launches_per_layer = 5 if self.fused else None     # q|k|v, attention, o, gate|up, down (else: torch ops around 4 GEMVs)
         self.w = []
         for li in self.layers:
             def mk(idx, N, K):
@@ -285,6 +286,7 @@ def decode_pipeline_figure(pipe, dev, tokens: int = 32, ctx: int = 64, layers: i
     toks = run(tokens)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    stage_launches = stage.launches_per_layer
     nbytes = torch.tensor([float(stage.packed_bytes())], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None and world > 1:
         dist.all_reduce(nbytes)
@@ -307,6 +309,6 @@ def decode_pipeline_figure(pipe, dev, tokens: int = 32, ctx: int = 64, layers: i
             "packed_weight_GB_per_token": round(nbytes.item() / 1e9, 3),
             "weight_stream_GBps": round(nbytes.item() / (dt / tokens) / 1e9, 1),
             "metadata_mode": "compact (fp16 zero-points)" if compact else "exact (fp32 zero-points)",
-            "hipgraph": bool(graph), "first_tokens": toks[:8], "token_ids": toks,
+            "hipgraph": bool(graph), "launches_per_layer": stage_launches, "first_tokens": toks[:8], "token_ids": toks,
             "backend": backend if world > 1 else None,
             "tokens_equal_single_process": equal, "first_mismatch": bad}
