@@ -392,6 +392,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    packing.workspace_status(dev)      # a stream-K wait that gave up in the timed region raises here (tiles would be NaN)
     bits_per_weight = sum(p.nbytes() for lin in layers for _, p in lin) * 8.0 / (LS.PARAMS_PER_LAYER * max(1, len(my_layers)))
     tokens_per_step = SEQ * n_micro
     flops_per_step = LS.linear_flops(SEQ) * n_micro                      # whole job
@@ -414,6 +415,15 @@ def main():
     # 32 greedy-decode tokens through the same layer pipeline, rank 0 re-decoding them in one process to compare the ids.
     # After the timed region; every rank runs it.
     census = rank_census(dev) if world > 1 else None
+    if census is not None and backend == "nccl" and (census["ranks_seen"] != world or census["distinct_devices"] != world):
+        # N ranks on fewer than N GPUs (or a rank missing) is not the N-GPU measurement the line would claim: fail loudly,
+        # on every rank, with a non-zero exit (the gloo rehearsal mode shares devices on purpose and is exempt)
+        if rank == 0:
+            print(f"bench.py: --gpus {world} under RCCL needs {world} ranks on {world} distinct devices, saw ranks_seen="
+                  f"{census['ranks_seen']} distinct_devices={census['distinct_devices']}: {census['ranks']}", file=sys.stderr, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        raise SystemExit(3)
     decode_fig = None
     if world > 1 and not args.no_decode_pipeline:
         from mxq_amd.llama_decode import decode_pipeline_figure

@@ -123,6 +123,24 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
  * used by tools/ alone: they are not part of this ABI.) */
 size_t mxq_gemm_workspace_bytes(void);
+/* A stream-K launch makes workgroups wait for other workgroups of the SAME launch (an owner for the lower-numbered units of
+ * its tile; in the all-contributors reduction, any contributor for any other).  That needs the launch's workgroups resident
+ * together -- the grid is at most one workgroup per CU -- so a stream-K launch must not share the device with another
+ * kernel that ALSO waits on its own unscheduled workgroups (two stream-K launches on two streams can starve each other;
+ * ordinary kernels only delay it).  Every wait is bounded (~4 M polls, seconds).  A wait that gives up is never silent:
+ * the tile (or token block) whose partial sums did not arrive is written as NaN, and the last four ints of the workspace's
+ * 64-KiB head become {code, tail-tile index, workgroup, count seen} (code 1: an owner's wait, 2: the all-contributors
+ * reduction's; 0: nothing happened).  After a non-zero code the counters are inconsistent: zero the head again before the
+ * workspace is reused.  mxq_workspace_status copies the four ints to `status4` (HOST memory) after synchronising `stream`
+ * -- the one entry point of this library that synchronises. */
+int mxq_workspace_status(const void* workspace, size_t workspace_bytes, int* status4, void* stream);
+/* Bytes of workspace the dispatch of mxq_linear_f16_auto can use for a call of this shape (0: it never touches one --
+ * GEMV, skinny kernel, or, with `hoisting` != 0, the hoisted mode from mxq_hoist_min_tokens() tokens on); at most
+ * mxq_gemm_workspace_bytes().  For callers that own one workspace per captured graph.  Host-only helper. */
+size_t mxq_linear_workspace_need(int M, int N, int K, int layout, int hoisting);
+/* hipStreamGetCaptureInfo through this library's HIP runtime: *active = 1 and *id = the capture sequence's id while
+ * `stream` is being captured, else *active = 0, *id = 0.  Host-only helper (no device work). */
+int mxq_stream_capture_id(void* stream, int* active, unsigned long long* id);
 int mxq_linear_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                       void* workspace, size_t workspace_bytes, void* stream);
 int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,

@@ -241,6 +241,9 @@ int mxq_dense_f16(const void* x, const void* w16, void* y, int M, int N, int K, 
 // 21 / 41 .. 64 tokens on launches of <= 64 tiles (and up to 256 tokens where the workspace is too small for those builds,
 // or absent).  The whole map against hipBLASLt: profiles/r04_dispatch_map.txt.
 static const int MIDM_MAX_TOKENS = 256;
+// Token count from which hoisting the dequant out of the token loop (dequant pass + dense 256 x 256 kernel) beats the
+// fused kernel on the Llama shapes (tools/ab_gemm.py; profiles/r03_dense256.txt)
+static const int HOIST_MIN_TOKENS = 4096;
 // ... and the token count up to which the skinny kernel (one workgroup per 16-row block, every wave reads all of x from
 // L2) still beats it: its time grows with tokens x weight size, the split-K kernel's is flat up to 64 tokens.  Measured
 // crossovers (profiles/r03_midM.txt): ~44 tokens at 4096^2, ~22 at 11008 x 4096 and 4096 x 11008.
@@ -287,19 +290,77 @@ static int small_tile_launch(int M, int mode, const void* x, const void* qweight
                      : mxq_launch_gemm8h_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, ws_bytes, stream);
 }
 
+// The workspace-free schedule of EVERY layout (mxq_linear_f16, and the _ws entries when `workspace` is NULL): the K range is
+// never split.  Streaming GEMV (<= 4 tokens), skinny MFMA kernel as far as it goes (mixed layouts 64 tokens: 19.5 us at
+// 4096^2 where the 128 x 128-tile kernel took 57; uniform layouts 48), then -- mixed layouts -- the mid-M kernel with one
+// slice per tile up to 256 tokens (44-54 us at 4096^2: use a _ws entry where it matters; a shape beyond its 32-bit offsets
+// falls through), and the prefill kernel on whole tiles beyond.
+static int linear_noworkspace(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,
+                              hipStream_t stream) {
+    const bool mixed = mxq_layout_is_mixed(layout);
+    if (M <= 4) return mxq_launch_gemv_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, stream);
+    if (M <= (mixed ? 64 : 48)) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, stream);
+    if (mixed && M <= MIDM_MAX_TOKENS) {
+        const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, layout, nullptr, 0, 0, 0, stream);
+        if (e != MXQ_E_SHAPE) return e;
+    }
+    if (layout == MXQ_LAYOUT_MIXED) return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, stream);
+    return mxq_launch_gemm8_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, nullptr, 0, stream);
+}
+
 int mxq_linear_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
-    if (M <= 4) return mxq_launch_gemv_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-    // no workspace, no K split: the skinny kernel as far as it goes (64 tokens x 4096^2: 19.5 us; the 128 x 128-tile
-    // kernel took 57), then the mid-M kernel with one slice per tile (44-54 us at 4096^2: use the _ws entry where it matters)
-    if (M <= 64) return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
-    if (M <= MIDM_MAX_TOKENS)
-        return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, nullptr, 0, 0, 0, (hipStream_t)stream);
-    return mxq_launch_gemm_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
+    return linear_noworkspace(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, (hipStream_t)stream);
 }
 
 size_t mxq_gemm_workspace_bytes(void) { return mxq_gemm8_workspace_bytes(); }
+
+// Bytes of workspace the dispatch of mxq_linear_f16_auto can use for THIS call (0: the call never touches a workspace --
+// GEMV, skinny kernel, hoisted mode with a scratch): what a caller that owns one workspace per captured graph allocates
+// instead of the maximum (mxq_gemm_workspace_bytes()).  Mirrors the dispatch above.
+size_t mxq_linear_workspace_need(int M, int N, int K, int layout, int hoisting) {
+    if (!shape_ok(N, K) || M <= 0 || !layout_ok(layout)) return 0;
+    if (M <= 4 || (hoisting && M >= HOIST_MIN_TOKENS)) return 0;
+    const bool mixed = mxq_layout_is_mixed(layout);
+    if (M <= (mixed ? skinny_max_tokens(N, K) : 48)) return 0;
+    const size_t full = mxq_gemm8_workspace_bytes();
+    if (M > 64 ? gemm8h_mode(M, N, full) : gemm8q_mode(M, N, full, layout == MXQ_LAYOUT_W2G16 || layout == MXQ_LAYOUT_W4ROW)) {
+        size_t need = M > 64 ? mxq_gemm8h_workspace_bytes() : mxq_gemm8q_workspace_bytes();
+        if (M > 64 && mxq_gemm8n_workspace_bytes() > need) need = mxq_gemm8n_workspace_bytes();
+        return need;
+    }
+    if (mixed && M <= MIDM_MAX_TOKENS) {   // the mid-M kernel's partial tiles: one slice per idle CU, at most
+        const size_t tiles = (size_t)((M + 127) / 128) * ((N + 127) / 128);
+        size_t slabs = tiles > 256 ? tiles : 256 + tiles;
+        return (size_t)65536 + slabs * 128 * 128 * sizeof(float);
+    }
+    return full;
+}
+
+// hipStreamGetCaptureInfo through THIS library's HIP runtime (the process's own: a caller that dlopens "libamdhip64.so" by
+// name may load a second runtime next to the one its framework bundles): *active = 1 and *id = the capture sequence's
+// id while `stream` is being captured, else *active = 0.
+int mxq_stream_capture_id(void* stream, int* active, unsigned long long* id) {
+    if (!active || !id) return MXQ_E_NULL;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    const hipError_t e = hipStreamGetCaptureInfo((hipStream_t)stream, &st, &cid);
+    if (e != hipSuccess) return (int)e;
+    *active = st == hipStreamCaptureStatusActive;
+    *id = *active ? cid : 0;
+    return 0;
+}
+
+// The stream-K kernels' status words (csrc/gemm8.hip, SK_STATUS_OFF: the last 16 bytes of the 64-KiB head).  The ONE entry
+// that synchronises: it waits for `stream`, then copies the four ints to the host.
+int mxq_workspace_status(const void* workspace, size_t workspace_bytes, int* status4, void* stream) {
+    if (!workspace || !status4) return MXQ_E_NULL;
+    if (workspace_bytes < 65536) return MXQ_E_SHAPE;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpy(status4, (const char*)workspace + 65536 - 16, 16, hipMemcpyDeviceToHost);
+}
 
 static int gemm_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                    void* workspace, size_t ws_bytes, hipStream_t stream) {
@@ -341,17 +402,18 @@ int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* row
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (!layout_ok(layout)) return MXQ_E_SHAPE;
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
+    if (!workspace) return linear_noworkspace(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
     if (layout == MXQ_LAYOUT_MIXED)
         return mxq_linear_f16_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, stream);
     if (M <= 4) return mxq_launch_gemv_layout_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
     // every layout: the skinny MFMA kernel up to the token count where the split-K / prefill kernels overtake it
-    if (M <= (workspace && layout == MXQ_LAYOUT_MIXEDC ? skinny_max_tokens(N, K) : layout == MXQ_LAYOUT_MIXEDC ? 64 : 48))
+    if (M <= (layout == MXQ_LAYOUT_MIXEDC ? skinny_max_tokens(N, K) : 48))
         return mxq_launch_skinny_f16(x, qweight, rowmeta, y, M, N, K, layout, (hipStream_t)stream);
-    if (const int mode = !workspace ? 0 : M > 64 ? gemm8h_mode(M, N, workspace_bytes)
-                                                : gemm8q_mode(M, N, workspace_bytes, layout != MXQ_LAYOUT_MIXEDC))
+    if (const int mode = M > 64 ? gemm8h_mode(M, N, workspace_bytes)
+                                : gemm8q_mode(M, N, workspace_bytes, layout != MXQ_LAYOUT_MIXEDC))
         return small_tile_launch(M, mode, x, qweight, rowmeta, y, N, K, layout, workspace, workspace_bytes, (hipStream_t)stream);
     if (layout == MXQ_LAYOUT_MIXEDC) {
-        if (M <= MIDM_MAX_TOKENS && (!workspace || midm_ws_ok(M, N, workspace_bytes))) {
+        if (M <= MIDM_MAX_TOKENS && midm_ws_ok(M, N, workspace_bytes)) {
             const int e = mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, layout, workspace, workspace_bytes, 0, 0,
                                               (hipStream_t)stream);
             if (e != MXQ_E_SHAPE) return e;
@@ -361,9 +423,6 @@ int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* row
                                        (hipStream_t)stream);
 }
 
-// Token count from which hoisting the dequant out of the token loop (dequant pass + dense 256 x 256 kernel) beats the
-// fused kernel on the Llama shapes (tools/ab_gemm.py; profiles/r03_dense256.txt)
-static const int HOIST_MIN_TOKENS = 4096;
 int mxq_hoist_min_tokens(void) { return HOIST_MIN_TOKENS; }
 
 int mxq_linear_f16_auto(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K, int layout,

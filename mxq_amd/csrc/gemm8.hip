@@ -133,6 +133,10 @@ constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K
 // s_memrealtime, MFMA wave 0 of every workgroup -> 8 u64 per workgroup at byte 32768 of the workspace head);
 // 32768 = the all-contributors reduction from 3 contributors per tile on (product: SK_DIST_MIN)
 [[maybe_unused]] constexpr int EXP_SKSTAMPS = 16384, EXP_SK_DIST3 = 32768;
+// 65536 = fault injection for the expiry test (tests/test_gpu_parity.py, profiling library only): unit 0 never counts its
+// parked pieces and every wait gives up after 4096 polls -- the launch must end with the workspace's status words set and
+// the starved tiles poisoned, not with silently wrong sums
+[[maybe_unused]] constexpr int EXP_SK_WITHHOLD = 65536;
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
@@ -418,7 +422,26 @@ __device__ __forceinline__ void mma_prologue_issue(const XDma& xd, char* smem, i
 #else
 #define SK_KOFF(k) (k)
 #endif
-constexpr int SK_SPIN_BOUND = 1 << 22;
+constexpr int SK_SPIN_BOUND = 1 << 22;      // polls (each one agent-scope load + s_sleep: several seconds in all)
+template <int ABL> constexpr int sk_spin_bound() { return (ABL & EXP_SK_WITHHOLD) ? 4096 : SK_SPIN_BOUND; }
+// A wait that gives up must not pass for a result.  Status words at the END of the workspace's 64-KiB head (ints
+// SK_STATUS_OFF .. +3; the K-step counts, the "done" counts and the profiling stamps all lie below byte 49152):
+//   [0] code (0 = fine; 1 = an owner's wait expired, 2 = a wait of the all-contributors reduction expired)
+//   [1] tail-tile index, [2] workgroup, [3] the count it saw.
+// The first failure's details stay (later ones only keep [0] non-zero); the tile (or token block) whose operands never
+// arrived is written as NaN.  The counters are then inconsistent: the host re-zeroes the head before the workspace is used
+// again (mxq_workspace_status reports, packing.workspace_status raises and resets).
+constexpr int SK_STATUS_OFF = 16380;
+__device__ __forceinline__ void sk_fail(int* cnt, int code, int j, int seen, int lane) {
+    if (lane == 0) {
+        int* st = cnt + SK_STATUS_OFF;
+        if (__hip_atomic_exchange(st, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __hip_atomic_store(st + 1, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st + 2, (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st + 3, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 #ifndef MXQ_SK_DIST_MIN
 #define MXQ_SK_DIST_MIN 6
 #endif
@@ -457,15 +480,26 @@ __device__ __forceinline__ void sk_reduce_distributed(const SkSeg& sk, int j, in
     char* stage = smem + wave * WSLOT;               // room for NJ contributors' four fragments per batch
     for (int t = self * N_MMA + wave; t < NJ * N_MMA; t += C * N_MMA) {
         const int ws = t / NJ, jj = t % NJ;
-        for (int spin = 0; spin < SK_SPIN_BOUND; ++spin) {
+        bool arrived = false;
+        int seen = 0;
+        for (int spin = 0; spin < sk_spin_bound<ABL>(); ++spin) {
             int v = 0;
             if (lane == 0) v = __hip_atomic_load(cw + ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_readfirstlane(v) >= NT_tile) break;
+            seen = __builtin_amdgcn_readfirstlane(v);
+            if (seen >= NT_tile) { arrived = true; break; }
             __builtin_amdgcn_s_sleep(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler ordering only: the slot loads are sc1
         sk_stamp<ABL>(sk.cnt, wave, lane, 4);
         f32x4 c4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (!arrived) {   // the wait gave up: flag the workspace, poison the token block (never a silent partial sum)
+            sk_fail(sk.cnt, 2, j, seen, lane);
+            const float qnan = __builtin_nanf("");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c4[i] = f32x4{qnan, qnan, qnan, qnan};
+            store_block_xpose(c4, y, M, N, m0, n0, ws / WGN, ws % WGN, jj, lane & 15, lane >> 4);
+            continue;
+        }
         int staged = 0;
         auto flush = [&]() {                                     // (sums start from +0: unit order, fixed)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -501,9 +535,10 @@ __device__ __forceinline__ void sk_reduce_distributed(const SkSeg& sk, int j, in
 }
 
 // a parked piece's K-steps enter its tile's count (pre: the slot stores have retired -- the caller's vmcnt wait)
+template <int ABL = 0>
 __device__ __forceinline__ void sk_bump_pending(SkSeg& sk, int wave, int lane) {
     if (sk.pend_j >= 0) {
-        if (lane == 0)
+        if (lane == 0 && !((ABL & EXP_SK_WITHHOLD) && sk.u == 0))   // (fault injection: unit 0's counts never arrive)
             __hip_atomic_fetch_add(sk.cnt + (sk.pend_j * 8 + sk.e) * N_MMA + wave, sk.pend_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sk.pend_j = -1;
     }
@@ -519,14 +554,27 @@ __device__ __forceinline__ void sk_finish_owner(const SkSeg& sk, int own, int NT
     int* c = sk.cnt + (j * 8 + sk.e) * N_MMA + wave;
     const int need = NT_tile - own;
     sk_stamp<ABL>(sk.cnt, wave, lane, 7);   // (marks the workgroup as an owner)
-    for (int spin = 0; spin < SK_SPIN_BOUND; ++spin) {
+    bool arrived = false;
+    int seen = 0;
+    for (int spin = 0; spin < sk_spin_bound<ABL>(); ++spin) {
         int v = 0;
         if (lane == 0) v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__builtin_amdgcn_readfirstlane(v) >= need) break;
+        seen = __builtin_amdgcn_readfirstlane(v);
+        if (seen >= need) { arrived = true; break; }
         __builtin_amdgcn_s_sleep(4);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler ordering only: the slot loads are agent-scope themselves
     sk_stamp<ABL>(sk.cnt, wave, lane, 2);
+    if (!arrived) {   // the wait gave up: flag the workspace and write the tile as NaN (never a silent partial sum)
+        sk_fail(sk.cnt, 1, j, seen, lane);
+        const float qnan = __builtin_nanf("");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = f32x4{qnan, qnan, qnan, qnan};
+        store_tile_xpose(acc, y, M, N, m0, n0, wave / WGN, wave % WGN, lane & 15, lane >> 4);
+        return;
+    }
     int uf;
     sk_contributors(sk, j, NT_tile, uf);
     // A contributor's slot comes through LDS, not through registers: 16 LDS-DMA pieces (sc1: the bytes were written by
@@ -579,7 +627,7 @@ __device__ __forceinline__ void mma_segment(char* smem, int wave, int lane, int 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // vmcnt retires in order: the wait for this segment's first x tile has also retired every older operation of the
     // wave -- the slot stores of the piece it parked before.  Its K-step count moves now, for free.
-    sk_bump_pending(sk, wave, lane);
+    sk_bump_pending<ABL>(sk, wave, lane);
     __builtin_amdgcn_s_barrier();   // prologue barrier 1: x tile 0 and packed blocks 0..3 landed
     __builtin_amdgcn_s_barrier();   // prologue barrier 2: W16(0) written by the dequant waves
 
@@ -1101,7 +1149,7 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
         if (sk.pend_j >= 0) {   // the unit ended on a parked piece: its stores must have retired before the count moves
             MXQ_LANE_ID(ln);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            sk_bump_pending(sk, wave, ln);
+            sk_bump_pending<ABL>(sk, wave, ln);
             sk_stamp<ABL>(cnt, wave, ln, 3);
         }
         // tiles with many contributors are reduced by all of them, after every piece of this unit is parked and counted
@@ -1434,6 +1482,11 @@ extern "C" int G8_SYM(prof_, _stamps_f16)(const void* x, const void* qweight, co
         case 2: return launch8_stamps<4096 + 2>(x, qweight, rowmeta, y, M, N, K, dbg, stream);
     }
     return -1;
+}
+// fault injection for the expiry test (EXP_SK_WITHHOLD above): the tail always split, unit 0's counts withheld
+extern "C" int G8_SYM(prof_, _skwithhold_f16)(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N,
+                                             int K, void* workspace, size_t ws_bytes, void* stream_) {
+    return launch8<EXP_SK_WITHHOLD>(x, qweight, rowmeta, y, M, N, K, workspace, ws_bytes, true, (hipStream_t)stream_);
 }
 // stream-K fix-up phases (tools/sk_stamps.py): the product dispatch (force = 0) or the tail always split, with the owner
 // protocol as shipped (dist3 = 0) or the all-contributors reduction from 3 contributors on; correct results

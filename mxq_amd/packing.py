@@ -53,64 +53,77 @@ _WS_HEAD = 65536      # bytes of K-step counters at the head of a workspace (inc
 MIDM_MAX_TOKENS = 256     # capi.hip: the most tokens mxq_linear_f16_ws may hand to the mid-M split-K kernel (no counters)
 
 
-_CAPTURE_KEYS: list = []          # capture workspaces in order of creation (bounded: _MAX_CAPTURE_WS)
-_MAX_CAPTURE_WS = 32
-_hip_rt = None
+_CAPTURE_KEYS: list = []          # capture workspaces in order of creation
+# A capture workspace lives in its graph's private memory pool; this cache holds a reference so that the memory cannot be
+# handed to a later capture that shares the pool while the first graph still replays on it.  The price is that
+# the bytes stay pinned after their graph is gone, so the cache is bounded -- generously: 256 graphs of <= 67 MB.
+_MAX_CAPTURE_WS = 256
 
 
-def _capture_id(stream_handle: int) -> int:
-    """Id of the capture sequence the stream is recording (hipStreamGetCaptureInfo): unique per captured graph."""
-    global _hip_rt
+def _capture_id(stream_handle: int):
+    """(capturing?, id of the capture sequence) of a stream, asked through libmxq_hip.so's own HIP runtime
+    (include/mxq_hip.h: mxq_stream_capture_id -- never a second runtime opened by name)."""
     import ctypes
-    if _hip_rt is None:
-        _hip_rt = ctypes.CDLL("libamdhip64.so")
-        _hip_rt.hipStreamGetCaptureInfo.restype = ctypes.c_int
-        _hip_rt.hipStreamGetCaptureInfo.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int),
-                                                    ctypes.POINTER(ctypes.c_ulonglong)]
-    status, cid = ctypes.c_int(0), ctypes.c_ulonglong(0)
-    rc = _hip_rt.hipStreamGetCaptureInfo(ctypes.c_void_p(stream_handle), ctypes.byref(status), ctypes.byref(cid))
-    if rc != 0 or status.value != 1:          # hipStreamCaptureStatusActive == 1
-        raise RuntimeError(f"hipStreamGetCaptureInfo: rc {rc}, status {status.value} on a stream torch reports as capturing")
-    return int(cid.value)
+    active, cid = ctypes.c_int(0), ctypes.c_ulonglong(0)
+    _lib.check(_lib.load().mxq_stream_capture_id(ctypes.c_void_p(stream_handle), ctypes.byref(active), ctypes.byref(cid)),
+               "mxq_stream_capture_id")
+    return bool(active.value), int(cid.value)
 
 
-def gemm_workspace(device: torch.device, counters: bool = True, stream: Optional[int] = None) -> torch.Tensor:
+def gemm_workspace(device: torch.device, counters: bool = True, stream: Optional[int] = None,
+                   need: Optional[int] = None) -> Optional[torch.Tensor]:
     """Scratch buffer of the stream-K prefill GEMM and of the mid-M kernel's partial tiles (include/mxq_hip.h:
     mxq_linear_f16_ws).  Its counter head must be zero when a stream-K launch starts; the kernels leave it zeroed.
 
-    Eager launches: one buffer per (device, stream), created and zeroed on first use -- launches on one stream run in
-    order and may share it, launches on different streams may not.
+    Eager launches: one buffer of the maximum size per (device, stream), created and zeroed on first use -- launches on
+    one stream run in order and may share it, launches on different streams may not.
 
-    Captured launches: one buffer per CAPTURED GRAPH (keyed by the capture sequence's id), so two graphs replayed at
-    the same time on two streams never share partial sums or counters (round 3 shared one buffer per device among all
-    graphs and only documented "replay them one at a time").  It is born under capture, i.e. never zeroed for real
-    until a replay runs: its first hand-out records ONE memset of the 64-KiB counter head into the graph (once per
-    replay, ~2 us, in front of the graph's first launch -- not one per launch, which round 3 found inside every
-    graph-replay timing of round 2); later launches of the same graph find the counters as the previous one left them.
+    Captured launches: buffers per CAPTURED GRAPH (keyed by the capture sequence's id), so two graphs replayed at the same
+    time on two streams never share partial sums or counters.  ``need`` (bytes this launch can use,
+    mxq_linear_workspace_need; None = the maximum) sizes them: a graph whose launches never leave the skinny kernel gets
+    none at all (``need`` 0 returns None), one that stays within the small-tile builds a 34-MB buffer instead of 67 MB
+    (two size classes per graph at most).  A buffer born under capture is never zeroed for real until a replay runs: its
+    first counters hand-out records ONE memset of the 64-KiB counter head into the graph.
 
     ``counters=False``: the caller's kernel uses the buffer beyond the head only (the mid-M kernel's partial tiles):
     no memset is recorded for it."""
+    if need is not None and need <= 0:
+        return None
     dev_index = device.index if device.index is not None else torch.cuda.current_device()
     if stream is None:                      # (callers on the hot path pass the handle they already hold)
         stream = torch.cuda.current_stream(device).cuda_stream
-    capturing = torch.cuda.is_current_stream_capturing()
-    key = (dev_index, "capture", _capture_id(stream)) if capturing else (dev_index, stream)
+    lib = _lib.load()
+    full = lib.mxq_gemm_workspace_bytes()
+    # (torch's own query looks at the CURRENT device's stream; only when it says "capturing" -- or the device is another
+    #  one -- is the stream itself asked, through the library)
+    capturing, cid = False, 0
+    if dev_index != torch.cuda.current_device() or torch.cuda.is_current_stream_capturing():
+        capturing, cid = _capture_id(stream)
+    if capturing:
+        nbytes = full if need is None or 2 * need > full else (full + _WS_HEAD) // 2     # two size classes
+        nbytes = max(nbytes, need or 0)
+        key = (dev_index, "capture", cid, nbytes)
+    else:
+        nbytes, key = full, (dev_index, stream)
     ws = _WORKSPACES.get(key)
+    if ws is None and capturing:             # a bigger buffer of the same graph serves a smaller need
+        ws = _WORKSPACES.get((dev_index, "capture", cid, full))
+        if ws is not None:
+            key = (dev_index, "capture", cid, full)
     if ws is None:
-        nbytes = _lib.load().mxq_gemm_workspace_bytes()
         ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _WS_EAGER[key] = not capturing
         if capturing:
             _WS_EAGER[key] = False                    # ... until a counters hand-out has recorded the memset
             _CAPTURE_KEYS.append(key)
-            while len(_CAPTURE_KEYS) > _MAX_CAPTURE_WS:    # the graph's memory pool keeps the buffer alive, not this cache
+            while len(_CAPTURE_KEYS) > _MAX_CAPTURE_WS:
                 old = _CAPTURE_KEYS.pop(0)
                 _WORKSPACES.pop(old, None)
                 _WS_EAGER.pop(old, None)
         else:
+            _WS_EAGER[key] = True
             ws[:_WS_HEAD].zero_()
     if capturing and counters and not _WS_EAGER.get(key, False):
-        ws[:_WS_HEAD].zero_()                          # recorded once per graph
+        ws[:_WS_HEAD].zero_()                          # recorded once per graph and buffer
         _WS_EAGER[key] = True
     return ws
 
@@ -156,6 +169,33 @@ def linear_hoisted(x: torch.Tensor, p, out: Optional[torch.Tensor] = None) -> to
                                               M, p.N, p.K, _layout_code(p), scratch.data_ptr(), scratch.numel(),
                                               _stream(x2)), "mxq_linear_f16_hoisted")
     return out.reshape(*x.shape[:-1], p.N)
+
+
+def workspace_status(device: Optional[torch.device] = None, reset: bool = True) -> None:
+    """Raise RuntimeError if a stream-K wait gave up on any cached workspace (all devices, or one) since the last check
+    (include/mxq_hip.h: mxq_workspace_status -- the affected tiles were written as NaN).  Synchronises the workspace's
+    stream; call it wherever the caller synchronises anyway (end of a prefill, a test, a bench's timed region).
+    ``reset``: re-zero the counter head of a flagged workspace so that it can be used again."""
+    import ctypes
+    lib = _lib.load()
+    bad = []
+    for key, ws in list(_WORKSPACES.items()):
+        dev_index = key[0]
+        if device is not None and (device.index if device.index is not None else torch.cuda.current_device()) != dev_index:
+            continue
+        st = (ctypes.c_int * 4)()
+        with torch.cuda.device(dev_index):
+            torch.cuda.synchronize(dev_index)          # (capture workspaces have no eager stream of their own)
+            _lib.check(lib.mxq_workspace_status(ws.data_ptr(), ws.numel(), ctypes.cast(st, ctypes.c_void_p), None),
+                       "mxq_workspace_status")
+            if st[0] != 0:
+                bad.append((key, list(st)))
+                if reset:
+                    ws[:_WS_HEAD].zero_()
+                    torch.cuda.synchronize(dev_index)
+    if bad:
+        raise RuntimeError("stream-K wait expired (workspace key, [code, tail tile, workgroup, count seen]): "
+                           f"{bad}; the affected output tiles are NaN" + ("; counter heads re-zeroed" if reset else ""))
 
 
 def reset_gemm_workspace(device: Optional[torch.device] = None):
@@ -388,12 +428,14 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
         # ONE C call for the whole dispatch (include/mxq_hip.h: mxq_linear_f16_auto): skinny / mid-M split-K / fused
         # prefill kernel with its stream-K tail / hoisted-dequant mode, chosen inside the library by token count
         hoists = M >= HOIST_MIN_TOKENS
-        # (counters: any non-hoisted launch beyond the skinny kernel's range may be a stream-K one -- the library decides)
         st = _stream(x2)
-        ws = gemm_workspace(x2.device, counters=not hoists, stream=st)
-        scratch = hoist_scratch(x2.device, lib.mxq_hoist_scratch_bytes(p.N, p.K)) if hoists else None
+        lay = _layout_code(p)
         with _on_device(x.device):
-            _lib.check(lib.mxq_linear_f16_auto(*args, _layout_code(p), ws.data_ptr(), ws.numel(),
+            # (a workspace only where the dispatch can use one, and -- under capture -- only as big as this launch needs)
+            ws = gemm_workspace(x2.device, stream=st, need=lib.mxq_linear_workspace_need(M, p.N, p.K, lay, 1))
+            scratch = hoist_scratch(x2.device, lib.mxq_hoist_scratch_bytes(p.N, p.K)) if hoists else None
+            _lib.check(lib.mxq_linear_f16_auto(*args, lay, ws.data_ptr() if ws is not None else None,
+                                               ws.numel() if ws is not None else 0,
                                                scratch.data_ptr() if scratch is not None else None,
                                                scratch.numel() if scratch is not None else 0, st),
                        "mxq_linear_f16_auto")
@@ -554,9 +596,10 @@ def linear_layout(x: torch.Tensor, p, out: Optional[torch.Tensor] = None, path: 
     with _on_device(x.device):
         if path == "auto" and M > 4:        # the library's own dispatch: skinny kernel / fused prefill GEMM / hoisted mode
             hoists = M >= HOIST_MIN_TOKENS
-            ws = gemm_workspace(x2.device, counters=not hoists)
+            ws = gemm_workspace(x2.device, need=lib.mxq_linear_workspace_need(M, p.N, p.K, layout, 1))
             scratch = hoist_scratch(x2.device, lib.mxq_hoist_scratch_bytes(p.N, p.K)) if hoists else None
-            _lib.check(lib.mxq_linear_f16_auto(*args, ws.data_ptr(), ws.numel(),
+            _lib.check(lib.mxq_linear_f16_auto(*args, ws.data_ptr() if ws is not None else None,
+                                               ws.numel() if ws is not None else 0,
                                                scratch.data_ptr() if scratch is not None else None,
                                                scratch.numel() if scratch is not None else 0, _stream(x2)),
                        "mxq_linear_f16_auto")

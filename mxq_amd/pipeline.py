@@ -12,14 +12,17 @@ of xGMI never enters.
 
 Schedule of ``run_microbatches`` (stage r, micro-batch b):
 
-    post irecv(b+1) into recv ring slot (b+1) % 2      <- before b is computed: the hop of b+1 flies under b
     wait  irecv(b)
     h = stage_fn(recv slot b % 2)
-    wait  isend(b-2) (frees send ring slot b % 2); copy h into it; isend(b)   <- flies under b+1's compute
+    wait  isend(b-2) (frees send ring slot b % 2); copy h into it
+    ONE group { isend(b), irecv(b+1) into recv ring slot (b+1) % 2 }          <- both fly under b+1's compute
 
 RCCL runs point-to-point transfers on its own stream, ordered against the compute stream by events at
 post / wait time, so "flies under" is real overlap on the GPU; the blocking ``send`` / ``recv`` of round 1
-made the compute stream wait for every hop.  The copy into the send ring (16.8 MB at 2048 tokens, ~4 us)
+made the compute stream wait for every hop.  The send of b and the receive of b+1 are posted as one group
+(``dist.batch_isend_irecv``): issued one after the other on a communicator's single stream, the later one
+would wait for the earlier one's peer (round 5; a host-memory backend -- gloo moving device tensors --
+keeps the receive-first order, it has no such stream).  The copy into the send ring (16.8 MB at 2048 tokens, ~4 us)
 decouples the transfer from whatever buffer the stage reuses for its next output.
 
 Nothing here touches the HIP library: the stage computation is a callable, so the schedule is
@@ -182,29 +185,49 @@ class LayerPipeline:
         swork = [None, None]
         src = self._peer(self.rank - 1) if not self.is_first else None
         dst = self._peer(self.rank + 1) if not self.is_last else None
+        staged = self._staged(recv_buf)
         if not self.is_first and n:
             rwork[0] = self._irecv(rbuf[0], src)
         for b in range(n):
+            more = not self.is_first and b + 1 < n          # slot (b+1) % 2 last held micro-batch b-1, consumed by stage_fn(b-1)
+            if more and staged:
+                # host-memory backend: the receive lands in a host buffer, so it can be posted before b is computed
+                rwork[(b + 1) % 2] = self._irecv(rbuf[(b + 1) % 2], src)
             if not self.is_first:
-                if b + 1 < n:                   # slot (b+1) % 2 last held micro-batch b-1, consumed by stage_fn(b-1)
-                    rwork[(b + 1) % 2] = self._irecv(rbuf[(b + 1) % 2], src)
                 rwork[b % 2].wait()
                 x = rbuf[b % 2]
             else:
                 x = inputs[b]
             h = stage_fn(x)
+            s = b % 2
             if not self.is_last:
-                s = b % 2
                 if swork[s] is not None:
                     swork[s].wait()             # isend(b-2) done: its ring slot is free
-                if self._staged(h):             # host-memory backend: .cpu() IS the copy out of the stage's buffer
+            if staged:
+                if not self.is_last:            # .cpu() IS the copy out of the stage's buffer
                     swork[s] = self._isend(h, dst)
-                else:
+            else:
+                # RCCL (and CPU tensors over gloo): the send of b and the receive of b+1 are ONE group
+                # (dist.batch_isend_irecv = ncclGroupStart / End): torch's NCCL backend enqueues the point-to-point ops of
+                # a communicator on one stream in issue order, so a receive of b+1 posted BEFORE the send of b would hold
+                # that send back until the upstream stage has finished b+1 -- the downstream stage would idle for a whole
+                # stage time per micro-batch.  Grouped, neither orders the other; both fly under stage_fn(b+1).
+                ops = []
+                if not self.is_last:
                     if sbuf[s] is None:
                         sbuf[s] = torch.empty_like(h, memory_format=torch.contiguous_format)
                     sbuf[s].copy_(h)
-                    swork[s] = self._isend(sbuf[s], dst)
-            elif collect:
+                    ops.append(dist.P2POp(dist.isend, sbuf[s], dst, group=self.group))
+                if more:
+                    ops.append(dist.P2POp(dist.irecv, rbuf[(b + 1) % 2], src, group=self.group))
+                if ops:
+                    works = dist.batch_isend_irecv(ops)
+                    # (a coalesced batch returns ONE work for the group, otherwise one per op in order)
+                    if not self.is_last:
+                        swork[s] = works[0]
+                    if more:
+                        rwork[(b + 1) % 2] = works[-1]
+            if self.is_last and collect:
                 outs.append(h.clone() if (rbuf is not None and any(h is r for r in rbuf)) else h)
         for w in swork:
             if w is not None:

@@ -4,6 +4,7 @@ single-process decode of the same model -- token ids must be identical (tools/de
 (torch.distributed.run) never touches the GPU; two worker processes do (well inside the box's process guard)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -12,12 +13,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port() -> str:
+    """A port nobody listens on right now (bind to 0, read it back): a leftover or parallel run on the box must not fail
+    the rendezvous with "address in use"."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("compact", [False, True])
 def test_decode_pipeline_world2_tokens_equal_single_process(compact):
     env = dict(os.environ, MXQ_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533" if compact else "29532", os.path.join(ROOT, "tools", "decode_bench.py"), "--tokens", "12",
+           "--master-port", _free_port(), os.path.join(ROOT, "tools", "decode_bench.py"), "--tokens", "12",
            "--layers", "4", "--ctx", "64", "--verify"] + (["--compact"] if compact else [])
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -34,7 +43,7 @@ def test_bench_world2_proves_its_ranks_and_carries_the_decode_figure():
     8-GPU SCALE run the same fields read ranks_seen = distinct_devices = N over RCCL."""
     env = dict(os.environ, MXQ_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

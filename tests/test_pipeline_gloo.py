@@ -1,4 +1,4 @@
-"""The layer-pipeline schedule (mxq_amd/pipeline.py) on CPU with gloo, world_size 2 and 3:
+"""The layer-pipeline schedule (mxq_amd/pipeline.py) on CPU with gloo, world_size 2, 3, 4 and 8:
 micro-batch streaming and greedy decode must reproduce the single-process result exactly."""
 import os
 import socket
@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 
 from mxq_amd.pipeline import LayerPipeline, layer_range, rank_census
 
-N_LAYERS, HID, VOCAB = 6, 32, 50
+N_LAYERS, HID, VOCAB = 8, 32, 50
 
 
 def _weights():
@@ -68,7 +68,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_pipeline_matches_single_process(world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
@@ -78,7 +78,7 @@ def test_pipeline_matches_single_process(world):
         p.start()
     res = {}
     for _ in range(world):
-        r, outs, gen = q.get(timeout=120)
+        r, outs, gen = q.get(timeout=300)
         res[r] = (outs, gen)
     for p in procs:
         p.join(timeout=60)
