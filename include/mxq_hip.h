@@ -282,6 +282,18 @@ int mxq_actquant_fwd(const void* x, void* out, void* range_ws, int64_t n_seg, in
 int mxq_gemv_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int B,
                      int IC, int OC, int group_size, void* stream);
 
+/* gemm_forward_cuda(in_feats, kernel, scaling_factors, zeros, split_k_iters) (gemm_cuda.h:3-4; launcher and its checks
+ * gemm_cuda_gen.cu:424-478; nibble order dequantize.cuh:35-51) -- declared by the reference, never compiled into its module
+ * (setup.py:37-41).  x f16[M, IC]; kernel i32[IC, OC/8] (a word = the 4-bit codes of 8 consecutive output channels at one
+ * input channel, channel e in nibble (0, 4, 1, 5, 2, 6, 3, 7)[e]); scales f16[IC/G, OC]; zeros i32[IC/G, OC/8] (packed like
+ * the codes); weight = fp16(fp16(q - z) * s) as the reference computes it (gemm_cuda_gen.cu:134-141), fp32 accumulation.
+ * split_k == 1: y f16[M, OC].  split_k > 1 (the launcher's split_k_iters): slice j takes the 64-deep K-steps j, j + split_k,
+ * ... and y is f32[split_k, M, OC] -- the caller adds the slices, as the reference's wrapper does (`_out_feats.sum(0)`,
+ * gemm_cuda_gen.cu:477; fp32 partials here, fp16 there).  MXQ_E_SHAPE for the launcher's rejections (OC % 64, group_size
+ * % 32, OC % group_size) and for IC % 64, IC % group_size, split_k outside [1, IC/64]. */
+int mxq_gemm_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
+                     int group_size, int split_k, void* stream);
+
 /* gemv_mxq_forward_cuda(in_feats, kernel, kernel_last, zeros_and_scales, scales_2nd,
  * zeros_2nd, scales_4b, zeros_4b, group_size) (gemv_mxq_cuda.h:4-12; operand layout
  * gemv_mxq_cuda.cu:54-62,96-201).  IC must be 4096 and group_size 16, as in the reference. */

@@ -520,6 +520,17 @@ int mxq_gemv_awq_f16(const void* x, const void* kernel, const void* scales, cons
     return mxq_launch_gemv_awq_f16(x, kernel, scales, zeros, y, B, IC, OC, group_size, (hipStream_t)stream);
 }
 
+int mxq_gemm_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
+                     int group_size, int split_k, void* stream) {
+    if (!x || !kernel || !scales || !zeros || !y) return MXQ_E_NULL;
+    // the reference launcher's checks (gemm_cuda_gen.cu:447-454) + this kernel's 64-deep K-step
+    if (M <= 0 || IC <= 0 || OC <= 0 || OC % 64 != 0 || OC % 8 != 0) return MXQ_E_SHAPE;
+    if (group_size <= 0 || group_size % 32 != 0 || OC % group_size != 0) return MXQ_E_SHAPE;
+    if (IC % 64 != 0 || IC % group_size != 0 || split_k < 1 || split_k > IC / 64) return MXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(scales) || !aligned16(y) || ((uintptr_t)kernel & 3) || ((uintptr_t)zeros & 3)) return MXQ_E_ALIGN;
+    return mxq_launch_gemm_awq_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, split_k, (hipStream_t)stream);
+}
+
 int mxq_gemv_proto_f16(const void* x, const void* weight, const void* weight_last, const void* zeros_and_scales,
                        const void* scales_2nd, const void* zeros_2nd, const void* scales_4b, const void* zeros_4b,
                        void* y, int B, int IC, int OC, int group_size, void* stream) {

@@ -1,7 +1,8 @@
 """Drop-in for the reference's native module ``mxq_inference_engine``
 (mxq_quant/cuda_kernel/csrc/pybind.cpp:6-10, built by cuda_kernel/setup.py:32-44).
 
-Same two callables, same positional signatures, tensors on ``torch.device('cuda')`` (the HIP
+Same two callables (plus ``gemm_forward_cuda``, which the reference declares in gemm_cuda.h:3-4 and implements in
+gemm_cuda_gen.cu:424-478 but never compiles into the module, setup.py:37-41), same positional signatures, tensors on ``torch.device('cuda')`` (the HIP
 device on ROCm), so ``cuda_kernel/test_correct_gemv.py`` and ``test_mxq_gemv.py`` run
 unmodified.  Implemented as ctypes calls into libmxq_hip.so; unlike the reference the
 operands are validated, the kernels run on PyTorch's current stream, and an unsupported
@@ -45,6 +46,45 @@ def gemv_forward_cuda(in_feats, kernel, scaling_factors, zeros, group_size):
                                         zeros.data_ptr(), out.data_ptr(), B, IC, OC, int(group_size),
                                         torch.cuda.current_stream().cuda_stream), "gemv_forward_cuda")
     return out
+
+
+def gemm_forward_cuda(in_feats, kernel, scaling_factors, zeros, split_k_iters):
+    """W4A16 group-wise GEMM on the reference's operands (gemm_cuda.h:3-4): in_feats f16 [M, IC], kernel i32 [IC, OC/8],
+    scaling_factors f16 [IC/G, OC], zeros i32 [IC/G, OC/8].  Returns f16 [M, OC].  The launcher's rejections
+    (gemm_cuda_gen.cu:447-454: std::invalid_argument -> ValueError) are raised with its messages; like the launcher,
+    ``split_k_iters`` slices the K loop into that many partial outputs which are summed afterwards (:436, :477)."""
+    _chk(in_feats, "in_feats", torch.float16); _chk(kernel, "kernel", torch.int32)
+    _chk(scaling_factors, "scaling_factors", torch.float16); _chk(zeros, "zeros", torch.int32)
+    if in_feats.dim() != 2 or kernel.dim() != 2 or scaling_factors.dim() != 2 or zeros.dim() != 2:
+        raise ValueError("in_feats [M, IC], kernel [IC, OC/8], scaling_factors [IC/G, OC], zeros [IC/G, OC/8]")
+    M, IC = in_feats.shape
+    OC = kernel.shape[1] * 8
+    if kernel.shape[0] != IC or scaling_factors.shape[0] == 0 or IC % scaling_factors.shape[0] != 0:
+        raise ValueError("kernel must be [IC, OC/8] and scaling_factors [IC/G, OC]")
+    group_size = IC // scaling_factors.shape[0]
+    if OC % 64 != 0:
+        raise ValueError("OC is not multiple of cta_N = 64")
+    if OC % 8 != 0:
+        raise ValueError("OC is not multiple of pack_num = 8")
+    if group_size % 32 != 0:
+        raise ValueError("Group size should be a multiple of 32")
+    if OC % group_size != 0:
+        raise ValueError("OC is not multiple of Group size")
+    if scaling_factors.shape[1] != OC or tuple(zeros.shape) != (IC // group_size, OC // 8):
+        raise ValueError("scaling_factors must be [IC/G, OC] and zeros [IC/G, OC/8]")
+    S = int(split_k_iters)
+    if S < 1:
+        raise ValueError("split_k_iters must be >= 1")
+    S = min(S, IC // 64)
+    out = torch.empty((S, M, OC) if S > 1 else (M, OC), dtype=torch.float32 if S > 1 else in_feats.dtype, device=in_feats.device)
+    if M == 0:
+        return torch.empty((0, OC), dtype=in_feats.dtype, device=in_feats.device)
+    lib = _lib.load()
+    with torch.cuda.device(in_feats.device):
+        _lib.check(lib.mxq_gemm_awq_f16(in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
+                                        out.data_ptr(), M, IC, OC, group_size, S,
+                                        torch.cuda.current_stream().cuda_stream), "gemm_forward_cuda")
+    return out.sum(0).to(in_feats.dtype) if S > 1 else out
 
 
 def gemv_mxq_forward_cuda(in_feats, kernel, kernel_last, zeros_and_scales, scales_2nd, zeros_2nd, scales_4b,

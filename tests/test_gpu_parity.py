@@ -1731,6 +1731,51 @@ def test_decode_gemv_launches_full_size_vs_oracle(dev):
     check(packing.linear_fused(gu16.to(dev), p, 2, residual=res.to(dev)), ref, "down_proj")
 
 
+@pytest.mark.parametrize("M,IC,OC,G,S", [(16, 4096, 4096, 128, 8), (128, 4096, 4096, 128, 4), (2048, 4096, 4096, 64, 1),
+                                         (16, 4096, 11008, 128, 8), (128, 4096, 11008, 32, 2), (2048, 4096, 11008, 128, 1),
+                                         (1, 256, 64, 32, 1), (130, 320, 192, 64, 3)])
+def test_gemm_forward_cuda_reference_operands_vs_oracle(dev, M, IC, OC, G, S):
+    """`gemm_forward_cuda(in_feats, kernel, scaling_factors, zeros, split_k_iters)` on the reference's
+    operand format (gemm_cuda.h:3-4; K-major int32 words of 8 interleaved nibbles, group-G scales [IC/G, OC], packed
+    integer zeros) against the oracle's restatement: <= 1e-3 (max-norm and Frobenius) of the fp32-accumulated product on
+    the fp16 weight fp16((q - z) * s).  Parity UNPINNED: the reference never compiles this kernel."""
+    import mxq_inference_engine as eng
+    rng = np.random.default_rng(M + IC + OC + G)
+    q = rng.integers(0, 16, size=(IC, OC))
+    z = rng.integers(0, 16, size=(IC // G, OC))
+    s = (rng.random((IC // G, OC)) * 0.004 + 0.001).astype(np.float16)
+    x = (rng.standard_normal((M, IC))).astype(np.float16)
+    kern, zw = O.gemm_awq_pack(q), O.gemm_awq_pack(z)
+    y = eng.gemm_forward_cuda(torch.from_numpy(x).to(dev), torch.from_numpy(kern).to(dev), torch.from_numpy(s).to(dev),
+                              torch.from_numpy(zw).to(dev), S)
+    assert y.shape == (M, OC) and y.dtype == torch.float16
+    _check_gemm(y.cpu().numpy(), O.gemm_awq_ref(x, kern, s, zw, G), f"awq gemm {M}x{IC}x{OC} G{G} S{S}")
+
+
+def test_gemm_forward_cuda_integer_exact_and_rejections(dev):
+    """Operand mapping exactly (small integers: every product and sum exact in fp16 / fp32) and the launcher's rejections
+    (gemm_cuda_gen.cu:447-454) as ValueError with its messages."""
+    import mxq_inference_engine as eng
+    rng = np.random.default_rng(3)
+    M, IC, OC, G = 20, 128, 128, 32
+    q = rng.integers(0, 16, size=(IC, OC)); z = rng.integers(0, 16, size=(IC // G, OC))
+    s = rng.integers(1, 3, size=(IC // G, OC)).astype(np.float16)
+    x = rng.integers(-2, 3, size=(M, IC)).astype(np.float16)
+    kern, zw = O.gemm_awq_pack(q), O.gemm_awq_pack(z)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    for S in (1, 2):
+        y = eng.gemm_forward_cuda(t(x), t(kern), t(s), t(zw), S).float().cpu().numpy()
+        assert np.array_equal(y, O.gemm_awq_ref(x, kern, s, zw, G)), S
+    with pytest.raises(ValueError, match="cta_N = 64"):
+        eng.gemm_forward_cuda(t(x), t(kern[:, :12].copy()), t(s[:, :96].copy()), t(zw[:, :12].copy()), 1)
+    with pytest.raises(ValueError, match="multiple of 32"):
+        eng.gemm_forward_cuda(t(x), t(kern), t(np.ones((8, OC), np.float16)), t(np.zeros((8, OC // 8), np.int32)), 1)
+    with pytest.raises(ValueError, match="Group size"):      # OC % group_size: 192 % 128
+        eng.gemm_forward_cuda(t(x), t(np.zeros((IC, 24), np.int32)), t(np.ones((1, 192), np.float16)), t(np.zeros((1, 24), np.int32)), 1)
+    with pytest.raises(TypeError):
+        eng.gemm_forward_cuda(t(x).float(), t(kern), t(s), t(zw), 1)
+
+
 def test_decode_token_graph_matches_eager_loop(dev):
     """The one-graph-per-token loop (embedding -> layers -> head -> argmax captured together) must generate
     exactly the tokens of the step-by-step loop through LayerPipeline.decode on the same stage."""

@@ -164,3 +164,22 @@ def test_compact_metadata_stays_inside_the_gemm_budget():
     err_fro = np.linalg.norm(y_comp - y_exact) / np.linalg.norm(y_exact)
     err_max = np.abs(y_comp - y_exact).max() / np.abs(y_exact).max()
     assert err_fro < 6e-4 and err_max < 8e-4, (err_fro, err_max)
+
+
+def test_gemm_awq_operand_restatement_nibble_order():
+    """oracle.gemm_awq_*: the interleaved nibble order of the reference GEMM's operands (dequantize.cuh:35-51: the
+    conversion returns nibbles (0, 4, 1, 5, 2, 6, 3, 7) as elements 0..7) -- a known-answer word and pack / unpack
+    round trips.  (Parity unpinned for this entry: the reference never builds the kernel and ships no vector for it.)"""
+    import numpy as np
+    from oracle import mxq_oracle as O
+    word = np.array([[0x76543210]], np.uint32).view(np.int32)          # nibble i holds the value i
+    assert O.gemm_awq_unpack(word).tolist() == [[0, 4, 1, 5, 2, 6, 3, 7]]
+    rng = np.random.default_rng(0)
+    q = rng.integers(0, 16, size=(64, 128))
+    assert np.array_equal(O.gemm_awq_unpack(O.gemm_awq_pack(q)), q)
+    s = (rng.random((2, 128)) * 0.01 + 0.001).astype(np.float16)
+    z = rng.integers(0, 16, size=(2, 128))
+    w = O.gemm_awq_weight(O.gemm_awq_pack(q), s, O.gemm_awq_pack(z), 32)
+    k, n = 40, 77
+    want = np.float16((np.float32(q[k, n]) - np.float32(z[1, n])) * np.float32(s[1, n]))
+    assert w.shape == (64, 128) and w[k, n] == want
