@@ -18,8 +18,12 @@
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
  *   - every function returns 0 on success, a positive hipError_t if the HIP runtime
  *     reported one at launch, or a negative MXQ_E* code for rejected arguments;
- *   - nothing here allocates, frees, synchronises or keeps state: outputs are
- *     caller-allocated and the library is re-entrant (safe under hipGraph capture);
+ *   - nothing here allocates or frees device memory, and nothing synchronises except mxq_workspace_status: outputs
+ *     and scratch are caller-allocated and the library is re-entrant (safe under hipGraph capture).  The library keeps
+ *     exactly two pieces of process-global HOST state, both caches of device facts that never change: the CU count of
+ *     the first device a stream-K launcher ran on (csrc/gemm8.hip cu_count(): one device model per process is assumed),
+ *     and one bit per (kernel, device ordinal) recording that hipFuncSetAttribute(MaxDynamicSharedMemorySize) was made
+ *     (csrc/mxq_kernels.h mxq_set_dyn_lds_once).  No data-dependent state survives a call;
  *   - shapes: weight W[N, K] row-major (nn.Linear.weight), N % 16 == 0, K % 64 == 0.
  */
 #ifndef MXQ_HIP_H
@@ -112,16 +116,24 @@ int mxq_gemv_f16(const void* x, const void* qweight, const void* rowmeta, void* 
  * tokens) with K cut into one slice per idle CU, fp32 slabs in the workspace beyond its first 64 KiB and a combine launch; 65..176 tiles (gate/up at 65-256 tokens, 4096^2 at
  * 257-640) in one launch, stream-K over the otherwise idle CUs.  Up to 64 tokens, launches of 65..176 tiles of 64 x 128
  * (gate/up) run its 64-token build (csrc/gemm8q.hip) the same way.
- * mxq_gemm_f16_ws: variant 0 = default dispatch, 1 = the 128x128-tile kernel (workspace ignored), 8 = the
- * 256x128-tile kernel (MFMA waves stream x, dedicated waves dequantise, persistent over tiles, stream-K tail;
- * csrc/gemm8.hip) at any M, 9 = the same but splitting its tail whenever that is structurally possible (tests),
- * 10 = the mid-M split-K kernel (csrc/midm.hip) at any M, 12 / 13 = the fused kernel's 128-token build (csrc/gemm8h.hip)
- * at any M, splitting its tail where that pays / whenever possible, 14 = the same in slices mode (K slices + combine launch);
- * 16 / 17 = the 64-token build (csrc/gemm8q.hip) with its tail always split / in slices mode;
- * 20 / 21 = the 128 x 64-tile build (csrc/gemm8n.hip) likewise;
- * anything else is MXQ_E_SHAPE.  Results of every variant agree to fp32-summation-order rounding and
- * are run-to-run deterministic.  (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`,
- * used by tools/ alone: they are not part of this ABI.) */
+ * mxq_gemm_f16_ws runs ONE named schedule (enum mxq_gemm_variant below) at any token count: the entry behind the parity
+ * tests of every kernel build and behind tools/'s A/B timings; production callers use mxq_linear_f16_auto.  Results of every
+ * variant agree to fp32-summation-order rounding and are run-to-run deterministic; an unknown code is MXQ_E_SHAPE.
+ * (Profiling-only ablation builds live in libmxq_hip_prof.so, `make prof`, used by tools/ alone: not part of this ABI.) */
+enum mxq_gemm_variant {
+    MXQ_GEMM_DEFAULT = 0,           /* by token count: 128 x 128-tile kernel (no workspace) or the 256 x 128 fused kernel */
+    MXQ_GEMM_TILE128 = 1,           /* csrc/gemm.hip: 128 x 128 tile, two LDS stages; workspace ignored */
+    MXQ_GEMM_FUSED256 = 8,          /* csrc/gemm8.hip: 256 x 128 tile, wave-specialised, persistent; tail split where it pays */
+    MXQ_GEMM_FUSED256_SPLIT = 9,    /* ... tail split whenever that is structurally possible */
+    MXQ_GEMM_MIDM = 10,             /* csrc/midm.hip: split-K slices + combine launch */
+    MXQ_GEMM_FUSED128 = 12,         /* csrc/gemm8h.hip: the fused kernel's 128-token build, tail split where it pays */
+    MXQ_GEMM_FUSED128_SPLIT = 13,   /* ... always split */
+    MXQ_GEMM_FUSED128_SLICES = 14,  /* ... K slices + combine launch */
+    MXQ_GEMM_FUSED64_SPLIT = 16,    /* csrc/gemm8q.hip: the 64-token build, stream-K tail always split */
+    MXQ_GEMM_FUSED64_SLICES = 17,   /* ... K slices + combine launch */
+    MXQ_GEMM_FUSED128N64_SPLIT = 20,  /* csrc/gemm8n.hip: the 128 x 64-tile build, tail always split */
+    MXQ_GEMM_FUSED128N64_SLICES = 21  /* ... K slices + combine launch */
+};
 size_t mxq_gemm_workspace_bytes(void);
 /* A stream-K launch makes workgroups wait for other workgroups of the SAME launch (an owner for the lower-numbered units of
  * its tile; in the all-contributors reduction, any contributor for any other).  That needs the launch's workgroups resident

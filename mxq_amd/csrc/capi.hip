@@ -439,28 +439,29 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
                     int variant, void* workspace, size_t workspace_bytes, void* stream) {
     if (int e = linear_check(x, qweight, rowmeta, y, M, N, K)) return e;
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
-    if (variant == 0) return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, (hipStream_t)stream);
-    if (variant == 1) return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, (hipStream_t)stream);
-    if (variant == 10)   // the mid-M split-K kernel at any token count (tests, tools)
-        return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0,
-                                   (hipStream_t)stream);
-    if (variant == 20 || variant == 21)   // the 128 x 64 tile of the fused kernel: stream-K (tail always split) / slices mode
-        return variant == 20 ? mxq_launch_gemm8n_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, 1, (hipStream_t)stream)
-                             : mxq_launch_gemm8n_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace,
-                                                            workspace_bytes, 0, (hipStream_t)stream);
-    if (variant == 16 || variant == 17)   // the 64-token tile of the fused kernel: stream-K (tail always split) / slices mode
-        return variant == 16 ? mxq_launch_gemm8q_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, 1, (hipStream_t)stream)
-                             : mxq_launch_gemm8q_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace,
-                                                            workspace_bytes, 0, (hipStream_t)stream);
-    if (variant == 14)   // ... in slices mode (K cut into one slice per idle CU, combine launch)
-        return mxq_launch_gemm8h_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0,
-                                            (hipStream_t)stream);
-    if (variant == 12 || variant == 13)   // the 128-token tile of the fused kernel (13: tail always split)
-        return mxq_launch_gemm8h_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 13,
-                                     (hipStream_t)stream);
-    if (variant == 8 || variant == 9)
-        return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == 9,
-                                    (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {   // enum mxq_gemm_variant (include/mxq_hip.h)
+        case MXQ_GEMM_DEFAULT: return gemm_ws(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, st);
+        case MXQ_GEMM_TILE128: return mxq_launch_gemm1_f16(x, qweight, rowmeta, y, M, N, K, st);
+        case MXQ_GEMM_FUSED256:
+        case MXQ_GEMM_FUSED256_SPLIT:
+            return mxq_launch_gemm8_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == MXQ_GEMM_FUSED256_SPLIT, st);
+        case MXQ_GEMM_MIDM:
+            return mxq_launch_midm_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, 0, st);
+        case MXQ_GEMM_FUSED128:
+        case MXQ_GEMM_FUSED128_SPLIT:
+            return mxq_launch_gemm8h_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, variant == MXQ_GEMM_FUSED128_SPLIT, st);
+        case MXQ_GEMM_FUSED128_SLICES:
+            return mxq_launch_gemm8h_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, st);
+        case MXQ_GEMM_FUSED64_SPLIT:
+            return mxq_launch_gemm8q_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, 1, st);
+        case MXQ_GEMM_FUSED64_SLICES:
+            return mxq_launch_gemm8q_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, st);
+        case MXQ_GEMM_FUSED128N64_SPLIT:
+            return mxq_launch_gemm8n_f16(x, qweight, rowmeta, y, M, N, K, workspace, workspace_bytes, 1, st);
+        case MXQ_GEMM_FUSED128N64_SLICES:
+            return mxq_launch_gemm8n_slices_f16(x, qweight, rowmeta, y, M, N, K, MXQ_LAYOUT_MIXED, workspace, workspace_bytes, 0, st);
+    }
     return MXQ_E_SHAPE;
 }
 

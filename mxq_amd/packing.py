@@ -388,7 +388,7 @@ def linear_dense(x: torch.Tensor, w16: torch.Tensor, out: Optional[torch.Tensor]
     return out.reshape(*x.shape[:-1], N)
 
 
-GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10, "gemm8h": 12, "gemm8h_split": 13, "gemm8h_slices": 14, "gemm8q_split": 16, "gemm8q_slices": 17, "gemm8n_split": 20, "gemm8n_slices": 21}   # include/mxq_hip.h: mxq_gemm_f16_ws variants
+GEMM_PATHS = {"gemm": 0, "fused": 0, "gemm1": 1, "gemm8": 8, "gemm9": 9, "midm": 10, "gemm8h": 12, "gemm8h_split": 13, "gemm8h_slices": 14, "gemm8q_split": 16, "gemm8q_slices": 17, "gemm8n_split": 20, "gemm8n_slices": 21}   # include/mxq_hip.h: enum mxq_gemm_variant
 
 
 def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, path: str = "auto") -> torch.Tensor:
