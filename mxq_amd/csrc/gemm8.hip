@@ -1360,10 +1360,7 @@ template <int LAYOUT>
 static int launch8_slices(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                           void* workspace, size_t ws_bytes, int S, hipStream_t stream) {
     const int NT = K / BK, tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
-#ifndef MXQ_SLICES_MULT
-#define MXQ_SLICES_MULT 1
-#endif
-    if (S <= 0) S = MXQ_SLICES_MULT * cu_count() / tiles;
+    if (S <= 0) S = cu_count() / tiles;               // (2-3 x as many slices, i.e. 2-3 workgroups per CU: no faster, profiles/r05_smalltile_slices.txt)
     if (S > NT / 4) S = NT / 4;                       // at least 4 K-steps per slice
     const size_t room = workspace && ws_bytes > CNT_BYTES ? (ws_bytes - CNT_BYTES) / ((size_t)tiles * BM * BN * sizeof(float)) : 0;
     if ((size_t)S > room) S = (int)room;
