@@ -250,6 +250,14 @@ int mxq_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, 
 int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                         const void* sin_t, void* out, int heads, int head_dim, int max_ctx, void* stream);
 
+/* The same with the rotary table rows of the CURRENT position gathered once per token instead of once per layer:
+ * mxq_rope_row_f32 writes row = {cos_t[*pos][0..half_dim), sin_t[*pos][0..half_dim)} (f32 [2 * half_dim]; *pos clamped
+ * into [0, max_ctx)), and mxq_attn_decode_row_f16 takes that row in place of the two tables -- its launch then has no
+ * load that depends on another load's result except the cache rows beyond the 64th key.  Same arithmetic, same results. */
+int mxq_rope_row_f32(const void* pos, const void* cos_t, const void* sin_t, void* row, int half_dim, int max_ctx, void* stream);
+int mxq_attn_decode_row_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row, void* out,
+                            int heads, int head_dim, int max_ctx, void* stream);
+
 /* Decode-harness glue (BASELINE config 3), not part of the reference's hot path: final RMSNorm + the fp16 lm_head
  * Linear + greedy argmax of ONE token.  h fp16[K], norm_w fp16[K], w fp16[V, K] (row-major nn.Linear weight), K = 4096;
  * the normalised row is fp16(h * rsqrt(mean h^2 + eps)) * norm_w, a logit the fp32 dot rounded to fp16, the result

@@ -141,8 +141,22 @@ int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const voi
                         const void* sin_t, void* out, int heads, int head_dim, int max_ctx, void* stream) {
     if (!qkv || !k_cache || !v_cache || !pos || !cos_t || !sin_t || !out) return MXQ_E_NULL;
     if (heads <= 0 || head_dim != 128 || max_ctx <= 0 || max_ctx > 32768) return MXQ_E_SHAPE;
-    return mxq_launch_attn_decode_f16(qkv, k_cache, v_cache, pos, cos_t, sin_t, out, heads, head_dim, max_ctx,
+    return mxq_launch_attn_decode_f16(qkv, k_cache, v_cache, pos, cos_t, sin_t, out, heads, head_dim, max_ctx, 0,
                                       (hipStream_t)stream);
+}
+
+int mxq_rope_row_f32(const void* pos, const void* cos_t, const void* sin_t, void* row, int half_dim, int max_ctx, void* stream) {
+    if (!pos || !cos_t || !sin_t || !row) return MXQ_E_NULL;
+    if (half_dim <= 0 || half_dim > 4096 || max_ctx <= 0) return MXQ_E_SHAPE;
+    return mxq_launch_rope_row_f32(pos, cos_t, sin_t, row, half_dim, max_ctx, (hipStream_t)stream);
+}
+
+int mxq_attn_decode_row_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row, void* out,
+                            int heads, int head_dim, int max_ctx, void* stream) {
+    if (!qkv || !k_cache || !v_cache || !pos || !rope_row || !out) return MXQ_E_NULL;
+    if (heads <= 0 || head_dim != 128 || max_ctx <= 0 || max_ctx > 32768) return MXQ_E_SHAPE;
+    return mxq_launch_attn_decode_f16(qkv, k_cache, v_cache, pos, rope_row, (const float*)rope_row + head_dim / 2, out, heads,
+                                      head_dim, max_ctx, 1, (hipStream_t)stream);
 }
 
 int mxq_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,

@@ -29,6 +29,10 @@ __device__ __forceinline__ uint16_t f2h(float f) {
 // are loaded (inside the allocation: clamped to max_ctx) and ignored.  Only cos/sin of the position (an L2-resident
 // table) is a second trip, and contexts beyond 64 keys continue with ordinary loads.  The new key / value take part
 // from LDS, not through the cache they are appended to.
+// ROW (round 5): cos_t / sin_t are the ONE row of the rotary tables for this token's position ([HD/2] each, gathered once
+// per token by rope_row_kernel below) instead of the [max_ctx][HD/2] tables: the 128 values are then loaded in round trip 1
+// with everything else, and the dependent second trip (position -> table row) is gone from every layer's launch.
+template <bool ROW>
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t* __restrict__ qkv,
                                                                   uint16_t* __restrict__ k_cache,
                                                                   uint16_t* __restrict__ v_cache,
@@ -62,6 +66,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
 #pragma unroll
         for (int v = 0; v < 4; ++v) kspec[v] = kr[v];
     }
+    float c_row = 0.f, s_row = 0.f;
+    if constexpr (ROW) {
+        c_row = cos_t[d2];
+        s_row = sin_t[d2];
+    }
     const int dg = tid & 15, kg = tid >> 4;                    // P.V: 16 key groups x 16 lanes of 8 dims
     uint4 vspec[4];
 #pragma unroll
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
 
     // ---- round trip 2 (L2-resident table): cos / sin of the position; RoPE on q and k; append k, v at `pos`
     if (tid < HD) {
-        const float c = cos_t[(int64_t)pos * (HD / 2) + d2], s = sin_t[(int64_t)pos * (HD / 2) + d2];
+        const float c = ROW ? c_row : cos_t[(int64_t)pos * (HD / 2) + d2], s = ROW ? s_row : sin_t[(int64_t)pos * (HD / 2) + d2];
         const float q1 = h2f(q1h), q2 = h2f(q2h), k1 = h2f(k1h), k2 = h2f(k2h);
         const float qr = d < HD / 2 ? q1 * c - q2 * s : q2 * c + q1 * s;
         const float kr = d < HD / 2 ? k1 * c - k2 * s : k2 * c + k1 * s;
@@ -176,6 +185,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += o2[g * HD + tid];
         out[h * HD + tid] = f2h(t);
+    }
+}
+
+// cos / sin of the CURRENT position -> one [2][HD/2] row (one launch per token; the position lives in device memory)
+__global__ __launch_bounds__(64) void rope_row_kernel(const int64_t* __restrict__ pos_p, const float* __restrict__ cos_t,
+                                                      const float* __restrict__ sin_t, float* __restrict__ row, int half_dim,
+                                                      int max_ctx) {
+    int64_t pos = *pos_p;
+    pos = pos < 0 ? 0 : pos >= max_ctx ? max_ctx - 1 : pos;    // (an out-of-range position is refused by the attention kernel itself)
+    for (int d = threadIdx.x; d < half_dim; d += 64) {
+        row[d] = cos_t[pos * half_dim + d];
+        row[half_dim + d] = sin_t[pos * half_dim + d];
     }
 }
 
@@ -304,19 +325,33 @@ int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, c
     return (int)hipGetLastError();
 }
 
-int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
-                               const void* sin_t, void* out, int heads, int head_dim, int max_ctx,
-                               hipStream_t stream) {
+template <bool ROW>
+static int launch_attn(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t, const void* sin_t,
+                       void* out, int heads, int head_dim, int max_ctx, hipStream_t stream) {
     if (head_dim != HD) return (int)hipErrorInvalidValue;
     const size_t smem = (size_t)(3 * HD + max_ctx + 8 + 16 * HD) * 4;
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)attn_decode_kernel<ROW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    attn_decode_kernel<<<heads, ATT_THREADS, smem, stream>>>((const uint16_t*)qkv, (uint16_t*)k_cache,
-                                                             (uint16_t*)v_cache, (const int64_t*)pos,
-                                                             (const float*)cos_t, (const float*)sin_t, (uint16_t*)out,
-                                                             heads, max_ctx);
+    attn_decode_kernel<ROW><<<heads, ATT_THREADS, smem, stream>>>((const uint16_t*)qkv, (uint16_t*)k_cache,
+                                                                  (uint16_t*)v_cache, (const int64_t*)pos,
+                                                                  (const float*)cos_t, (const float*)sin_t, (uint16_t*)out,
+                                                                  heads, max_ctx);
+    return (int)hipGetLastError();
+}
+
+int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
+                               const void* sin_t, void* out, int heads, int head_dim, int max_ctx, int rope_row,
+                               hipStream_t stream) {
+    return rope_row ? launch_attn<true>(qkv, k_cache, v_cache, pos, cos_t, sin_t, out, heads, head_dim, max_ctx, stream)
+                    : launch_attn<false>(qkv, k_cache, v_cache, pos, cos_t, sin_t, out, heads, head_dim, max_ctx, stream);
+}
+
+int mxq_launch_rope_row_f32(const void* pos, const void* cos_t, const void* sin_t, void* row, int half_dim, int max_ctx,
+                            hipStream_t stream) {
+    rope_row_kernel<<<1, 64, 0, stream>>>((const int64_t*)pos, (const float*)cos_t, (const float*)sin_t, (float*)row, half_dim,
+                                          max_ctx);
     return (int)hipGetLastError();
 }

@@ -92,6 +92,7 @@ class DecodeStage:
         if last:
             g = torch.Generator(device=dev).manual_seed(98)
             self.lm_head = (torch.randn(vocab, hidden, generator=g, device=dev) * 0.02).half()   # plain fp16 Linear
+        self.rope_row = torch.zeros(2 * (self.hd // 2), dtype=torch.float32, device=dev)   # cos | sin of the current position
         self._graph = None
         self._head_ws = None
         self._head_tok = None
@@ -134,13 +135,19 @@ class DecodeStage:
         logits = torch.nn.functional.linear(self._rms(h), self.lm_head)
         return logits.argmax(dim=-1)
 
+    def _rope_row(self):
+        """cos / sin of the current (device-resident) position, gathered ONCE per step for all of this stage's layers."""
+        _lib.check(_lib.load().mxq_rope_row_f32(self.pos.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(),
+                                                self.rope_row.data_ptr(), self.hd // 2, self.max_ctx,
+                                                torch.cuda.current_stream(self.dev).cuda_stream), "mxq_rope_row_f32")
+
     def _attn(self, qkv, i):
         out = torch.empty((1, self.hidden), dtype=torch.float16, device=self.dev)
         lib = _lib.load()
-        _lib.check(lib.mxq_attn_decode_f16(qkv.data_ptr(), self.k_cache[i].data_ptr(), self.v_cache[i].data_ptr(),
-                                           self.pos.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(),
-                                           out.data_ptr(), self.heads, self.hd, self.max_ctx,
-                                           torch.cuda.current_stream(self.dev).cuda_stream), "mxq_attn_decode_f16")
+        _lib.check(lib.mxq_attn_decode_row_f16(qkv.data_ptr(), self.k_cache[i].data_ptr(), self.v_cache[i].data_ptr(),
+                                               self.pos.data_ptr(), self.rope_row.data_ptr(), out.data_ptr(), self.heads,
+                                               self.hd, self.max_ctx, torch.cuda.current_stream(self.dev).cuda_stream),
+                   "mxq_attn_decode_row_f16")
         return out
 
     def step(self, h):
@@ -148,6 +155,7 @@ class DecodeStage:
         if self.window.pos >= self.max_ctx:
             raise RuntimeError(f"decode position {self.window.pos} is outside the KV cache (max_ctx = {self.max_ctx})")
         if self.fused:
+            self._rope_row()
             for i, (qkv, o, gu, down) in enumerate(self.w):
                 y = packing.linear_fused(h, qkv, 1, self.norm_w)                  # RMSNorm -> q|k|v
                 a = self._attn(y, i)                                              # RoPE + cache + attention

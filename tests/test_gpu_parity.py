@@ -923,6 +923,17 @@ def test_attn_decode_kernel_across_the_prefetched_rows(dev, pos):
     att = (qr[:, None, :] @ kref[:, : pos + 1].float().transpose(1, 2) / hd ** 0.5).half().float().softmax(-1)
     want = (att.half().float() @ vref[:, : pos + 1].float()).reshape(-1)
     assert ((out.float() - want).abs().max() / want.abs().max()).item() < 4e-3
+    # round 5: the position's rotary row gathered once per token (mxq_rope_row_f32) + the kernel variant that takes the row
+    # instead of the tables: same arithmetic, identical bits -- output and both caches
+    row = torch.empty(hd, dtype=torch.float32, device=dev)
+    out2 = torch.empty_like(out)
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.mxq_rope_row_f32(posd.data_ptr(), cos.data_ptr(), sin.data_ptr(), row.data_ptr(), hd // 2, ctx, st), "rope_row")
+    assert torch.equal(row[: hd // 2], cos[pos]) and torch.equal(row[hd // 2:], sin[pos])
+    _lib.check(lib.mxq_attn_decode_row_f16(qkv.data_ptr(), kc2.data_ptr(), vc2.data_ptr(), posd.data_ptr(), row.data_ptr(),
+                                           out2.data_ptr(), heads, hd, ctx, st), "mxq_attn_decode_row_f16")
+    assert torch.equal(out2, out) and torch.equal(kc2, kc) and torch.equal(vc2, vc)
 
 
 @pytest.mark.parametrize("M", [1, 5, 8, 16, 17, 32, 33, 48, 64])
