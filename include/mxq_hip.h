@@ -255,6 +255,10 @@ int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const voi
  * into [0, max_ctx)), and mxq_attn_decode_row_f16 takes that row in place of the two tables -- its launch then has no
  * load that depends on another load's result except the cache rows beyond the 64th key.  Same arithmetic, same results. */
 int mxq_rope_row_f32(const void* pos, const void* cos_t, const void* sin_t, void* row, int half_dim, int max_ctx, void* stream);
+/* ... and the token's embedding row in the same launch, for the stage that owns the embedding: h_out f16[hidden] =
+ * embed f16[vocab, hidden][*token] (token int64[1] on the device, clamped into [0, vocab)), next to the rotary row. */
+int mxq_embed_rope_row(const void* token, const void* embed, int vocab, int hidden, void* h_out, const void* pos, const void* cos_t,
+                       const void* sin_t, void* row, int half_dim, int max_ctx, void* stream);
 int mxq_attn_decode_row_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row, void* out,
                             int heads, int head_dim, int max_ctx, void* stream);
 
@@ -265,6 +269,11 @@ int mxq_attn_decode_row_f16(const void* qkv, void* k_cache, void* v_cache, const
  * part_slots * 8 bytes (>= 256 slots recommended; fewer slots = fewer workgroups). */
 int mxq_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
                           int part_slots, void* token, void* stream);
+/* The same, plus the token loop's bookkeeping in the second launch: the id is also stored at generated[*pos] (int64
+ * [max_generated], nullable; skipped when *pos is outside it) and the device-resident position *pos (int64[1]) moves on by
+ * one -- a decoded token then costs no separate "position += 1" and "append the id" launches. */
+int mxq_lmhead_argmax_advance_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
+                                  int part_slots, void* token, void* pos, void* generated, int max_generated, void* stream);
 
 /* MXAsymQuantizer.forward (utils_quant.py:316-462; 2-D, layerwise=False branch):
  * fake-quantise w[rows, cols] of `dtype` into out (same shape/dtype), bit-identical to

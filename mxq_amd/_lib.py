@@ -66,6 +66,9 @@ SIGNATURES = {
     "mxq_lmhead_argmax_f16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mxq_attn_decode_f16": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     "mxq_rope_row_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "mxq_embed_rope_row": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mxq_lmhead_argmax_advance_f16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                              c_void_p, c_int, c_void_p]),
     "mxq_attn_decode_row_f16": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
     "mxq_fakequant_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_fakequant_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),

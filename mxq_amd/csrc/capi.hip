@@ -148,7 +148,15 @@ int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const voi
 int mxq_rope_row_f32(const void* pos, const void* cos_t, const void* sin_t, void* row, int half_dim, int max_ctx, void* stream) {
     if (!pos || !cos_t || !sin_t || !row) return MXQ_E_NULL;
     if (half_dim <= 0 || half_dim > 4096 || max_ctx <= 0) return MXQ_E_SHAPE;
-    return mxq_launch_rope_row_f32(pos, cos_t, sin_t, row, half_dim, max_ctx, (hipStream_t)stream);
+    return mxq_launch_rope_row_f32(pos, cos_t, sin_t, row, half_dim, max_ctx, nullptr, nullptr, 0, 0, nullptr, (hipStream_t)stream);
+}
+
+int mxq_embed_rope_row(const void* token, const void* embed, int vocab, int hidden, void* h_out, const void* pos, const void* cos_t,
+                       const void* sin_t, void* row, int half_dim, int max_ctx, void* stream) {
+    if (!token || !embed || !h_out || !pos || !cos_t || !sin_t || !row) return MXQ_E_NULL;
+    if (vocab <= 0 || hidden <= 0 || hidden % 8 != 0 || half_dim <= 0 || half_dim > 4096 || max_ctx <= 0) return MXQ_E_SHAPE;
+    if (!aligned16(embed) || !aligned16(h_out)) return MXQ_E_ALIGN;
+    return mxq_launch_rope_row_f32(pos, cos_t, sin_t, row, half_dim, max_ctx, token, embed, vocab, hidden, h_out, (hipStream_t)stream);
 }
 
 int mxq_attn_decode_row_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row, void* out,
@@ -164,7 +172,16 @@ int mxq_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const vo
     if (!h || !norm_w || !w || !part || !token) return MXQ_E_NULL;
     if (V <= 0 || K != 4096 || part_slots < 1) return MXQ_E_SHAPE;
     if (!aligned16(h) || !aligned16(norm_w) || !aligned16(w)) return MXQ_E_ALIGN;
-    return mxq_launch_lmhead_argmax_f16(h, norm_w, eps, w, V, K, part, part_slots, token, (hipStream_t)stream);
+    return mxq_launch_lmhead_argmax_f16(h, norm_w, eps, w, V, K, part, part_slots, token, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+int mxq_lmhead_argmax_advance_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
+                                  int part_slots, void* token, void* pos, void* generated, int max_generated, void* stream) {
+    if (!h || !norm_w || !w || !part || !token || !pos) return MXQ_E_NULL;
+    if (V <= 0 || K != 4096 || part_slots < 1 || max_generated < 0 || (generated && max_generated == 0)) return MXQ_E_SHAPE;
+    if (!aligned16(h) || !aligned16(norm_w) || !aligned16(w)) return MXQ_E_ALIGN;
+    return mxq_launch_lmhead_argmax_f16(h, norm_w, eps, w, V, K, part, part_slots, token, pos, generated, max_generated,
+                                        (hipStream_t)stream);
 }
 
 // ---- uniform layouts of the config-5 sweep ---------------------------------------------------

@@ -189,15 +189,22 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
 }
 
 // cos / sin of the CURRENT position -> one [2][HD/2] row (one launch per token; the position lives in device memory)
-__global__ __launch_bounds__(64) void rope_row_kernel(const int64_t* __restrict__ pos_p, const float* __restrict__ cos_t,
-                                                      const float* __restrict__ sin_t, float* __restrict__ row, int half_dim,
-                                                      int max_ctx) {
+// ... and, for the stage that owns the embedding, the token's embedding row in the same launch (tok nullable): a token's
+// two table look-ups are one small launch instead of two (each costs ~4.5 us of launch + cold round trip)
+__global__ __launch_bounds__(256) void rope_row_kernel(const int64_t* __restrict__ pos_p, const float* __restrict__ cos_t,
+                                                       const float* __restrict__ sin_t, float* __restrict__ row, int half_dim,
+                                                       int max_ctx, const int64_t* __restrict__ tok, const uint16_t* __restrict__ embed,
+                                                       int vocab, int hidden, uint16_t* __restrict__ h_out) {
     int64_t pos = *pos_p;
     pos = pos < 0 ? 0 : pos >= max_ctx ? max_ctx - 1 : pos;    // (an out-of-range position is refused by the attention kernel itself)
-    for (int d = threadIdx.x; d < half_dim; d += 64) {
+    int64_t t = tok ? *tok : 0;
+    t = t < 0 ? 0 : t >= vocab ? vocab - 1 : t;
+    for (int d = threadIdx.x; d < half_dim; d += 256) {
         row[d] = cos_t[pos * half_dim + d];
         row[half_dim + d] = sin_t[pos * half_dim + d];
     }
+    if (tok)
+        for (int i = threadIdx.x; i < hidden / 8; i += 256) ((uint4*)h_out)[i] = ((const uint4*)(embed + t * hidden))[i];
 }
 
 // Final RMSNorm + lm_head (a plain fp16 Linear in the reference: MXQ quantises the decoder Linears only) + greedy
@@ -278,8 +285,11 @@ __global__ __launch_bounds__(LMH_THREADS) void lmhead_argmax_kernel(const uint16
         part_idx[blockIdx.x] = besti;
     }
 }
+// advance (nullable): the device-resident position -- the token id is also appended at generated[*advance] (nullable,
+// max_generated slots) and the position moves on by one: the token loop's bookkeeping without its two tiny launches
 __global__ __launch_bounds__(64) void lmhead_final_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
-                                                          int n, int64_t* __restrict__ token) {
+                                                          int n, int64_t* __restrict__ token, int64_t* __restrict__ advance,
+                                                          int64_t* __restrict__ generated, int max_generated) {
     const int lane = threadIdx.x;
     float best = -INFINITY;
     int besti = 0x7FFFFFFF;
@@ -305,13 +315,22 @@ __global__ __launch_bounds__(64) void lmhead_final_kernel(const float* __restric
         const int ix = __shfl_xor(besti, o, 64);
         if (v > best || (v == best && ix < besti)) { best = v; besti = ix; }
     }
-    if (lane == 0) *token = besti == 0x7FFFFFFF ? 0 : besti;
+    if (lane == 0) {
+        const int64_t id = besti == 0x7FFFFFFF ? 0 : besti;
+        *token = id;
+        if (advance) {
+            const int64_t p = *advance;
+            if (generated && p >= 0 && p < max_generated) generated[p] = id;
+            *advance = p + 1;
+        }
+    }
 }
 
 }   // namespace
 
 int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
-                                 int part_slots, void* token, hipStream_t stream) {
+                                 int part_slots, void* token, void* advance, void* generated, int max_generated,
+                                 hipStream_t stream) {
     if (K != LMH_K) return (int)hipErrorInvalidValue;
     int wgs = (V + 3) / 4;
     if (wgs > part_slots) wgs = part_slots;
@@ -321,7 +340,7 @@ int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, c
     int* pi = (int*)(pv + part_slots);
     lmhead_argmax_kernel<<<wgs, LMH_THREADS, 0, stream>>>((const uint16_t*)h, (const uint16_t*)norm_w, eps,
                                                           (const uint16_t*)w, V, pv, pi);
-    lmhead_final_kernel<<<1, 64, 0, stream>>>(pv, pi, wgs, (int64_t*)token);
+    lmhead_final_kernel<<<1, 64, 0, stream>>>(pv, pi, wgs, (int64_t*)token, (int64_t*)advance, (int64_t*)generated, max_generated);
     return (int)hipGetLastError();
 }
 
@@ -350,8 +369,8 @@ int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, co
 }
 
 int mxq_launch_rope_row_f32(const void* pos, const void* cos_t, const void* sin_t, void* row, int half_dim, int max_ctx,
-                            hipStream_t stream) {
-    rope_row_kernel<<<1, 64, 0, stream>>>((const int64_t*)pos, (const float*)cos_t, (const float*)sin_t, (float*)row, half_dim,
-                                          max_ctx);
+                            const void* tok, const void* embed, int vocab, int hidden, void* h_out, hipStream_t stream) {
+    rope_row_kernel<<<1, 256, 0, stream>>>((const int64_t*)pos, (const float*)cos_t, (const float*)sin_t, (float*)row, half_dim,
+                                           max_ctx, (const int64_t*)tok, (const uint16_t*)embed, vocab, hidden, (uint16_t*)h_out);
     return (int)hipGetLastError();
 }

@@ -9,7 +9,7 @@
 // A 32-bit word holds channels e = 0..7 in nibbles (0, 4, 1, 5, 2, 6, 3, 7): dequantize_s4_to_fp16x2 returns the halves
 // (n0, n4 | n1, n5 | n2, n6 | n3, n7) as elements 0..7 (dequantize.cuh:35-51).  The reference subtracts the zero and
 // multiplies by the scale in fp16 (sub.f16x2, fma.rn.f16x2 with a zero addend, gemm_cuda_gen.cu:134-141): q - z is an
-// exact integer, so the weight is the product rounded ONCE to fp16 -- reproduced here as fp16(float(q - z) * float(s)).
+// exact integer, so the weight is the product rounded ONCE to fp16 -- reproduced here with the same packed fp16 operations.
 //
 // The weight is K-major (a word = 8 channels at one k), the MFMA operand wants 8 consecutive k of one channel: a thread
 // takes the 4 words of (channel octet c, 4 consecutive k), dequantises the 8 x 4 block in registers and writes 8 rows of
@@ -27,14 +27,15 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
 constexpr int SMEM_BYTES = 2 * STAGE_BYTES;   // 64 KiB -> 2 workgroups per CU
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
-// nibble position of channel e of a word (dequantize.cuh:35-51): (0, 4, 1, 5, 2, 6, 3, 7)
-__device__ __forceinline__ int nib_shift(int e) { return 4 * ((e >> 1) + 4 * (e & 1)); }
+// (channel e of a word sits in nibble (0, 4, 1, 5, 2, 6, 3, 7)[e], dequantize.cuh:35-51: the even nibbles' pair masks give
+//  channels (0, 1) and (4, 5), the odd nibbles' (2, 3) and (6, 7))
 
 struct WStage {
     uint32_t q[4];   // code words of (octet c, k = 4 kq .. 4 kq + 3)
@@ -90,20 +91,50 @@ __global__ __launch_bounds__(256, 2) void mxq_gemm_awq_f16_kernel(const uint16_t
         st.z = zeros[g * OC8 + oc8];
         st.s = *(const uint4*)(scales + g * OC + (int64_t)oc8 * 8);
     };
+    // Dequant = the reference's own method (dequantize.cuh:15-78 + gemm_cuda_gen.cu:134-141) in packed fp16: a masked word OR-ed
+    // into 0x6400 reads (1024 + q) [or 1024 + 16 q for the odd nibbles], and
+    //     (1024 + q) - (1024 + z)            = q - z        exact
+    //     (1024 + 16 q) / 16 - (64 + z)      = q - z        exact (one v_pk_fma_f16)
+    // then ONE rounding in the multiply by the scale -- 13 packed ops per word of 8 weights.  The packed results hold
+    // channels (2 j, 2 j + 1) at one k; two v_perm_b32 per channel gather its four k's.
     auto write_w = [&](const WStage& st, int buf) {
         char* base = smem + buf * STAGE_BYTES + A_BYTES;
-        const uint32_t sw[4] = {st.s.x, st.s.y, st.s.z, st.s.w};
+        constexpr uint32_t LO = 0x000f000fu, HI = 0x00f000f0u, MAGIC = 0x64006400u;
+        const h2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+        auto pairs = [&](uint32_t w, h2 (&o)[4]) {    // o[j] = (1024 + n) or (1024 + 16 n) of channels (2 j, 2 j + 1)
+            const uint32_t t = w >> 8;
+            o[0] = __builtin_bit_cast(h2, (w & LO) | MAGIC);
+            o[1] = __builtin_bit_cast(h2, (w & HI) | MAGIC);
+            o[2] = __builtin_bit_cast(h2, (t & LO) | MAGIC);
+            o[3] = __builtin_bit_cast(h2, (t & HI) | MAGIC);
+        };
+        h2 zc[4];                                     // 1024 + z (even pairs) / 64 + z (odd pairs)
+        pairs(st.z, zc);
+        zc[1] = __builtin_elementwise_fma(zc[1], sixteenth, (h2){(_Float16)0.f, (_Float16)0.f});   // 64 + z, exact
+        zc[3] = __builtin_elementwise_fma(zc[3], sixteenth, (h2){(_Float16)0.f, (_Float16)0.f});
+        const h2 sp[4] = {__builtin_bit_cast(h2, st.s.x), __builtin_bit_cast(h2, st.s.y), __builtin_bit_cast(h2, st.s.z),
+                          __builtin_bit_cast(h2, st.s.w)};
+        uint32_t r[4][4];                              // r[i][j]: weights of channels (2 j, 2 j + 1) at k = 4 kq + i
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int sh = nib_shift(e);
-            const float zf = (float)(int)((st.z >> sh) & 15u);
-            const float sf = (float)__builtin_bit_cast(_Float16, (uint16_t)(sw[e >> 1] >> (16 * (e & 1))));
-            half4 w;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = (_Float16)(((float)(int)((st.q[i] >> sh) & 15u) - zf) * sf);
-            // row = channel 8 c + e of the tile, k offset 4 kq: 16-byte slot kq >> 1, its half kq & 1
-            *(half4*)(base + swz(c * 8 + e, kq >> 1) + (kq & 1) * 8) = w;
+        for (int i = 0; i < 4; ++i) {
+            h2 q[4];
+            pairs(st.q[i], q);
+            r[i][0] = __builtin_bit_cast(uint32_t, (q[0] - zc[0]) * sp[0]);
+            r[i][1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(q[1], sixteenth, -zc[1]) * sp[1]);
+            r[i][2] = __builtin_bit_cast(uint32_t, (q[2] - zc[2]) * sp[2]);
+            r[i][3] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(q[3], sixteenth, -zc[3]) * sp[3]);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int odd = 0; odd < 2; ++odd) {
+                const uint32_t sel = odd ? 0x07060302u : 0x05040100u;      // the high / low halves of (second, first)
+                uint2 w;
+                w.x = __builtin_amdgcn_perm(r[1][j], r[0][j], sel);
+                w.y = __builtin_amdgcn_perm(r[3][j], r[2][j], sel);
+                // row = channel 8 c + 2 j + odd of the tile, k offset 4 kq: 16-byte slot kq >> 1, its half kq & 1
+                *(uint2*)(base + swz(c * 8 + 2 * j + odd, kq >> 1) + (kq & 1) * 8) = w;
+            }
     };
 
     const int wm = wave >> 1, wn = wave & 1;

@@ -105,12 +105,13 @@ int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* ro
                               int prologue, const void* norm_w, float eps, const void* residual, int compact,
                               hipStream_t stream);
 int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
-                                 int part_slots, void* token, hipStream_t stream);
+                                 int part_slots, void* token, void* advance, void* generated, int max_generated,
+                                 hipStream_t stream);
 int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                                const void* sin_t, void* out, int heads, int head_dim, int max_ctx, int rope_row,
                                hipStream_t stream);   // rope_row: cos_t / sin_t are the position's ONE row (mxq_launch_rope_row_f32)
 int mxq_launch_rope_row_f32(const void* pos, const void* cos_t, const void* sin_t, void* row, int half_dim, int max_ctx,
-                            hipStream_t stream);
+                            const void* tok, const void* embed, int vocab, int hidden, void* h_out, hipStream_t stream);
 int mxq_launch_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype,
                              hipStream_t stream);
 int mxq_launch_fakequant_bwd(const void* grad_out, const void* w, void* grad_in, int64_t n, float lo, float hi,

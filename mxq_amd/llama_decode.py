@@ -150,12 +150,14 @@ class DecodeStage:
                    "mxq_attn_decode_row_f16")
         return out
 
-    def step(self, h):
-        """One token through this stage's layers.  h [1, hidden] fp16."""
+    def step(self, h, rope_done: bool = False):
+        """One token through this stage's layers.  h [1, hidden] fp16.  ``rope_done``: the caller has already gathered the
+        position's rotary row (the token loop does it together with the embedding look-up)."""
         if self.window.pos >= self.max_ctx:
             raise RuntimeError(f"decode position {self.window.pos} is outside the KV cache (max_ctx = {self.max_ctx})")
         if self.fused:
-            self._rope_row()
+            if not rope_done:
+                self._rope_row()
             for i, (qkv, o, gu, down) in enumerate(self.w):
                 y = packing.linear_fused(h, qkv, 1, self.norm_w)                  # RMSNorm -> q|k|v
                 a = self._attn(y, i)                                              # RoPE + cache + attention
@@ -214,10 +216,32 @@ class DecodeStage:
         if getattr(self, "embed", None) is None or getattr(self, "lm_head", None) is None:
             raise ValueError("capture_token_loop needs the first and the last stage in one process")
 
+        # Llama-width fused stages: the token's two table look-ups (embedding row, rotary row) are ONE launch, and the head's
+        # second launch also appends the id to a device-side list and advances the position: 4 + 32 x 5 launches per token,
+        # nothing between two graph replays
+        native = (self.fused and self.hidden == 4096 and token_buf.dtype == torch.int64 and token_buf.numel() == 1
+                  and token_buf.is_contiguous())
+        self._generated = torch.zeros(self.max_ctx, dtype=torch.int64, device=self.dev) if native else None
+        lib = _lib.load()
+
         def one():
-            t = self.head(self.step(self.embed_token(token_buf)), out=token_buf)
-            if t is not token_buf:
-                token_buf.copy_(t.reshape(-1)[:1])
+            if not native:
+                t = self.head(self.step(self.embed_token(token_buf)), out=token_buf)
+                if t is not token_buf:
+                    token_buf.copy_(t.reshape(-1)[:1])
+                self.pos += 1
+                return
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            _lib.check(lib.mxq_embed_rope_row(token_buf.data_ptr(), self.embed.data_ptr(), self.embed.shape[0], self.hidden,
+                                              self._h_in.data_ptr(), self.pos.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(),
+                                              self.rope_row.data_ptr(), self.hd // 2, self.max_ctx, st), "mxq_embed_rope_row")
+            h = self.step(self._h_in, rope_done=True).contiguous()
+            if self._head_ws is None:
+                self._head_ws = torch.empty(2 * 1024, dtype=torch.float32, device=self.dev)
+            _lib.check(lib.mxq_lmhead_argmax_advance_f16(h.data_ptr(), self.norm_w.data_ptr(), 1e-5, self.lm_head.data_ptr(),
+                                                         self.lm_head.shape[0], self.hidden, self._head_ws.data_ptr(), 1024,
+                                                         token_buf.data_ptr(), self.pos.data_ptr(), self._generated.data_ptr(),
+                                                         self.max_ctx, st), "mxq_lmhead_argmax_advance_f16")
         for _ in range(2):
             one()
         self.pos.zero_()
@@ -225,15 +249,18 @@ class DecodeStage:
         self._tgraph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._tgraph):
             one()
-            self.pos += 1
         self.pos.zero_()
         self.window.reset()
         return self
 
     def decode_tokens(self, token_buf: torch.Tensor, first_token: int, n_tokens: int):
         """Greedy decode with the graph of ``capture_token_loop``; returns the generated ids."""
-        self.window.take(n_tokens)             # every replay advances the device position by one
+        p0 = self.window.take(n_tokens)        # every replay advances the device position by one
         token_buf.fill_(int(first_token))
+        if getattr(self, "_generated", None) is not None:      # the graph itself appends the ids at generated[position]
+            for _ in range(n_tokens):
+                self._tgraph.replay()
+            return self._generated[p0:p0 + n_tokens].tolist()
         out = torch.zeros(n_tokens, dtype=token_buf.dtype, device=token_buf.device)
         for i in range(n_tokens):
             self._tgraph.replay()
