@@ -240,6 +240,17 @@ int mxq_gemv_f16_layout(const void* x, const void* qweight, const void* rowmeta,
  *   x <- silu(gate) * up.  residual (nullable, fp16 [N]): y <- residual + W.x. */
 int mxq_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K, int prologue,
                        const void* norm_w, float eps, const void* residual, void* stream);
+/* The decoder MLP's two launches with the SwiGLU moved from the consumer's staging into the producer's final reduction
+ * (round 5; no reference counterpart).  mxq_gemv_swiglu_f16: x fp16[K] -> RMSNorm prologue (norm_w, eps) -> the weight
+ * [N2 = 2 I, K] = gate stacked on up; a workgroup takes the same 16 rows of gate and of up, and writes
+ * act = fp16(silu(gate)) * up -- one 16-column scale group of the down projection's input -- in the kernels' staged order
+ * (per eight: x0, x2, x1, x3, x4, x6, x5, x7) into `act` (fp16 [I]) with the group's fp32 sum in `act_sum` (f32 [I / 16]).
+ * mxq_gemv_staged_f16: y fp16[N] = residual (nullable) + W[N, K] . act for such a staged row.  Bit for bit the results of
+ * mxq_gemv_fused_f16 prologue 1 followed by prologue 2.  N2 % 32 == 0, K % 256 == 0 (first call). */
+int mxq_gemv_swiglu_f16(const void* x, const void* qweight, const void* rowmeta, void* act, void* act_sum, int N2, int K,
+                        const void* norm_w, float eps, int compact, void* stream);
+int mxq_gemv_staged_f16(const void* x_staged, const void* x_sum, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                        const void* residual, int compact, void* stream);
 /* Decode-harness glue (BASELINE config 3), not part of the reference's hot path: rotary embedding
  * of q/k, KV-cache append at *pos and single-query attention for one token; one workgroup per
  * head, head_dim 128.  qkv fp16 [3*heads*128]; caches fp16 [heads][max_ctx][128]; pos int64[1]

@@ -63,6 +63,8 @@ SIGNATURES = {
     "mxq_gemm_f16_layout": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_gemv_f16_layout": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_gemv_fused_f16": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p]),
+    "mxq_gemv_swiglu_f16": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_float, c_int, c_void_p]),
+    "mxq_gemv_staged_f16": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_int, c_void_p]),
     "mxq_lmhead_argmax_f16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mxq_attn_decode_f16": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     "mxq_rope_row_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),

@@ -137,6 +137,22 @@ int mxq_gemv_fused_f16_compact(const void* x, const void* qweight, const void* r
                                      (hipStream_t)stream);
 }
 
+int mxq_gemv_swiglu_f16(const void* x, const void* qweight, const void* rowmeta, void* act, void* act_sum, int N2, int K,
+                        const void* norm_w, float eps, int compact, void* stream) {
+    if (!x || !qweight || !rowmeta || !act || !act_sum || !norm_w) return MXQ_E_NULL;
+    if (!shape_ok(N2, K) || N2 % 32 != 0 || K % 256 != 0) return MXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(rowmeta) || !aligned16(act) || ((uintptr_t)act_sum & 3)) return MXQ_E_ALIGN;
+    return mxq_launch_gemv_swiglu_f16(x, qweight, rowmeta, act, act_sum, N2, K, norm_w, eps, compact != 0, (hipStream_t)stream);
+}
+
+int mxq_gemv_staged_f16(const void* x_staged, const void* x_sum, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                        const void* residual, int compact, void* stream) {
+    if (int e = linear_check(x_staged, qweight, rowmeta, y, 1, N, K)) return e;
+    if (!x_sum) return MXQ_E_NULL;
+    if ((uintptr_t)x_sum & 3) return MXQ_E_ALIGN;
+    return mxq_launch_gemv_staged_f16(x_staged, x_sum, qweight, rowmeta, y, N, K, residual, compact != 0, (hipStream_t)stream);
+}
+
 int mxq_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                         const void* sin_t, void* out, int heads, int head_dim, int max_ctx, void* stream) {
     if (!qkv || !k_cache || !v_cache || !pos || !cos_t || !sin_t || !out) return MXQ_E_NULL;

@@ -72,13 +72,23 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // residual (nullable): y <- residual + W.x (the decoder layer's skip connection).
 // LAYOUT: MXQ_LAYOUT_MIXED / MIXEDC (3 two-bit groups + the 4-bit quarter per chunk; exact / compact metadata),
 // MXQ_LAYOUT_W2G16 (4 two-bit groups) or MXQ_LAYOUT_W4ROW (4 four-bit quarters, scale / zero per row from rowmeta).
-template <int MB, int GEMV_THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED, int RB = 1>
+//   3 = the input row is ALREADY staged (round 5): fp16 values in the code-dot order + their per-group fp32 sums in `aux`
+//   (float [K / 16]) -- what the EPI = 1 launch below writes; the staging is a plain copy into LDS.
+// EPI 1 (round 5; RB == 2, M == 1): the weight is gate | up stacked ([2 * I, K]); the workgroup takes the PAIR of row blocks
+// (i, i + I / 16) -- the same 16 rows of gate and of up -- and its final reduction applies SwiGLU itself: act = fp16(silu(gate))
+// * up, the 16 values ONE scale group of the down projection's input, written in the code-dot order with their fp32 sum
+// (y = the staged row [I], aux = the sums [I / 16]).  Bit for bit the values the PRO 2 staging computes from the fp16
+// gate | up row, computed once by the producer instead of by every consumer workgroup (22 KB instead of 44 KB per
+// consumer, no exp).
+template <int MB, int GEMV_THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED, int RB = 1, int EPI = 0>
 __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16_t* __restrict__ x,
                                                                      const uint32_t* __restrict__ qweight,
                                                                      const float4* __restrict__ rowmeta,
                                                                      uint16_t* __restrict__ y, int M, int N, int K,
                                                                      const uint16_t* __restrict__ norm_w, float eps,
-                                                                     const uint16_t* __restrict__ residual) {
+                                                                     const uint16_t* __restrict__ residual,
+                                                                     float* __restrict__ aux) {
+    static_assert(EPI == 0 || (RB == 2 && MB == 1), "the SwiGLU epilogue pairs two row blocks of one token");
     constexpr int W = GEMV_THREADS / 64;
     constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC;   // exact / compact metadata
     constexpr bool COMPACT = LAYOUT == MXQ_LAYOUT_MIXEDC;
@@ -90,9 +100,10 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, cs = lane >> 4;
-    const int rb0 = blockIdx.x * RB;                    // this workgroup's first row block
+    const int rb0 = EPI ? blockIdx.x : blockIdx.x * RB;   // this workgroup's first row block
+    const int PS = EPI ? N / 32 : 1;                      // row-block distance between the workgroup's row blocks
     const int NC = K / 64, NC4 = (NC + 3) / 4, NG = K / 16;
-    const int nrb = min(RB, N / 16 - rb0);              // ... and how many it has (the last workgroup may have fewer)
+    const int nrb = EPI ? 2 : min(RB, N / 16 - rb0);      // ... and how many it has (the last workgroup may have fewer)
     const int NT = nrb * NC4;                           // its tile list (RB > 1 only when K % 256 == 0: tiles never straddle)
     GEMV_STAMP(0)
 
@@ -105,6 +116,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     struct Act {
         h8 a0, a1;     // 16 activations (one scale group)
         h8 b0, b1;     // PRO 1: their RMSNorm weights; PRO 2: the up projection (a = gate)
+        float sum;     // PRO 3: the group's fp32 sum, as staged by the producer
     };
     auto load_act = [&](int i) {
         Act t;
@@ -121,6 +133,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
             t.b0 = *(const h8*)(xr + K);
             t.b1 = *(const h8*)(xr + K + 8);
         }
+        if constexpr (PRO == 3) t.sum = aux[g];
         return t;                                       // (nothing here may USE a loaded value: that would be a wait)
     };
     const Act act0 = load_act(tid), act1 = load_act(tid + GEMV_THREADS);
@@ -131,11 +144,14 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
         uint2 qq[NG2 ? NG2 : 1];
     };
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(qweight + (int64_t)rb0 * NC * BLK_DW), 0, nrb * NC * BLK_DW * 4, 0x00020000);
+        (void*)(qweight + (int64_t)rb0 * NC * BLK_DW), 0, EPI ? (PS + 1) * NC * BLK_DW * 4 : nrb * NC * BLK_DW * 4, 0x00020000);
     const int lane_off = (cs * BLK_DW) * 4;             // byte offset of the lane's block inside a tile
     auto load_tile = [&](int c4) {                      // tile index in the list; beyond its end (or a chunk >= NC): zeros, no traffic
         Tile t = {};
-        const int so = c4 * (4 * BLK_DW * 4);           // wave-uniform
+        int so = c4 * (4 * BLK_DW * 4);                 // wave-uniform
+        if constexpr (EPI) {   // the second row block lies PS row blocks on; a tile past the list: an offset beyond the buffer
+            so = c4 < NC4 ? so : c4 < 2 * NC4 ? (PS * NC * BLK_DW + (c4 - NC4) * 4 * BLK_DW) * 4 : (int)0xC0000000u;
+        }
         auto dw = [&](int idx) { return __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off + idx * 4, so, MXQ_GEMV_WAUX); };
         if constexpr (LAYOUT == MXQ_LAYOUT_W4ROW) {
 #pragma unroll
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     // behind tile 1, and the loop's first wait then covers most of tile 1 in EVERY iteration)
     // the 4-bit arm's per-row parameters are applied in the final reduction: thread (row block, token, row) loads its own
     const int f_rbl = tid / (MB * 16), f_m = (tid >> 4) % MB, f_r = tid & 15;
-    const float4 rm = rowmeta[min(rb0 + min(f_rbl, nrb - 1), N / 16 - 1) * 16 + f_r];
+    const float4 rm = rowmeta[min(rb0 + min(f_rbl, nrb - 1) * PS, N / 16 - 1) * 16 + f_r];
     __builtin_amdgcn_sched_barrier(0);
     Tile T0 = load_tile(wave);
     __builtin_amdgcn_sched_barrier(0);
@@ -200,8 +216,15 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
             }
         }
         float sum = 0.f;
-        const uint4 o0 = stage8(__builtin_bit_cast(uint4, t.a0), sum);
-        const uint4 o1 = stage8(__builtin_bit_cast(uint4, t.a1), sum);
+        uint4 o0, o1;
+        if constexpr (PRO == 3) {                      // staged by the producer: a plain copy
+            o0 = __builtin_bit_cast(uint4, t.a0);
+            o1 = __builtin_bit_cast(uint4, t.a1);
+            sum = t.sum;
+        } else {
+            o0 = stage8(__builtin_bit_cast(uint4, t.a0), sum);
+            o1 = stage8(__builtin_bit_cast(uint4, t.a1), sum);
+        }
         char* dst = live ? smem + (size_t)i * 32 : dummy + lane * 32;
         float* sdst = live ? xsum + i : (float*)(dummy + 64 * 32) + lane;
         *(uint4*)dst = o0;
@@ -325,7 +348,25 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
             for (int w = 0; w < W; ++w) tot += wsum[w];
             v *= rsqrtf(tot / (float)K + eps);
         }
-        if (f_m < M) {
+        if constexpr (EPI == 1) {
+            // threads 0..15 hold the gate rows, 16..31 the up rows of the pair (one wave): SwiGLU exactly as the PRO 2
+            // staging computes it from the fp16 row, then the code-dot order (x0, x2, x1, x3, x4, x6, x5, x7 per eight) and the
+            // group's fp32 sum in element order
+            const _Float16 h = (_Float16)v;
+            const uint32_t hb = __builtin_bit_cast(uint16_t, h);
+            const uint32_t ub = __shfl(hb, (lane + 16) & 31, 64);
+            const float g0 = (float)h;
+            const _Float16 act = (_Float16)(g0 / (1.0f + __expf(-g0))) * __builtin_bit_cast(_Float16, (uint16_t)ub);
+            const uint32_t ab = __builtin_bit_cast(uint16_t, act);
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += (float)__builtin_bit_cast(_Float16, (uint16_t)__shfl(ab, r, 64));
+            if (tid < 16) {
+                const int e = f_r & 7, pos = (f_r & 8) | ((e == 1 || e == 2) ? (e ^ 3) : (e == 5 || e == 6) ? (e ^ 3) : e);
+                y[rb0 * 16 + pos] = (uint16_t)ab;
+                if (tid == 0) aux[rb0] = sum;
+            }
+        } else if (f_m < M) {
             const int n = (rb0 + f_rbl) * 16 + f_r;
             _Float16 h = (_Float16)v;
             if (residual) h = __builtin_bit_cast(_Float16, residual[(int64_t)f_m * N + n]) + h;
@@ -335,22 +376,22 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
     GEMV_STAMP(3)
 }
 
-template <int MB, int THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED, int RB = 1>
+template <int MB, int THREADS, int PRO, int LAYOUT = MXQ_LAYOUT_MIXED, int RB = 1, int EPI = 0>
 int launch_t(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-             const void* norm_w, float eps, const void* residual, hipStream_t stream) {
+             const void* norm_w, float eps, const void* residual, hipStream_t stream, void* aux = nullptr) {
     constexpr int W = THREADS / 64;
     static_assert(RB * MB * 16 <= THREADS, "one thread per output of the final reduction");
     const size_t smem = (size_t)MB * K * 2 + (size_t)MB * (K / 16) * 4 + (size_t)RB * W * MB * 16 * 3 * 4 + (size_t)W * 4 +
                         64 * 32 + 64 * 4;
     if (smem > 64 * 1024) {
         // (the attribute is a ceiling: the CU's whole LDS, set once per kernel and device)
-        hipError_t e = mxq_set_dyn_lds_once<&mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT, RB>>(160 * 1024);
+        hipError_t e = mxq_set_dyn_lds_once<&mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT, RB, EPI>>(160 * 1024);
         if (e != hipSuccess) return (int)e;
     }
     const int rbs = N / 16;
-    mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT, RB><<<(rbs + RB - 1) / RB, THREADS, smem, stream>>>(
+    mxq_gemv_f16_kernel<MB, THREADS, PRO, LAYOUT, RB, EPI><<<EPI ? rbs / 2 : (rbs + RB - 1) / RB, THREADS, smem, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K,
-        (const uint16_t*)norm_w, eps, (const uint16_t*)residual);
+        (const uint16_t*)norm_w, eps, (const uint16_t*)residual, (float*)aux);
     return (int)hipGetLastError();
 }
 
@@ -432,6 +473,39 @@ int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* ro
                               hipStream_t stream) {
     return compact ? fused_layout<MXQ_LAYOUT_MIXEDC>(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual, stream)
                    : fused_layout<MXQ_LAYOUT_MIXED>(x, qweight, rowmeta, y, N, K, prologue, norm_w, eps, residual, stream);
+}
+
+// gate | up of ONE token with the SwiGLU applied in the final reduction (EPI 1 above): x fp16 [K] (RMSNorm prologue), weight
+// [2 I, K] = gate stacked on up, act fp16 [I] in the code-dot order, act_sum f32 [I / 16].  K % 256 == 0, (2 I) % 32 == 0.
+int mxq_launch_gemv_swiglu_f16(const void* x, const void* qweight, const void* rowmeta, void* act, void* act_sum, int N2, int K,
+                               const void* norm_w, float eps, int compact, hipStream_t stream) {
+    const int M = 1;
+    const void* residual = nullptr;
+    if (N2 % 32 != 0 || K % 256 != 0) return -1;
+    return compact ? launch_t<1, 256, 1, MXQ_LAYOUT_MIXEDC, 2, 1>(x, qweight, rowmeta, act, M, N2, K, norm_w, eps, residual, stream, act_sum)
+                   : launch_t<1, 256, 1, MXQ_LAYOUT_MIXED, 2, 1>(x, qweight, rowmeta, act, M, N2, K, norm_w, eps, residual, stream, act_sum);
+}
+
+// ... and the Linear that consumes such a staged row (PRO 3): y fp16 [N] = residual + W . act
+template <int LAYOUT>
+static int staged_layout(const void* x, const void* x_sum, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                         const void* residual, hipStream_t stream) {
+    const int th = gemv_shape(N, K, 0), M = 1;
+    const void* norm_w = nullptr;
+    const float eps = 0.f;
+    void* aux = const_cast<void*>(x_sum);
+    switch (th) {
+        case 512: return launch_t<1, 512, 3, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream, aux);
+        case 256: return launch_t<1, 256, 3, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream, aux);
+        case 128: return launch_t<1, 128, 3, LAYOUT>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream, aux);
+        case (2 << 16) | 256: return launch_t<1, 256, 3, LAYOUT, 2>(x, qweight, rowmeta, y, M, N, K, norm_w, eps, residual, stream, aux);
+    }
+    return (int)hipErrorInvalidValue;
+}
+int mxq_launch_gemv_staged_f16(const void* x, const void* x_sum, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                               const void* residual, int compact, hipStream_t stream) {
+    return compact ? staged_layout<MXQ_LAYOUT_MIXEDC>(x, x_sum, qweight, rowmeta, y, N, K, residual, stream)
+                   : staged_layout<MXQ_LAYOUT_MIXED>(x, x_sum, qweight, rowmeta, y, N, K, residual, stream);
 }
 
 #ifdef MXQ_PROFILING

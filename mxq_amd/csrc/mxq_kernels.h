@@ -104,6 +104,10 @@ int mxq_launch_uniform_expand(const void* qweight, const void* rowmeta, void* w1
 int mxq_launch_gemv_fused_f16(const void* x, const void* qweight, const void* rowmeta, void* y, int N, int K,
                               int prologue, const void* norm_w, float eps, const void* residual, int compact,
                               hipStream_t stream);
+int mxq_launch_gemv_swiglu_f16(const void* x, const void* qweight, const void* rowmeta, void* act, void* act_sum, int N2, int K,
+                               const void* norm_w, float eps, int compact, hipStream_t stream);
+int mxq_launch_gemv_staged_f16(const void* x, const void* x_sum, const void* qweight, const void* rowmeta, void* y, int N, int K,
+                               const void* residual, int compact, hipStream_t stream);
 int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, const void* w, int V, int K, void* part,
                                  int part_slots, void* token, void* advance, void* generated, int max_generated,
                                  hipStream_t stream);

@@ -61,6 +61,8 @@ class DecodeStage:
         # fused: RMSNorm / SwiGLU / residual folded into the GEMV launches and one RoPE + cache-append
         # + attention kernel per layer (5 launches per layer); otherwise plain torch ops around 4 GEMVs
         self.fused = fused and self.hd == 128
+        # the SwiGLU in gate|up's final reduction instead of in down's staging (bit-identical; round 5)
+        self.swiglu_in_producer = self.fused and (2 * inter) % 32 == 0 and hidden % 256 == 0
         self.launches_per_layer = 5 if self.fused else None     # q|k|v, attention, o, gate|up, down (else: torch ops around 4 GEMVs)
         self.w = []
         for li in self.layers:
@@ -162,8 +164,12 @@ class DecodeStage:
                 y = packing.linear_fused(h, qkv, 1, self.norm_w)                  # RMSNorm -> q|k|v
                 a = self._attn(y, i)                                              # RoPE + cache + attention
                 h = packing.linear_fused(a, o, 0, residual=h)                     # o_proj + skip
-                g = packing.linear_fused(h, gu, 1, self.norm_w)                   # RMSNorm -> gate|up
-                h = packing.linear_fused(g, down, 2, residual=h)                  # SwiGLU -> down_proj + skip
+                if self.swiglu_in_producer:
+                    act, act_sum = packing.linear_swiglu(h, gu, self.norm_w)          # RMSNorm -> gate|up -> SwiGLU
+                    h = packing.linear_staged(act, act_sum, down, residual=h)         # down_proj + skip
+                else:
+                    g = packing.linear_fused(h, gu, 1, self.norm_w)               # RMSNorm -> gate|up
+                    h = packing.linear_fused(g, down, 2, residual=h)              # SwiGLU -> down_proj + skip
             return h
         scale = 1.0 / math.sqrt(self.hd)
         mask = (self.ctx_ids <= self.pos)[None, None, :]              # [1, 1, max_ctx]

@@ -503,6 +503,43 @@ def linear_fused(x: torch.Tensor, p: PackedMXQ, prologue: int = 0, norm_w: Optio
     return out
 
 
+def linear_swiglu(x: torch.Tensor, gate_up: PackedMXQ, norm_w: torch.Tensor, eps: float = 1e-5):
+    """One token through RMSNorm -> gate | up -> SwiGLU in ONE launch (include/mxq_hip.h: mxq_gemv_swiglu_f16): ``gate_up`` is
+    gate stacked on up ([2 I, K], ``concat_packed``).  Returns (act fp16 [1, I] in the kernels' staged order, act_sum f32
+    [I / 16]) -- the input of ``linear_staged``; bit for bit what ``linear_fused(.., 1, norm_w)`` followed by the SwiGLU
+    staging of ``linear_fused(.., 2)`` computes."""
+    _need_gpu(x, gate_up.qweight, norm_w)
+    if x.dtype != torch.float16 or x.numel() != gate_up.K or norm_w.dtype != torch.float16 or norm_w.numel() != gate_up.K:
+        raise ValueError("expected one fp16 token and an fp16 RMSNorm weight of in_features elements")
+    if gate_up.N % 32 != 0 or gate_up.K % 256 != 0:
+        raise ValueError("the fused SwiGLU launch needs out_features % 32 == 0 (gate | up) and in_features % 256 == 0")
+    inter = gate_up.N // 2
+    x = x.contiguous()
+    act = torch.empty((1, inter), dtype=torch.float16, device=x.device)
+    act_sum = torch.empty(inter // 16, dtype=torch.float32, device=x.device)
+    with _on_device(x.device):
+        _lib.check(_lib.load().mxq_gemv_swiglu_f16(x.data_ptr(), gate_up.qweight.data_ptr(), gate_up.rowmeta.data_ptr(),
+                                                   act.data_ptr(), act_sum.data_ptr(), gate_up.N, gate_up.K, norm_w.data_ptr(),
+                                                   float(eps), int(gate_up.compact), _stream(x)), "mxq_gemv_swiglu_f16")
+    return act, act_sum
+
+
+def linear_staged(act: torch.Tensor, act_sum: torch.Tensor, p: PackedMXQ, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = residual + W . act for a staged row from ``linear_swiglu`` (mxq_gemv_staged_f16)."""
+    _need_gpu(act, act_sum, p.qweight, residual)
+    if act.dtype != torch.float16 or act.numel() != p.K or act_sum.dtype != torch.float32 or act_sum.numel() != p.K // 16:
+        raise ValueError("expected a staged fp16 row of in_features elements and its in_features / 16 fp32 group sums")
+    if residual is not None and (residual.dtype != torch.float16 or residual.numel() != p.N):
+        raise ValueError("residual must be fp16 [1, out_features]")
+    out = torch.empty((1, p.N), dtype=torch.float16, device=act.device)
+    with _on_device(act.device):
+        _lib.check(_lib.load().mxq_gemv_staged_f16(act.data_ptr(), act_sum.data_ptr(), p.qweight.data_ptr(), p.rowmeta.data_ptr(),
+                                                   out.data_ptr(), p.N, p.K,
+                                                   residual.contiguous().data_ptr() if residual is not None else None,
+                                                   int(p.compact), _stream(act)), "mxq_gemv_staged_f16")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # uniform layouts of the BASELINE config-5 sweep (W2A16 / W4A16 arms next to the mixed layout)
 # ------------------------------------------------------------------------------------------------

@@ -1691,6 +1691,40 @@ def test_decode_stage_matches_dense_reference(dev, heads, fused):
     assert int(st.pos.item()) == 5
 
 
+@pytest.mark.parametrize("hidden,inter", [(256, 704), (4096, 11008), (512, 1408)])
+@pytest.mark.parametrize("compact", [False, True])
+def test_swiglu_in_the_producer_is_bit_identical(dev, hidden, inter, compact):
+    """Round 5: gate | up with the SwiGLU in its final reduction (mxq_gemv_swiglu_f16: the row blocks (i, i + I / 16) paired
+    in one workgroup, the activation written in the kernels' staged order with its group sums) + the Linear on that
+    staged row (mxq_gemv_staged_f16) against the two launches they replace (RMSNorm -> gate | up, then SwiGLU staging ->
+    down + residual): the staged row is the permutation of fp16(silu(gate)) * up, the sums are its sequential fp32 group
+    sums, and the layer output is identical bit for bit."""
+    from mxq_amd import packing
+    g = torch.Generator(device=dev).manual_seed(hidden + inter + int(compact))
+    mk = lambda N, K: packing.quantize_pack((torch.randn(N, K, generator=g, device=dev) * 0.02).half(), compact_meta=compact)
+    gu = packing.concat_packed([mk(inter, hidden), mk(inter, hidden)])
+    down = mk(hidden, inter)
+    norm_w = (1.0 + 0.1 * torch.randn(hidden, generator=g, device=dev)).half()
+    for it in range(3):
+        h = (torch.randn(1, hidden, generator=g, device=dev) * (1 + it)).half()
+        y_gu = packing.linear_fused(h, gu, 1, norm_w)
+        want = packing.linear_fused(y_gu, down, 2, residual=h)
+        act, act_sum = packing.linear_swiglu(h, gu, norm_w)
+        gate, up = y_gu[0, :inter].float(), y_gu[0, inter:]
+        ref_act = (gate / (1.0 + torch.exp(-gate))).half() * up                     # fp16 multiply, as the staging does
+        perm = torch.tensor([0, 2, 1, 3, 4, 6, 5, 7], device=dev)
+        unstaged = act[0].view(-1, 8)[:, perm].reshape(-1)                           # the permutation is its own inverse
+        close = (unstaged.float() - ref_act.float()).abs() <= 2e-3 * ref_act.float().abs() + 1e-6   # (__expf vs torch.exp)
+        assert bool(close.all())
+        sums = unstaged.float().view(-1, 16)
+        seq = torch.zeros(inter // 16, device=dev)
+        for j in range(16):
+            seq = seq + sums[:, j]                                                   # sequential fp32 sum in element order
+        assert torch.equal(act_sum, seq)
+        got = packing.linear_staged(act, act_sum, down, residual=h)
+        assert torch.equal(got, want), (it, (got.float() - want.float()).abs().max().item())
+
+
 def test_decode_gemv_launches_full_size_vs_oracle(dev):
     """Every GEMV launch of ONE full-size decode layer (hidden 4096, intermediate 11008), fused prologue / residual included,
     against the ORACLE: weights quantised by oracle/mxq_oracle.py (the kernel's packed form is checked bit-equal to it
