@@ -54,15 +54,20 @@ class ContextWindow:
 class DecodeStage:
     def __init__(self, layers, dev, max_ctx: int = 512, hidden: int = LS.HIDDEN, inter: int = LS.INTERMEDIATE,
                  heads: int = 32, first: bool = True, last: bool = True, vocab: int = 32000, fused: bool = True,
-                 compact: bool = False):
+                 compact: bool = False, staging: str = "swiglu"):
         self.layers, self.dev, self.max_ctx = list(layers), dev, max_ctx
         self.hidden, self.inter, self.heads, self.hd = hidden, inter, heads, hidden // heads
         self.first, self.last, self.compact = first, last, compact
         # fused: RMSNorm / SwiGLU / residual folded into the GEMV launches and one RoPE + cache-append
         # + attention kernel per layer (5 launches per layer); otherwise plain torch ops around 4 GEMVs
         self.fused = fused and self.hd == 128
-        # the SwiGLU in gate|up's final reduction instead of in down's staging (bit-identical; round 5)
-        self.swiglu_in_producer = self.fused and (2 * inter) % 32 == 0 and hidden % 256 == 0
+        # staging (round 5): "swiglu" = gate|up applies the SwiGLU in its final reduction and writes the activation in the form
+        # down's workgroups stage it in (they copy 22 KB instead of staging 44 KB with 11 k exponentials each); "consumer" =
+        # the round-4 launches.  Bit-identical; +3.6 % (tools/ab_decode.py, profiles/r05_decode_staging_ab.txt, which also
+        # records the two further producer-side steps that lost)
+        if staging not in ("consumer", "swiglu"):
+            raise ValueError("staging must be 'consumer' or 'swiglu'")
+        self.swiglu_in_producer = staging == "swiglu" and self.fused and (2 * inter) % 32 == 0 and hidden % 256 == 0
         self.launches_per_layer = 5 if self.fused else None     # q|k|v, attention, o, gate|up, down (else: torch ops around 4 GEMVs)
         self.w = []
         for li in self.layers:
