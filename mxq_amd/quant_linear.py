@@ -21,13 +21,21 @@ from . import packing
 
 
 class QuantLinear(nn.Module):
-    def __init__(self, in_features: int, out_features: int, bias: bool = False, device=None, compact: bool = False):
+    def __init__(self, in_features: int, out_features: int, bias: bool = False, device=None, compact: bool = False,
+                 _buffers=None):
         super().__init__()
         packing.check_shape(out_features, in_features)
         self.in_features, self.out_features, self.compact = in_features, out_features, bool(compact)
         nq = packing.qweight_bytes(out_features, in_features) // 4 * (120 if compact else 144) // 144
-        self.register_buffer("qweight", torch.zeros(nq, dtype=torch.int32, device=device))
-        self.register_buffer("rowmeta", torch.zeros((out_features, 4), dtype=torch.float32, device=device))
+        if _buffers is None:          # an empty module (to be filled by load_state_dict): zero-filled buffers of the right size
+            qweight = torch.zeros(nq, dtype=torch.int32, device=device)
+            rowmeta = torch.zeros((out_features, 4), dtype=torch.float32, device=device)
+        else:                         # from_packed: adopt the packed tensors, nothing allocated and filled to be thrown away
+            qweight, rowmeta = _buffers
+            if qweight.numel() != nq or tuple(rowmeta.shape) != (out_features, 4):
+                raise ValueError("packed buffers do not match [out_features, in_features]")
+        self.register_buffer("qweight", qweight)
+        self.register_buffer("rowmeta", rowmeta)
         self.register_buffer("fmt", torch.tensor([2 if compact else 1, out_features, in_features], dtype=torch.int32,
                                                  device=device))
         if bias:
@@ -38,8 +46,7 @@ class QuantLinear(nn.Module):
     # -- construction -------------------------------------------------------------------
     @classmethod
     def from_packed(cls, p: packing.PackedMXQ, bias: Optional[torch.Tensor] = None) -> "QuantLinear":
-        m = cls(p.K, p.N, bias=bias is not None, device=p.device, compact=p.compact)
-        m.qweight, m.rowmeta = p.qweight, p.rowmeta
+        m = cls(p.K, p.N, bias=bias is not None, device=p.device, compact=p.compact, _buffers=(p.qweight, p.rowmeta))
         if bias is not None:
             m.bias = bias.detach().to(device=p.device, dtype=torch.float16)
         return m
