@@ -166,7 +166,9 @@ def decode_1gpu(dev, tokens=64, ctx=512):
                      "GBps": fig["weight_stream_GBps"], "frac": round(fig["weight_stream_GBps"] / PEAK_HBM_GBPS, 4),
                      "launches_per_layer": fig.get("launches_per_layer"), "us_per_layer": round(fig["ms_per_token"] * 1e3 / LS.N_LAYERS, 2),
                      "first_tokens": fig["first_tokens"]}
-        torch.cuda.empty_cache()
+        # (no torch.cuda.empty_cache() between figures: weights allocated into memory that was just handed back to the driver
+        #  decode 3 % slower -- 700 vs 723 tokens/s on one box, tools/_variants/order_test.py in round 5 -- presumably smaller
+        #  physically contiguous fragments behind the same virtual range; the box has 288 GB, nothing needs to be returned)
     return out
 
 
@@ -245,7 +247,6 @@ def config5(dev, tokens=32768, iters=3):
                             "decode_M1": {"layer_us": round(us, 2), "packed_MB": round(nbytes / 1e6, 2),
                                           "GBps": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4)}}
         del copies, gr, lin
-        torch.cuda.empty_cache()
     return out
 
 
@@ -427,10 +428,7 @@ def main():
     decode_fig = None
     if world > 1 and not args.no_decode_pipeline:
         from mxq_amd.llama_decode import decode_pipeline_figure
-        del layers
-        torch.cuda.empty_cache()
         decode_fig = decode_pipeline_figure(pipe, dev, tokens=32, ctx=64, verify=True, dist=dist, backend=backend)
-        layers = []
     if rank == 0:
         bpw = bits_per_weight
         out = {
@@ -468,13 +466,10 @@ def main():
             out["decode_pipeline"] = decode_fig
         if world == 1 and not args.fuse and not args.headline_only:
             out["fused_launches_figure"] = fused_launch_figure(layers, dev, x_h, x_i, y_h)
-            del layers
-            torch.cuda.empty_cache()
             # the other BASELINE configs, each with its own roofline fraction (side figures; `value` is configs[1])
             out["decode_1gpu"] = decode_1gpu(dev)              # configs[2] on one GPU (HBM-bound)
             out["fakequant_block"] = fakequant_block(dev)      # configs[3] (HBM-bound)
             out["config5"] = config5(dev)                      # configs[4] (MFMA-bound prefill leg, HBM-bound decode leg)
-            layers = []
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             out["cpu_baseline"] = cpu_baseline(dev)
         print(json.dumps(out), flush=True)
