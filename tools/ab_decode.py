@@ -2,7 +2,7 @@
 """Same-process A/B of whole-model greedy decode (one GPU, hipGraph token loop): two DecodeStage variants built side by side
 and timed alternately, so that box-to-box differences (+-2 %) do not hide a 1 % step.
     python tools/ab_decode.py [--tokens 64] [--rounds 4] [--compact]
-Variants: DecodeStage(staging=...) "consumer" (round-4 launches), "swiglu" (mxq_amd/llama_decode.py)."""
+Variants: DecodeStage(staging=...) "consumer" (round-4 launches), "swiglu", "noarena" (swiglu with one allocation per weight) (mxq_amd/llama_decode.py)."""
 import argparse
 import json
 import os
@@ -28,7 +28,8 @@ def main():
     stages, bufs = {}, {}
     names = args.variants.split(",")
     for name in names:
-        st = DecodeStage(range(LS.N_LAYERS), dev, max_ctx=args.ctx, compact=args.compact, staging=name)
+        st = (DecodeStage(range(LS.N_LAYERS), dev, max_ctx=args.ctx, compact=args.compact, arena=False) if name == "noarena"
+              else DecodeStage(range(LS.N_LAYERS), dev, max_ctx=args.ctx, compact=args.compact, staging=name))
         bufs[name] = torch.zeros(1, dtype=torch.int64, device=dev)
         st.capture_token_loop(bufs[name])
         stages[name] = st
