@@ -288,6 +288,9 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="no side figures and no CPU baseline: the process launches nothing but the headline's kernels "
                          "(what tools/prof_round.sh traces, so that the trace's per-kernel average is the headline's)")
+    ap.add_argument("--figure", choices=["decode_1gpu", "fakequant_block", "config5"], default=None,
+                    help="run ONE side figure only and print it (no headline): what tools/prof_round.sh traces per figure, so "
+                         "that a trace's per-kernel average x launches reproduces the figure")
     ap.add_argument("--graph", action="store_true",
                     help="N = 1: replay the step as one hipGraph (measured r04: 1073.3 vs 1073.4 TFLOP/s stream-ordered -- the "
                          "queue never runs dry, so this is not the default)")
@@ -320,6 +323,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.figure:
+        fig = {"decode_1gpu": decode_1gpu, "fakequant_block": fakequant_block, "config5": config5}[args.figure](dev)
+        print(json.dumps({args.figure: fig}), flush=True)
+        return
     my_layers = list(LS.layer_range(rank, world))
     layers = build_layers(my_layers, dev)
     if args.fuse:   # LAYER_LINEARS order: q, k, v, o, gate, up, down
@@ -405,10 +412,8 @@ def main():
     achieved = flops_rank_step / (dev_ms / args.steps * 1e-3) / 1e12
 
     traffic = None       # HBM bytes per launch from rocprofv3 PMC counters (collected offline, see the file)
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm8_traffic.json") for r in (4,))
-                  if os.path.exists(q)), "") or \
-        next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm8_traffic.json") for r in (3, 2))
-              if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm8_traffic.json") for r in (5, 4, 3, 2))
+                  if os.path.exists(q)), "")
     if world == 1 and tpath:
         traffic = json.load(open(tpath))["avg_hbm_bytes_per_launch"]
 

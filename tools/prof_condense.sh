@@ -7,6 +7,12 @@ P=${2:-r02}        # prefix of the committed files: profiles/<P>_*
 cd "$(dirname "$0")/.."
 python3 tools/prof_summary.py gpurun_out/${T}_bench profiles/${P}_bench_gemm8.txt "bench.py --steps 5 --warmup 2 --headline-only"
 cp gpurun_out/${T}_bench.json profiles/${P}_bench_gemm8.json
+for fig in decode_1gpu fakequant_block config5; do
+  if [ -d gpurun_out/${T}_fig_$fig ]; then
+    python3 tools/prof_summary.py gpurun_out/${T}_fig_$fig profiles/${P}_fig_$fig.txt "bench.py --figure $fig" > /dev/null
+    grep "^{" gpurun_out/${T}_fig_$fig.json | tail -1 > profiles/${P}_fig_$fig.json
+  fi
+done
 python3 tools/traffic_json.py gpurun_out ${T} profiles/${P}_gemm8_traffic.json
 { echo "# rocprofv3 --pmc passes of tools/gemm_prof.py gemm 2048 4096 4096 (tools/prof_round.sh ${T})"
   python3 tools/pmc_summary.py gpurun_out/${T}_pmc_sq1; python3 tools/pmc_summary.py gpurun_out/${T}_pmc_sq2; } > profiles/${P}_gemm8_pmc.txt

@@ -12,6 +12,11 @@ export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_bench -- python3 $R/bench.py --steps 5 --warmup 2 --headline-only > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench trace done"
+# the side figures of the bench line (BASELINE configs[2], [3], [4]), each traced on its own: kernel average x launches = the figure
+for fig in decode_1gpu fakequant_block config5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_fig_$fig -- python3 $R/bench.py --figure $fig > $OUT/${TAG}_fig_$fig.json 2> $OUT/${TAG}_fig_$fig.err
+  echo "figure $fig traced"
+done
 for shape in "4096 4096" "11008 4096" "4096 11008"; do
   set -- $shape
   for c in FETCH_SIZE WRITE_SIZE; do
