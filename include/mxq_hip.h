@@ -273,6 +273,17 @@ int mxq_embed_rope_row(const void* token, const void* embed, int vocab, int hidd
 int mxq_attn_decode_row_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row, void* out,
                             int heads, int head_dim, int max_ctx, void* stream);
 
+/* The same for LONG contexts (round 5): one workgroup per head streams a head's whole cache through one CU (5 us per layer at
+ * 72 keys, 13 at 450, ~40 at 2048); here a head's keys are split over up to `splits` workgroups (grid heads x splits), each
+ * parks its partial softmax {o[128], max, sum} in `workspace`, and the head's LAST arriver (an arrival counter: nobody waits)
+ * merges them.  Up to 128 keys a head is ONE workgroup running mxq_attn_decode_row_f16's algorithm bit for bit, so short
+ * contexts pay nothing; beyond, the result differs from the one-workgroup kernel by fp32 summation order and by not
+ * rounding the probabilities to fp16.  workspace: mxq_attn_split_workspace_bytes(heads, splits) bytes, 16-byte aligned, its
+ * first 1024 * ceil(heads / 256) bytes (the counters) zeroed ONCE by the caller; the kernel leaves them zeroed. */
+size_t mxq_attn_split_workspace_bytes(int heads, int splits);
+int mxq_attn_decode_split_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row, void* out,
+                              int heads, int head_dim, int max_ctx, int splits, void* workspace, void* stream);
+
 /* Decode-harness glue (BASELINE config 3), not part of the reference's hot path: final RMSNorm + the fp16 lm_head
  * Linear + greedy argmax of ONE token.  h fp16[K], norm_w fp16[K], w fp16[V, K] (row-major nn.Linear weight), K = 4096;
  * the normalised row is fp16(h * rsqrt(mean h^2 + eps)) * norm_w, a logit the fp32 dot rounded to fp16, the result

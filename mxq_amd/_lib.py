@@ -67,6 +67,8 @@ SIGNATURES = {
     "mxq_gemv_staged_f16": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_int, c_void_p]),
     "mxq_lmhead_argmax_f16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mxq_attn_decode_f16": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    "mxq_attn_split_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mxq_attn_decode_split_f16": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mxq_rope_row_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "mxq_embed_rope_row": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mxq_lmhead_argmax_advance_f16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,

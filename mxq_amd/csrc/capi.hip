@@ -175,6 +175,19 @@ int mxq_embed_rope_row(const void* token, const void* embed, int vocab, int hidd
     return mxq_launch_rope_row_f32(pos, cos_t, sin_t, row, half_dim, max_ctx, token, embed, vocab, hidden, h_out, (hipStream_t)stream);
 }
 
+size_t mxq_attn_split_workspace_bytes(int heads, int splits) {
+    return heads > 0 && splits > 0 ? ::mxq_attn_split_workspace_bytes_impl(heads, splits) : 0;
+}
+
+int mxq_attn_decode_split_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row, void* out,
+                              int heads, int head_dim, int max_ctx, int splits, void* workspace, void* stream) {
+    if (!qkv || !k_cache || !v_cache || !pos || !rope_row || !out || !workspace) return MXQ_E_NULL;
+    if (heads <= 0 || head_dim != 128 || max_ctx <= 0 || max_ctx > 32768 || splits < 1 || splits > 64) return MXQ_E_SHAPE;
+    if (!aligned16(workspace)) return MXQ_E_ALIGN;
+    return mxq_launch_attn_decode_split_f16(qkv, k_cache, v_cache, pos, rope_row, out, heads, head_dim, max_ctx, splits, workspace,
+                                            (hipStream_t)stream);
+}
+
 int mxq_attn_decode_row_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row, void* out,
                             int heads, int head_dim, int max_ctx, void* stream) {
     if (!qkv || !k_cache || !v_cache || !pos || !rope_row || !out) return MXQ_E_NULL;

@@ -32,22 +32,22 @@ __device__ __forceinline__ uint16_t f2h(float f) {
 // ROW (round 5): cos_t / sin_t are the ONE row of the rotary tables for this token's position ([HD/2] each, gathered once
 // per token by rope_row_kernel below) instead of the [max_ctx][HD/2] tables: the 128 values are then loaded in round trip 1
 // with everything else, and the dependent second trip (position -> table row) is gone from every layer's launch.
+// Returns false (before any side effect) when `max_keys` > 0 and the position needs more keys than that: the caller then
+// takes the split path.  (The test sits INSIDE, behind round trip 1: a caller that read the position first and branched
+// would put a dependent round trip in front of every load of this function -- measured +2.2 us per layer.)
 template <bool ROW>
-__global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t* __restrict__ qkv,
-                                                                  uint16_t* __restrict__ k_cache,
-                                                                  uint16_t* __restrict__ v_cache,
-                                                                  const int64_t* __restrict__ pos_p,
-                                                                  const float* __restrict__ cos_t,
-                                                                  const float* __restrict__ sin_t,
-                                                                  uint16_t* __restrict__ out, int heads, int max_ctx) {
-    extern __shared__ float sm[];          // q[HD], knew[HD], vnew[HD], scores[max_ctx], red[8], o2[16*HD]
-    float* q_s = sm;
+__device__ __forceinline__ bool attn_one_workgroup(float* sm, int h, const uint16_t* __restrict__ qkv,
+                                                   uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
+                                                   const int64_t* __restrict__ pos_p, const float* __restrict__ cos_t,
+                                                   const float* __restrict__ sin_t, uint16_t* __restrict__ out, int heads,
+                                                   int max_ctx, int max_keys = 0) {
+    float* q_s = sm;                       // q[HD], knew[HD], vnew[HD], scores[max_ctx], red[8], o2[16*HD]
     float* k_s = sm + HD;
     float* v_s = sm + 2 * HD;
     float* sc = sm + 3 * HD;
     float* red = sc + max_ctx;
     float* o2 = red + 8;
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hidden = heads * HD;
     uint16_t* kc = k_cache + (int64_t)h * max_ctx * HD;
     uint16_t* vc = v_cache + (int64_t)h * max_ctx * HD;
@@ -80,10 +80,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
     // so the launcher cannot check it: a position outside the cache must neither be written to the cache nor index
     // the LDS score array.  The head's output is poisoned (NaN) instead, which the caller cannot miss downstream.
     if (pos64 < 0 || pos64 >= max_ctx) {   // uniform over the workgroup: taken before any barrier
-        if (tid < HD) out[blockIdx.x * HD + tid] = 0x7E00;
-        return;
+        if (tid < HD) out[h * HD + tid] = 0x7E00;
+        return true;
     }
     const int pos = (int)pos64;
+    if (max_keys > 0 && pos + 1 > max_keys) return false;   // (uniform; nothing written yet)
 
     // ---- round trip 2 (L2-resident table): cos / sin of the position; RoPE on q and k; append k, v at `pos`
     if (tid < HD) {
@@ -186,6 +187,184 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
         for (int g = 0; g < 16; ++g) t += o2[g * HD + tid];
         out[h * HD + tid] = f2h(t);
     }
+    return true;
+}
+
+template <bool ROW>
+__global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t* __restrict__ qkv,
+                                                                  uint16_t* __restrict__ k_cache,
+                                                                  uint16_t* __restrict__ v_cache,
+                                                                  const int64_t* __restrict__ pos_p,
+                                                                  const float* __restrict__ cos_t,
+                                                                  const float* __restrict__ sin_t,
+                                                                  uint16_t* __restrict__ out, int heads, int max_ctx) {
+    extern __shared__ float sm[];
+    attn_one_workgroup<ROW>(sm, blockIdx.x, qkv, k_cache, v_cache, pos_p, cos_t, sin_t, out, heads, max_ctx);
+}
+
+// LONG CONTEXTS (round 5): one workgroup per head streams a head's whole cache through ONE CU -- 5 us at 72 keys, 13 us at
+// 450, ~40 us at 2048 (per layer).  Here the keys of a head are split over up to S workgroups (grid = heads x S, split s of
+// head h = block s * heads + h): each computes the scores of its key range, their maximum m, p = exp(score - m), l = sum p
+// and the unnormalised o = sum p v in fp32, parks {o[128], m, l} in the workspace (write-through) and bumps the head's
+// arrival counter; the LAST arriver -- nobody waits -- merges the parts (o = sum_s o_s e^(m_s - M) / sum_s l_s e^(m_s - M)) and
+// writes the head's output, then re-zeroes the counter.  Up to SPLIT_MIN keys a head is ONE workgroup running the
+// single-workgroup algorithm above bit for bit (the other splits exit at once): short contexts pay nothing.
+// ws: int counters [heads] (zeroed once by the caller; left zeroed), then f32 parts [heads][S][HD + 2] from byte 1024 * ceil(heads / 256).
+constexpr int SPLIT_MIN = 128, SPLIT_CHUNK = 64;
+template <bool ROW>
+__global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(const uint16_t* __restrict__ qkv,
+                                                                        uint16_t* __restrict__ k_cache,
+                                                                        uint16_t* __restrict__ v_cache,
+                                                                        const int64_t* __restrict__ pos_p,
+                                                                        const float* __restrict__ cos_t,
+                                                                        const float* __restrict__ sin_t,
+                                                                        uint16_t* __restrict__ out, int heads, int max_ctx, int S,
+                                                                        int* __restrict__ cnt, float* __restrict__ part) {
+    extern __shared__ float sm[];
+    const int h = blockIdx.x % heads, split = blockIdx.x / heads;
+    // split 0 starts as the one-workgroup kernel (all its loads fly with the position's); it comes back unhandled only for a
+    // long context.  The other splits have nothing to do for a short or refused position.
+    if (split == 0 && attn_one_workgroup<ROW>(sm, h, qkv, k_cache, v_cache, pos_p, cos_t, sin_t, out, heads, max_ctx, SPLIT_MIN))
+        return;
+    const int64_t pos64 = *pos_p;
+    if (pos64 < 0 || pos64 >= max_ctx || pos64 + 1 <= SPLIT_MIN) return;
+    __syncthreads();                                                    // (split 0: every thread is out of the function's LDS use)
+    const int pos = (int)pos64, n = pos + 1;
+    // equal key ranges in units of SPLIT_CHUNK keys over the splits that get any
+    const int units = (n + SPLIT_CHUNK - 1) / SPLIT_CHUNK, S_eff = units < S ? units : S;
+    if (split >= S_eff) return;
+    const int per = (units + S_eff - 1) / S_eff * SPLIT_CHUNK;
+    const int j0 = split * per, j1 = min(n, j0 + per);                  // (the last split may be short, never empty: S_eff <= units)
+    float* q_s = sm;
+    float* k_s = sm + HD;
+    float* v_s = sm + 2 * HD;
+    float* sc = sm + 3 * HD;                                            // scores of keys j0 .. j1 - 1
+    float* red = sc + max_ctx;
+    float* o2 = red + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hidden = heads * HD;
+    uint16_t* kc = k_cache + (int64_t)h * max_ctx * HD;
+    uint16_t* vc = v_cache + (int64_t)h * max_ctx * HD;
+    const bool owns_new = pos >= j0 && pos < j1;                        // this split holds the token's own key
+    const int d = tid & (HD - 1), d2 = d & (HD / 2 - 1);
+    if (tid < HD) {
+        const uint16_t* qh = qkv + h * HD;
+        const uint16_t* kh = qkv + hidden + h * HD;
+        const float c = ROW ? cos_t[d2] : cos_t[(int64_t)pos * (HD / 2) + d2], s_ = ROW ? sin_t[d2] : sin_t[(int64_t)pos * (HD / 2) + d2];
+        const float q1 = h2f(qh[d2]), q2 = h2f(qh[d2 + HD / 2]);
+        q_s[d] = h2f(f2h(d < HD / 2 ? q1 * c - q2 * s_ : q2 * c + q1 * s_));
+        if (owns_new) {
+            const float k1 = h2f(kh[d2]), k2 = h2f(kh[d2 + HD / 2]);
+            const uint16_t krh = f2h(d < HD / 2 ? k1 * c - k2 * s_ : k2 * c + k1 * s_), vh = qkv[2 * hidden + h * HD + d];
+            k_s[d] = h2f(krh);
+            v_s[d] = h2f(vh);
+            kc[(int64_t)pos * HD + d] = krh;
+            vc[(int64_t)pos * HD + d] = vh;
+        }
+    }
+    __syncthreads();
+    const int part_ = tid & 3, kj = tid >> 2;
+    const float scale = rsqrtf((float)HD);
+    for (int j = j0 + kj; j < j1; j += ATT_THREADS / 4) {
+        float acc = 0.f;
+        if (j == pos) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) acc += q_s[part_ * 32 + e] * k_s[part_ * 32 + e];
+        } else {
+            const uint4* kr = (const uint4*)(kc + (int64_t)j * HD + part_ * 32);
+            uint4 kw[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) kw[v] = kr[v];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const uint32_t ws[4] = {kw[v].x, kw[v].y, kw[v].z, kw[v].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc += q_s[part_ * 32 + v * 8 + 2 * e] * h2f((uint16_t)(ws[e] & 0xFFFF));
+                    acc += q_s[part_ * 32 + v * 8 + 2 * e + 1] * h2f((uint16_t)(ws[e] >> 16));
+                }
+            }
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (part_ == 0) sc[j - j0] = h2f(f2h(acc * scale));
+    }
+    __syncthreads();
+    const int nk = j1 - j0;
+    float mx = -INFINITY;
+    for (int j = tid; j < nk; j += ATT_THREADS) mx = fmaxf(mx, sc[j]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < nk; j += ATT_THREADS) {
+        const float p = __expf(sc[j] - mx);
+        sc[j] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __syncthreads();
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float l = red[4] + red[5] + red[6] + red[7];
+    const int dg = tid & 15, kg = tid >> 4;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int j = j0 + kg; j < j1; j += 16) {
+        const float p = sc[j - j0];
+        if (j == pos) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += p * v_s[dg * 8 + e];
+        } else {
+            const uint4 w = *(const uint4*)(vc + (int64_t)j * HD + dg * 8);
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[2 * e] += p * h2f((uint16_t)(ws[e] & 0xFFFF));
+                o[2 * e + 1] += p * h2f((uint16_t)(ws[e] >> 16));
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o2[kg * HD + dg * 8 + e] = o[e];
+    __syncthreads();
+    // park {o, m, l}: write-through (sc1) stores, drained before the arrival is counted
+    float* mine = part + ((int64_t)h * S + split) * (HD + 2);
+    if (tid < HD) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += o2[g * HD + tid];
+        __hip_atomic_store(mine + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        __hip_atomic_store(mine + HD, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + HD + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int last_s;
+    if (tid == 0) last_s = __hip_atomic_fetch_add(cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S_eff - 1;
+    __syncthreads();
+    if (!last_s) return;
+    // the last arriver of the head: every part was drained before its arrival was counted; agent-scope loads
+    if (tid < HD) {
+        float M = -INFINITY;
+        for (int s2 = 0; s2 < S_eff; ++s2)
+            M = fmaxf(M, __hip_atomic_load(part + ((int64_t)h * S + s2) * (HD + 2) + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        float L = 0.f, acc = 0.f;
+        for (int s2 = 0; s2 < S_eff; ++s2) {
+            const float* p2 = part + ((int64_t)h * S + s2) * (HD + 2);
+            const float w = __expf(__hip_atomic_load(p2 + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - M);
+            L += w * __hip_atomic_load(p2 + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc += w * __hip_atomic_load(p2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        out[h * HD + tid] = f2h(acc / L);
+    }
+    if (tid == 0) __hip_atomic_store(cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // cos / sin of the CURRENT position -> one [2][HD/2] row (one launch per token; the position lives in device memory)
@@ -366,6 +545,27 @@ int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, co
                                hipStream_t stream) {
     return rope_row ? launch_attn<true>(qkv, k_cache, v_cache, pos, cos_t, sin_t, out, heads, head_dim, max_ctx, stream)
                     : launch_attn<false>(qkv, k_cache, v_cache, pos, cos_t, sin_t, out, heads, head_dim, max_ctx, stream);
+}
+
+size_t mxq_attn_split_workspace_bytes_impl(int heads, int splits) {
+    return (size_t)((heads + 255) / 256) * 1024 + (size_t)heads * splits * (HD + 2) * sizeof(float);
+}
+// splits > 1: the long-context kernel (ws = mxq_attn_split_workspace_bytes(heads, splits), counters zeroed once)
+int mxq_launch_attn_decode_split_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row,
+                                     void* out, int heads, int head_dim, int max_ctx, int splits, void* ws, hipStream_t stream) {
+    if (head_dim != HD) return (int)hipErrorInvalidValue;
+    const size_t smem = (size_t)(3 * HD + max_ctx + 8 + 16 * HD) * 4;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_decode_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    int* cnt = (int*)ws;
+    float* part = (float*)((char*)ws + (size_t)((heads + 255) / 256) * 1024);
+    attn_decode_split_kernel<true><<<heads * splits, ATT_THREADS, smem, stream>>>(
+        (const uint16_t*)qkv, (uint16_t*)k_cache, (uint16_t*)v_cache, (const int64_t*)pos, (const float*)rope_row,
+        (const float*)rope_row + HD / 2, (uint16_t*)out, heads, max_ctx, splits, cnt, part);
+    return (int)hipGetLastError();
 }
 
 int mxq_launch_rope_row_f32(const void* pos, const void* cos_t, const void* sin_t, void* row, int half_dim, int max_ctx,

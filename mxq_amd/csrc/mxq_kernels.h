@@ -114,6 +114,9 @@ int mxq_launch_lmhead_argmax_f16(const void* h, const void* norm_w, float eps, c
 int mxq_launch_attn_decode_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* cos_t,
                                const void* sin_t, void* out, int heads, int head_dim, int max_ctx, int rope_row,
                                hipStream_t stream);   // rope_row: cos_t / sin_t are the position's ONE row (mxq_launch_rope_row_f32)
+size_t mxq_attn_split_workspace_bytes_impl(int heads, int splits);
+int mxq_launch_attn_decode_split_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row,
+                                     void* out, int heads, int head_dim, int max_ctx, int splits, void* ws, hipStream_t stream);
 int mxq_launch_rope_row_f32(const void* pos, const void* cos_t, const void* sin_t, void* row, int half_dim, int max_ctx,
                             const void* tok, const void* embed, int vocab, int hidden, void* h_out, hipStream_t stream);
 int mxq_launch_fakequant_fwd(const void* w, void* out, int rows, int cols, int num_bits, int dtype,

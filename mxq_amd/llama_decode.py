@@ -52,6 +52,8 @@ class ContextWindow:
 
 
 class DecodeStage:
+    SPLIT_KEYS = 128          # csrc/decode_ops.hip SPLIT_MIN: contexts up to this many keys are one workgroup per head
+
     def __init__(self, layers, dev, max_ctx: int = 512, hidden: int = LS.HIDDEN, inter: int = LS.INTERMEDIATE,
                  heads: int = 32, first: bool = True, last: bool = True, vocab: int = 32000, fused: bool = True,
                  compact: bool = False, staging: str = "swiglu", arena: bool = True):
@@ -102,6 +104,14 @@ class DecodeStage:
             g = torch.Generator(device=dev).manual_seed(98)
             self.lm_head = (torch.randn(vocab, hidden, generator=g, device=dev) * 0.02).half()   # plain fp16 Linear
         self.rope_row = torch.zeros(2 * (self.hd // 2), dtype=torch.float32, device=dev)   # cos | sin of the current position
+        # contexts beyond 128 keys: a head's keys split over up to 8 workgroups (include/mxq_hip.h: mxq_attn_decode_split_f16)
+        # -- chosen on the HOST, which mirrors the device position (ContextWindow): up to SPLIT_KEYS keys the one-workgroup
+        # launch (32 workgroups; the split launch's 256 cost 0.36 us per layer there), beyond it the split one; a captured
+        # stage holds one graph of each and replays the one the position calls for
+        self.attn_splits = 8 if (self.fused and max_ctx > self.SPLIT_KEYS) else 1
+        self._long_ctx = False
+        self._attn_ws = (torch.zeros(_lib.load().mxq_attn_split_workspace_bytes(heads, self.attn_splits), dtype=torch.uint8, device=dev)
+                         if self.attn_splits > 1 else None)
         self._graph = None
         self._head_ws = None
         self._head_tok = None
@@ -172,10 +182,16 @@ class DecodeStage:
     def _attn(self, qkv, i):
         out = torch.empty((1, self.hidden), dtype=torch.float16, device=self.dev)
         lib = _lib.load()
-        _lib.check(lib.mxq_attn_decode_row_f16(qkv.data_ptr(), self.k_cache[i].data_ptr(), self.v_cache[i].data_ptr(),
-                                               self.pos.data_ptr(), self.rope_row.data_ptr(), out.data_ptr(), self.heads,
-                                               self.hd, self.max_ctx, torch.cuda.current_stream(self.dev).cuda_stream),
-                   "mxq_attn_decode_row_f16")
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        if self.attn_splits > 1 and self._long_ctx:
+            _lib.check(lib.mxq_attn_decode_split_f16(qkv.data_ptr(), self.k_cache[i].data_ptr(), self.v_cache[i].data_ptr(),
+                                                     self.pos.data_ptr(), self.rope_row.data_ptr(), out.data_ptr(), self.heads,
+                                                     self.hd, self.max_ctx, self.attn_splits, self._attn_ws.data_ptr(), st),
+                       "mxq_attn_decode_split_f16")
+        else:
+            _lib.check(lib.mxq_attn_decode_row_f16(qkv.data_ptr(), self.k_cache[i].data_ptr(), self.v_cache[i].data_ptr(),
+                                                   self.pos.data_ptr(), self.rope_row.data_ptr(), out.data_ptr(), self.heads,
+                                                   self.hd, self.max_ctx, st), "mxq_attn_decode_row_f16")
         return out
 
     def step(self, h, rope_done: bool = False):
@@ -184,6 +200,8 @@ class DecodeStage:
         if self.window.pos >= self.max_ctx:
             raise RuntimeError(f"decode position {self.window.pos} is outside the KV cache (max_ctx = {self.max_ctx})")
         if self.fused:
+            if not torch.cuda.is_current_stream_capturing():
+                self._long_ctx = self.window.pos + 1 > self.SPLIT_KEYS      # eager step: the host knows the position
             if not rope_done:
                 self._rope_row()
             for i, (qkv, o, gu, down) in enumerate(self.w):
@@ -227,18 +245,41 @@ class DecodeStage:
             self._h_out.copy_(self.step(self._h_in))
         self.pos.zero_()
         torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+
+        def body():
             self._h_out.copy_(self.step(self._h_in))
             self.pos += 1
+        self._graph, self._graph_long = self._capture_short_and_long(body)
         self.pos.zero_()
         self.window.reset()
         return self
 
+    def _capture_short_and_long(self, body):
+        """One graph of ``body`` with the one-workgroup attention launch and -- when the cache is longer than SPLIT_KEYS --
+        one with the split launch; ``_pick`` replays the one the host-side position calls for."""
+        graphs = []
+        for long_ctx in ((False, True) if self.attn_splits > 1 else (False,)):
+            self._long_ctx = long_ctx
+            if long_ctx:                       # (the split kernel's launch attributes are set outside capture)
+                body()
+                self.pos.zero_()
+                torch.cuda.synchronize()
+            self._long_ctx = long_ctx          # (an eager step sets it from the host position; the capture pins it)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            graphs.append(g)
+        self._long_ctx = False
+        return graphs[0], (graphs[1] if len(graphs) > 1 else None)
+
+    def _pick(self, short, long_, position: int):
+        """The graph for a token at ``position`` (it attends to position + 1 keys)."""
+        return long_ if (long_ is not None and position + 1 > self.SPLIT_KEYS) else short
+
     def step_graph(self, h):
-        self.window.take(1)                    # the replay advances the device position by one
+        p = self.window.take(1)                # the replay advances the device position by one
         self._h_in.copy_(h)
-        self._graph.replay()
+        self._pick(self._graph, self._graph_long, p).replay()
         return self._h_out
 
     def capture_token_loop(self, token_buf: torch.Tensor):
@@ -278,9 +319,7 @@ class DecodeStage:
             one()
         self.pos.zero_()
         torch.cuda.synchronize()
-        self._tgraph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._tgraph):
-            one()
+        self._tgraph, self._tgraph_long = self._capture_short_and_long(one)
         self.pos.zero_()
         self.window.reset()
         return self
@@ -290,12 +329,12 @@ class DecodeStage:
         p0 = self.window.take(n_tokens)        # every replay advances the device position by one
         token_buf.fill_(int(first_token))
         if getattr(self, "_generated", None) is not None:      # the graph itself appends the ids at generated[position]
-            for _ in range(n_tokens):
-                self._tgraph.replay()
+            for i in range(n_tokens):
+                self._pick(self._tgraph, self._tgraph_long, p0 + i).replay()
             return self._generated[p0:p0 + n_tokens].tolist()
         out = torch.zeros(n_tokens, dtype=token_buf.dtype, device=token_buf.device)
         for i in range(n_tokens):
-            self._tgraph.replay()
+            self._pick(self._tgraph, self._tgraph_long, p0 + i).replay()
             out[i:i + 1].copy_(token_buf)
         return out.tolist()
 

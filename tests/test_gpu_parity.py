@@ -936,6 +936,58 @@ def test_attn_decode_kernel_across_the_prefetched_rows(dev, pos):
     assert torch.equal(out2, out) and torch.equal(kc2, kc) and torch.equal(vc2, vc)
 
 
+@pytest.mark.parametrize("pos", [0, 63, 127, 128, 129, 191, 192, 300, 511, 512, 777, 1023])
+@pytest.mark.parametrize("splits", [8, 3])
+def test_attn_decode_split_over_keys(dev, pos, splits):
+    """Long contexts: a head's keys split over up to `splits` workgroups, partial softmax parts merged by the head's last
+    arriver (csrc/decode_ops.hip attn_decode_split_kernel).  Up to 128 keys the result is the one-workgroup kernel's bit for
+    bit; beyond, against a torch restatement (fp32 softmax over fp16-rounded scores).  Exactly one cache row appended,
+    the arrival counters left zeroed, launch after launch on the same workspace."""
+    from mxq_amd import _lib
+    heads, hd, ctx = 4, 128, 1024
+    g = torch.Generator(device=dev).manual_seed(pos * 7 + splits)
+    qkv = torch.randn(3 * heads * hd, generator=g, device=dev).half()
+    kc0 = torch.randn(heads, ctx, hd, generator=g, device=dev).half()
+    vc0 = torch.randn(heads, ctx, hd, generator=g, device=dev).half()
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    ang = torch.arange(ctx, device=dev).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    posd = torch.tensor([pos], dtype=torch.int64, device=dev)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    row = torch.empty(hd, dtype=torch.float32, device=dev)
+    _lib.check(lib.mxq_rope_row_f32(posd.data_ptr(), cos.data_ptr(), sin.data_ptr(), row.data_ptr(), hd // 2, ctx, st), "rope_row")
+    ws = torch.zeros(lib.mxq_attn_split_workspace_bytes(heads, splits), dtype=torch.uint8, device=dev)
+    outs = []
+    for rep in range(2):                      # twice on the same workspace: the counters must come back zeroed
+        kc, vc = kc0.clone(), vc0.clone()
+        out = torch.empty(heads * hd, dtype=torch.float16, device=dev)
+        _lib.check(lib.mxq_attn_decode_split_f16(qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), posd.data_ptr(), row.data_ptr(),
+                                                 out.data_ptr(), heads, hd, ctx, splits, ws.data_ptr(), st), "attn split")
+        torch.cuda.synchronize()
+        assert int(ws[:1024].view(torch.int32).abs().sum().item()) == 0
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    q, k, v = (qkv[j * heads * hd:(j + 1) * heads * hd].view(heads, hd).float() for j in range(3))
+
+    def rope(t):
+        t1, t2 = t[:, : hd // 2], t[:, hd // 2:]
+        return torch.cat([t1 * cos[pos] - t2 * sin[pos], t2 * cos[pos] + t1 * sin[pos]], -1)
+    qr, kr = rope(q).half().float(), rope(k).half()
+    kref, vref = kc0.clone(), vc0.clone()
+    kref[:, pos], vref[:, pos] = kr, v.half()
+    assert torch.equal(kc, kref) and torch.equal(vc, vref)
+    if pos + 1 <= 128:                         # one workgroup per head: the other kernel's result bit for bit
+        one = torch.empty_like(out)
+        kc1, vc1 = kc0.clone(), vc0.clone()
+        _lib.check(lib.mxq_attn_decode_row_f16(qkv.data_ptr(), kc1.data_ptr(), vc1.data_ptr(), posd.data_ptr(), row.data_ptr(),
+                                               one.data_ptr(), heads, hd, ctx, st), "attn row")
+        assert torch.equal(out, one)
+    scores = (qr[:, None, :] @ kref[:, : pos + 1].float().transpose(1, 2) / hd ** 0.5).half().float()
+    want = (scores.softmax(-1) @ vref[:, : pos + 1].float()).reshape(-1)
+    assert ((out.float() - want).abs().max() / want.abs().max()).item() < 4e-3
+
+
 @pytest.mark.parametrize("M", [1, 5, 8, 16, 17, 32, 33, 48, 64])
 @pytest.mark.parametrize("N,K", [(64, 256), (256, 704), (4096, 4096), (11008, 4096), (4096, 11008)])
 @pytest.mark.parametrize("compact", [False, True])
