@@ -162,42 +162,26 @@ __global__ __launch_bounds__(256, 2) void mxq_gemm_awq_f16_kernel(const uint16_t
         }
     };
 
-    // this slice's K-steps: t = z, z + S, ...  (a slice without a step writes zeros).  The packed words are the HBM stream:
-    // they are fetched THREE steps ahead into registers (9 dwords per step and thread; a step's MFMAs are shorter than a
-    // loaded-memory round trip, so one step ahead left every step waiting for its words); x comes one step ahead by
-    // LDS-DMA into the other LDS stage.  Steps past the end re-read the last one (no branch around a load).
-    const int t_last = NT > z ? z + (NT - 1 - z) / S * S : z;
-    WStage s0, s1, s2;
-    int t = z, it = 0;
+    // this slice's K-steps: t = z, z + S, ...  (a slice without a step writes zeros)
+    WStage st;
+    int t = z;
     if (t < NT) {
-        load_w(t, s0);
-        load_w(min(t + S, t_last), s1);
-        load_w(min(t + 2 * S, t_last), s2);
         issue_a(t, 0);
-        write_w(s0, 0);
+        load_w(t, st);
+        write_w(st, 0);
     }
     __syncthreads();   // (also drains the LDS-DMA)
-    // one step: stage HELD holds step t (already in LDS: reloaded with step t + 3 S), stage NEXT step t + S (written now)
-#define AWQ_STEP(HELD, NEXT)                                  \
-    {                                                         \
-        const int cur = it & 1;                               \
-        const bool more = t + S < NT;                         \
-        if (more) issue_a(t + S, cur ^ 1);                    \
-        load_w(min(t + 3 * S, t_last), HELD);                 \
-        compute(cur);                                         \
-        if (more) write_w(NEXT, cur ^ 1);                     \
-        __syncthreads();                                      \
-        t += S;                                               \
-        ++it;                                                 \
+    for (int it = 0; t < NT; t += S, ++it) {
+        const int cur = it & 1;
+        const bool more = t + S < NT;
+        if (more) {
+            issue_a(t + S, cur ^ 1);
+            load_w(t + S, st);
+        }
+        compute(cur);
+        if (more) write_w(st, cur ^ 1);
+        __syncthreads();
     }
-    while (t < NT) {
-        AWQ_STEP(s0, s1)
-        if (t >= NT) break;
-        AWQ_STEP(s1, s2)
-        if (t >= NT) break;
-        AWQ_STEP(s2, s0)
-    }
-#undef AWQ_STEP
 
     // lane holds y[m = .. + fr][n = .. + 4 fq + 0..3]
 #pragma unroll
