@@ -165,7 +165,9 @@ int mxq_gemm_f16_ws(const void* x, const void* qweight, const void* rowmeta, voi
  * kernel (csrc/midm.hip: K cut into slices over the workgroups, fp32 partial tiles in the workspace beyond its first
  * 64 KiB, summed in slice order by a second launch -- the reference launcher's split_k_iters regime,
  * gemm_cuda_gen.cu:429-475) for the mixed layouts, the prefill kernel otherwise.  The mid-M kernel does not touch
- * the workspace's counters. */
+ * the workspace's counters.  workspace == NULL: ONE workspace-free schedule for every layout -- GEMV (<= 4 tokens), the skinny
+ * kernel (mixed layouts <= 64, uniform <= 48), the mid-M kernel unsplit (mixed layouts, <= 256), whole tiles of the prefill
+ * kernel beyond (csrc/capi.hip linear_noworkspace). */
 int mxq_linear_f16_layout_ws(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                              int layout, void* workspace, size_t workspace_bytes, void* stream);
 
