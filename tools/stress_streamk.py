@@ -80,12 +80,18 @@ def main():
         if int(ws[:32768].view(torch.int32).abs().sum().item()) != 0:
             print(f"FAIL counters not zero: M={M} N={N} K={K} layout={layout} path={path}", flush=True)
             sys.exit(1)
+        # the status words of a wait that gave up (the last 16 bytes of the head) must stay zero: an expiry is a failure here
+        if int(ws[65536 - 16:65536].view(torch.int32).abs().sum().item()) != 0:
+            print(f"FAIL stream-K wait expired {ws[65536 - 16:65536].view(torch.int32).tolist()}: M={M} N={N} K={K} layout={layout} "
+                  f"path={path}", flush=True)
+            sys.exit(1)
         worst = max(worst, err)
         by_path[path + "/" + layout] = by_path.get(path + "/" + layout, 0) + 1
         n += 1
         if n % 50 == 0:
             print(f"{n} cases, {time.time() - t0:.0f} s, worst rel err {worst:.2e}", flush=True)
-    print(f"DONE {n} cases in {time.time() - t0:.0f} s, worst rel err {worst:.2e}, all deterministic, counters zero", flush=True)
+    packing.workspace_status(dev)          # every cached workspace (raises on a flagged one)
+    print(f"DONE {n} cases in {time.time() - t0:.0f} s, worst rel err {worst:.2e}, all deterministic, counters and status words zero", flush=True)
     print("cases by path/layout:", dict(sorted(by_path.items())), flush=True)
 
 
