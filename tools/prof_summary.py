@@ -13,8 +13,9 @@ import sys
 
 
 def main(src, dst, cmd):
-    stats = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)
-    trace = glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)
+    # (a directory that collected more than one run holds one file set per process id: take the newest)
+    stats = sorted(glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+    trace = sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     lines = [f"# rocprofv3 --kernel-trace --stats -- python3 {cmd}", f"# source: {src}", ""]
     if stats:
         lines.append("## kernel stats (rocprofv3 *_kernel_stats.csv; names truncated to 90 chars)")
