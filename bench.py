@@ -15,7 +15,10 @@ hidden state hopping rank -> rank+1 by RCCL send/recv: per-GPU work is fixed ("w
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (mxq_gemm8_f16_kernel,
 MFMA-bound): algorithmic 2*M*N*K flops of the launches of one step / their device time measured
-with HIP events on the launch stream.  `cpu_baseline` times the CPU restatement of the
+with HIP events on the launch stream; `roofline.traffic` = HBM-side bytes per launch from rocprofv3
+PMC child passes made in this run (live_traffic).  The other BASELINE configs ride along as side
+figures with their own roofline fractions: `decode_1gpu` (configs[2]), `fakequant_block` (configs[3]),
+`config5` (configs[4]); `--figure NAME` runs one of them alone.  `cpu_baseline` times the CPU restatement of the
 reference's dequant + F.linear (oracle/cpu_linear.py) on a bounded sample, rank 0 / N = 1 only.
 """
 from __future__ import annotations
@@ -133,6 +136,60 @@ def cpu_baseline(dev, budget_s=12.0):
                           "mxq_linear_f16_auto dispatch at 128 tokens), stream-ordered launches, HIP events",
             "sample": "config 1: one 4096x4096 MXQ Linear, M=128 tokens, dequant(fp32)+F.linear per call "
                       "(4.295 GFLOP), median of the calls that fit ~12 s; the GPU runs the same call on the same inputs"}
+
+
+def live_traffic(budget_s=150.0):
+    """HBM-side bytes per launch of the headline kernel, MEASURED in this run (the figure used to be an
+    offline constant): rocprofv3 child processes -- `--kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in SEPARATE
+    passes, as MI355X_MICROARCH.md's HBM section prescribes -- around tools/gemm_prof.py at the three Linear shapes of the
+    step; bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB (the gfx950 correction: FETCH_SIZE reports half the bytes of wide
+    reads), weighted by the shapes' launches per step.  Returns (avg bytes per launch, detail) or None when rocprofv3 is
+    not there, a pass fails or the budget runs out (the caller then falls back to the committed constant)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    shapes = [(LS.HIDDEN, LS.HIDDEN, 128), (LS.INTERMEDIATE, LS.HIDDEN, 64), (LS.HIDDEN, LS.INTERMEDIATE, 32)]   # N, K, launches per step
+    tmp = tempfile.mkdtemp(prefix="mxq_pmc_", dir="/tmp")
+    t_end = time.perf_counter() + budget_s
+    detail, tot, tot_n = {}, 0.0, 0
+    try:
+        for N, K, n in shapes:
+            vals = {}
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                left = t_end - time.perf_counter()
+                if left < 5:
+                    return None
+                d = os.path.join(tmp, f"{c}_{N}x{K}")
+                # (the program itself follows "--": no shell, no env wrapper -- the profiler's library has initialised the GPU by then)
+                r = subprocess.run([exe, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                    os.path.join(ROOT, "tools", "gemm_prof.py"), "gemm", str(SEQ), str(N), str(K), "6"],
+                                   cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.DEVNULL, timeout=left)
+                if r.returncode != 0:
+                    return None
+                rows = []
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    rows += [float(x["Counter_Value"]) for x in csv.DictReader(open(f))
+                             if "gemm8" in x["Kernel_Name"] and x["Counter_Name"] == c]
+                if not rows:
+                    return None
+                tail = rows[len(rows) // 2:]            # drop the warm-up half
+                vals[c] = sum(tail) / len(tail)
+            hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+            alg = (N // 16) * (K // 64) * 576 + N * 16 + 2 * SEQ * K + 2 * SEQ * N
+            detail[f"{SEQ}x{N}x{K}"] = {"hbm_bytes": hbm, "algorithmic_bytes": float(alg), "ratio": round(hbm / alg, 2)}
+            tot += hbm * n
+            tot_n += n
+        return tot / tot_n, detail
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 PEAK_HBM_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches)
@@ -294,6 +351,8 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="N = 1: replay the step as one hipGraph (measured r04: 1073.3 vs 1073.4 TFLOP/s stream-ordered -- the "
                          "queue never runs dry, so this is not the default)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC constant instead of rocprofv3 child passes in this run (~40 s)")
     ap.add_argument("--no-decode-pipeline", action="store_true",
                     help="N > 1: skip the bounded configs[2] side figure (greedy decode through the layer pipeline)")
     ap.add_argument("--fuse", action="store_true",
@@ -461,6 +520,14 @@ def main():
                          "launches_per_step": launches_rank_step,
                          "algorithmic_flop_per_launch": flops_rank_step / launches_rank_step},
         }
+        if world == 1 and not args.headline_only and not args.no_live_traffic:
+            lt = live_traffic()
+            if lt is not None:
+                out["roofline"]["traffic"] = lt[0]
+                out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes "
+                                                     "(separate) of tools/gemm_prof.py at the step's three shapes, (2*FETCH_SIZE + WRITE_SIZE) KiB "
+                                                     "per launch, weighted by launches per step")
+                out["roofline"]["traffic_by_shape"] = lt[1]
         if census is not None:
             out["ranks_seen"] = census["ranks_seen"]
             out["distinct_devices"] = census["distinct_devices"]
