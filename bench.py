@@ -153,6 +153,9 @@ def live_traffic(budget_s=150.0):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None
+    # already under a profiler (rocprofv3 -- python3 bench.py): no nested profiler runs
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     shapes = [(LS.HIDDEN, LS.HIDDEN, 128), (LS.INTERMEDIATE, LS.HIDDEN, 64), (LS.HIDDEN, LS.INTERMEDIATE, 32)]   # N, K, launches per step
     tmp = tempfile.mkdtemp(prefix="mxq_pmc_", dir="/tmp")
     t_end = time.perf_counter() + budget_s
