@@ -213,8 +213,8 @@ def decode_1gpu(dev, tokens=64, ctx=512):
     """Side figure, not `value`: BASELINE configs[2] on ONE GPU -- greedy decode, batch 1, all 32 layers, hipGraph token
     loop (mxq_amd/llama_decode.py), in both metadata modes.  Bytes = the packed weights a token streams (codes + group
     metadata + row metadata of the 224 Linears; lm_head, KV cache and activations not counted): the HBM roofline's
-    algorithmic bytes per token.  The dominant kernels are the streaming GEMVs (csrc/gemv.hip,
-    csrc/decode_layer.hip)."""
+    algorithmic bytes per token.  The dominant kernels are the streaming GEMVs (csrc/gemv.hip).
+    """
     from mxq_amd.llama_decode import decode_pipeline_figure
     out = {"workload": f"BASELINE configs[2] on one GPU: Llama-2-7B W2/4A16 greedy decode, batch 1, {tokens} tokens from position 0 "
                        f"(KV cache of {ctx}), hipGraph token loop; bytes = packed weight bytes per token",
@@ -226,6 +226,10 @@ def decode_1gpu(dev, tokens=64, ctx=512):
                      "GBps": fig["weight_stream_GBps"], "frac": round(fig["weight_stream_GBps"] / PEAK_HBM_GBPS, 4),
                      "launches_per_layer": fig.get("launches_per_layer"), "us_per_layer": round(fig["ms_per_token"] * 1e3 / LS.N_LAYERS, 2),
                      "first_tokens": fig["first_tokens"]}
+        if not compact:      # the same at a LONG context: 64 tokens from position 1920 of a 2048-row cache (split attention launch)
+            fig = decode_pipeline_figure(LayerPipeline(0, 1), dev, tokens=tokens, ctx=2048, start=1920, compact=False)
+            out["exact_at_position_1920"] = {"tokens_per_s": fig["tokens_per_s"], "ms_per_token": fig["ms_per_token"], "kv_cache_rows": 2048,
+                                             "GBps": fig["weight_stream_GBps"], "frac": round(fig["weight_stream_GBps"] / PEAK_HBM_GBPS, 4)}
         # (no torch.cuda.empty_cache() between figures: weights allocated into memory that was just handed back to the driver
         #  decode 3 % slower -- 700 vs 723 tokens/s on one box, tools/_variants/order_test.py in round 5 -- presumably smaller
         #  physically contiguous fragments behind the same virtual range; the box has 288 GB, nothing needs to be returned)

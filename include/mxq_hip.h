@@ -276,7 +276,7 @@ int mxq_attn_decode_row_f16(const void* qkv, void* k_cache, void* v_cache, const
                             int heads, int head_dim, int max_ctx, void* stream);
 
 /* The same for LONG contexts (round 5): one workgroup per head streams a head's whole cache through one CU (5 us per layer at
- * 72 keys, 13 at 450, ~40 at 2048); here a head's keys are split over up to `splits` workgroups (grid heads x splits), each
+ * 72 keys, 13 at 450, ~40 at 2048); here a head's keys are split over up to `splits` (<= 16) workgroups (grid heads x splits), each
  * parks its partial softmax {o[128], max, sum} in `workspace`, and the head's LAST arriver (an arrival counter: nobody waits)
  * merges them.  Up to 128 keys a head is ONE workgroup running mxq_attn_decode_row_f16's algorithm bit for bit, so short
  * contexts pay nothing; beyond, the result differs from the one-workgroup kernel by fp32 summation order and by not

@@ -182,7 +182,7 @@ size_t mxq_attn_split_workspace_bytes(int heads, int splits) {
 int mxq_attn_decode_split_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row, void* out,
                               int heads, int head_dim, int max_ctx, int splits, void* workspace, void* stream) {
     if (!qkv || !k_cache || !v_cache || !pos || !rope_row || !out || !workspace) return MXQ_E_NULL;
-    if (heads <= 0 || head_dim != 128 || max_ctx <= 0 || max_ctx > 32768 || splits < 1 || splits > 64) return MXQ_E_SHAPE;
+    if (heads <= 0 || head_dim != 128 || max_ctx <= 0 || max_ctx > 32768 || splits < 1 || splits > 16) return MXQ_E_SHAPE;
     if (!aligned16(workspace)) return MXQ_E_ALIGN;
     return mxq_launch_attn_decode_split_f16(qkv, k_cache, v_cache, pos, rope_row, out, heads, head_dim, max_ctx, splits, workspace,
                                             (hipStream_t)stream);

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(const uint16_t
 // writes the head's output, then re-zeroes the counter.  Up to SPLIT_MIN keys a head is ONE workgroup running the
 // single-workgroup algorithm above bit for bit (the other splits exit at once): short contexts pay nothing.
 // ws: int counters [heads] (zeroed once by the caller; left zeroed), then f32 parts [heads][S][HD + 2] from byte 1024 * ceil(heads / 256).
-constexpr int SPLIT_MIN = 128, SPLIT_CHUNK = 64;
+constexpr int SPLIT_MIN = 128, SPLIT_CHUNK = 64, MAX_SPLITS = 16;
 template <bool ROW>
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(const uint16_t* __restrict__ qkv,
                                                                         uint16_t* __restrict__ k_cache,
@@ -265,29 +265,47 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(const ui
     __syncthreads();
     const int part_ = tid & 3, kj = tid >> 2;
     const float scale = rsqrtf((float)HD);
-    for (int j = j0 + kj; j < j1; j += ATT_THREADS / 4) {
+    // cached keys [j0, jc) in a branch-free loop (two keys = eight 16-byte loads in flight per thread); the token's own key,
+    // which is not in the cache yet for this launch's readers, from LDS afterwards
+    const int jc = owns_new ? pos : j1;
+    auto kdot = [&](const uint4 (&kw)[4]) {
         float acc = 0.f;
-        if (j == pos) {
 #pragma unroll
-            for (int e = 0; e < 32; ++e) acc += q_s[part_ * 32 + e] * k_s[part_ * 32 + e];
-        } else {
-            const uint4* kr = (const uint4*)(kc + (int64_t)j * HD + part_ * 32);
-            uint4 kw[4];
+        for (int v = 0; v < 4; ++v) {
+            const uint32_t ws[4] = {kw[v].x, kw[v].y, kw[v].z, kw[v].w};
 #pragma unroll
-            for (int v = 0; v < 4; ++v) kw[v] = kr[v];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const uint32_t ws[4] = {kw[v].x, kw[v].y, kw[v].z, kw[v].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc += q_s[part_ * 32 + v * 8 + 2 * e] * h2f((uint16_t)(ws[e] & 0xFFFF));
-                    acc += q_s[part_ * 32 + v * 8 + 2 * e + 1] * h2f((uint16_t)(ws[e] >> 16));
-                }
+            for (int e = 0; e < 4; ++e) {
+                acc += q_s[part_ * 32 + v * 8 + 2 * e] * h2f((uint16_t)(ws[e] & 0xFFFF));
+                acc += q_s[part_ * 32 + v * 8 + 2 * e + 1] * h2f((uint16_t)(ws[e] >> 16));
             }
         }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
-        if (part_ == 0) sc[j - j0] = h2f(f2h(acc * scale));
+        return acc;
+    };
+    for (int j = j0 + kj; j < jc; j += 2 * (ATT_THREADS / 4)) {
+        const int ja = j, jb = j + ATT_THREADS / 4;
+        const bool vb = jb < jc;
+        const uint4* ka = (const uint4*)(kc + (int64_t)ja * HD + part_ * 32);
+        const uint4* kb = (const uint4*)(kc + (int64_t)(vb ? jb : ja) * HD + part_ * 32);
+        uint4 wa[4], wb[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) wa[v] = ka[v];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) wb[v] = kb[v];
+        const float sa = kdot(wa), sb = kdot(wb);
+        if (part_ == 0) {
+            sc[ja - j0] = h2f(f2h(sa * scale));
+            if (vb) sc[jb - j0] = h2f(f2h(sb * scale));
+        }
+    }
+    if (owns_new && kj == ((pos - j0) & (ATT_THREADS / 4 - 1))) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) acc += q_s[part_ * 32 + e] * k_s[part_ * 32 + e];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (part_ == 0) sc[pos - j0] = h2f(f2h(acc * scale));
     }
     __syncthreads();
     const int nk = j1 - j0;
@@ -314,20 +332,30 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(const ui
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    for (int j = j0 + kg; j < j1; j += 16) {
-        const float p = sc[j - j0];
-        if (j == pos) {
+    for (int j = j0 + kg; j < jc; j += 64) {           // four cached V rows in flight per thread (clamped, weight 0 past the end)
+        uint4 w[4];
+        float p[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += p * v_s[dg * 8 + e];
-        } else {
-            const uint4 w = *(const uint4*)(vc + (int64_t)j * HD + dg * 8);
-            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        for (int u = 0; u < 4; ++u) {
+            const int jj = j + 16 * u;
+            const bool ok = jj < jc;
+            w[u] = *(const uint4*)(vc + (int64_t)(ok ? jj : j) * HD + dg * 8);
+            p[u] = ok ? sc[jj - j0] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t ws[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o[2 * e] += p * h2f((uint16_t)(ws[e] & 0xFFFF));
-                o[2 * e + 1] += p * h2f((uint16_t)(ws[e] >> 16));
+                o[2 * e] += p[u] * h2f((uint16_t)(ws[e] & 0xFFFF));
+                o[2 * e + 1] += p[u] * h2f((uint16_t)(ws[e] >> 16));
             }
         }
+    }
+    if (owns_new && kg == ((pos - j0) & 15)) {
+        const float p = sc[pos - j0];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += p * v_s[dg * 8 + e];
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) o2[kg * HD + dg * 8 + e] = o[e];
@@ -350,17 +378,29 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(const ui
     if (tid == 0) last_s = __hip_atomic_fetch_add(cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S_eff - 1;
     __syncthreads();
     if (!last_s) return;
-    // the last arriver of the head: every part was drained before its arrival was counted; agent-scope loads
+    // the last arriver of the head: every part was drained before its arrival was counted.  ALL the parts' loads go out
+    // together (agent-scope: sc1 buffer loads; clamped to the last part, whose weight is then zero) -- read one after the
+    // other, 16 parts were 16 dependent round trips, most of the launch at 2000 keys
     if (tid < HD) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(part + (int64_t)h * S * (HD + 2)), 0,
+                                                                           S * (HD + 2) * 4, 0x00020000);
+        float m_[MAX_SPLITS], l_[MAX_SPLITS], o_[MAX_SPLITS];
+#pragma unroll
+        for (int s2 = 0; s2 < MAX_SPLITS; ++s2) {
+            const int off = (s2 < S_eff ? s2 : S_eff - 1) * (HD + 2) * 4;
+            m_[s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + HD * 4, 0, 16));
+            l_[s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + (HD + 1) * 4, 0, 16));
+            o_[s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + tid * 4, 0, 16));
+        }
         float M = -INFINITY;
-        for (int s2 = 0; s2 < S_eff; ++s2)
-            M = fmaxf(M, __hip_atomic_load(part + ((int64_t)h * S + s2) * (HD + 2) + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int s2 = 0; s2 < MAX_SPLITS; ++s2) M = s2 < S_eff ? fmaxf(M, m_[s2]) : M;
         float L = 0.f, acc = 0.f;
-        for (int s2 = 0; s2 < S_eff; ++s2) {
-            const float* p2 = part + ((int64_t)h * S + s2) * (HD + 2);
-            const float w = __expf(__hip_atomic_load(p2 + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - M);
-            L += w * __hip_atomic_load(p2 + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc += w * __hip_atomic_load(p2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int s2 = 0; s2 < MAX_SPLITS; ++s2) {
+            const float w = s2 < S_eff ? __expf(m_[s2] - M) : 0.f;
+            L += w * l_[s2];
+            acc += w * o_[s2];
         }
         out[h * HD + tid] = f2h(acc / L);
     }
@@ -553,7 +593,7 @@ size_t mxq_attn_split_workspace_bytes_impl(int heads, int splits) {
 // splits > 1: the long-context kernel (ws = mxq_attn_split_workspace_bytes(heads, splits), counters zeroed once)
 int mxq_launch_attn_decode_split_f16(const void* qkv, void* k_cache, void* v_cache, const void* pos, const void* rope_row,
                                      void* out, int heads, int head_dim, int max_ctx, int splits, void* ws, hipStream_t stream) {
-    if (head_dim != HD) return (int)hipErrorInvalidValue;
+    if (head_dim != HD || splits > MAX_SPLITS) return (int)hipErrorInvalidValue;
     const size_t smem = (size_t)(3 * HD + max_ctx + 8 + 16 * HD) * 4;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_decode_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,

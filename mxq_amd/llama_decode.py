@@ -108,7 +108,7 @@ class DecodeStage:
         # -- chosen on the HOST, which mirrors the device position (ContextWindow): up to SPLIT_KEYS keys the one-workgroup
         # launch (32 workgroups; the split launch's 256 cost 0.36 us per layer there), beyond it the split one; a captured
         # stage holds one graph of each and replays the one the position calls for
-        self.attn_splits = 8 if (self.fused and max_ctx > self.SPLIT_KEYS) else 1
+        self.attn_splits = (16 if max_ctx >= 1024 else 8) if (self.fused and max_ctx > self.SPLIT_KEYS) else 1
         self._long_ctx = False
         self._attn_ws = (torch.zeros(_lib.load().mxq_attn_split_workspace_bytes(heads, self.attn_splits), dtype=torch.uint8, device=dev)
                          if self.attn_splits > 1 else None)
@@ -344,9 +344,24 @@ class DecodeStage:
         self.k_cache.zero_()
         self.v_cache.zero_()
 
+    def seek(self, position: int, seed: int = 5):
+        """Benchmark helper: pretend ``position`` tokens have been decoded -- the KV cache rows below it filled with seeded
+        random keys / values, the device and host positions set -- so that the next tokens run at that context length."""
+        if not 0 <= position < self.max_ctx:
+            raise ValueError("position outside the KV cache")
+        g = torch.Generator(device=self.dev).manual_seed(seed)
+        self.k_cache.zero_()
+        self.v_cache.zero_()
+        self.k_cache[:, :, :position].copy_(torch.randn(self.k_cache[:, :, :position].shape, generator=g, device=self.dev).half())
+        self.v_cache[:, :, :position].copy_(torch.randn(self.v_cache[:, :, :position].shape, generator=g, device=self.dev).half())
+        self.pos.fill_(position)
+        self.window.reset()
+        self.window.take(position)
+
 
 def decode_pipeline_figure(pipe, dev, tokens: int = 32, ctx: int = 64, layers: int = LS.N_LAYERS, compact: bool = False,
-                           verify: bool = False, graph: bool = True, warm: int = 8, dist=None, backend: str = "nccl") -> dict:
+                           verify: bool = False, graph: bool = True, warm: int = 8, dist=None, backend: str = "nccl",
+                           start: int = 0) -> dict:
     """BASELINE configs[2] as one measurement: greedy decode of ``tokens`` tokens at batch 1 with the decoder layers
     sharded over ``pipe``'s ranks (rank r owns ``layer_range(r, world, layers)``), the hidden state and the next-token
     id moving point to point (pipeline.LayerPipeline.decode).  Every rank calls it; every rank returns the same kind of
@@ -377,13 +392,15 @@ def decode_pipeline_figure(pipe, dev, tokens: int = 32, ctx: int = 64, layers: i
 
     def run(n):
         stage.reset()
+        if start:                              # decode at a long context: the cache below `start` holds seeded random rows
+            stage.seek(start)
         if single:
             return stage.decode_tokens(tbuf, 1, n)
         return pipe.decode(1, n, stage.embed_token if pipe.is_first else None, stage_fn,
                            stage.head if pipe.is_last else None, hbuf, tbuf)
 
-    if max(warm, tokens) > ctx:
-        raise ValueError("ctx must hold the warm-up run and the timed run (each starts at position 0)")
+    if start + max(warm, tokens) > ctx:
+        raise ValueError("ctx must hold the warm-up run and the timed run (each starts at position `start`)")
     run(warm)
     torch.cuda.synchronize(dev)
     if dist is not None and world > 1:
@@ -410,7 +427,7 @@ def decode_pipeline_figure(pipe, dev, tokens: int = 32, ctx: int = 64, layers: i
     else:
         bad = None
     return {"config": "BASELINE configs[2]: Llama-2-7B W2/4A16 greedy decode, batch 1, whole layers sharded over the ranks",
-            "n_gpus": world, "layers": layers, "tokens": tokens, "ctx": ctx,
+            "n_gpus": world, "layers": layers, "tokens": tokens, "ctx": ctx, "start_position": start,
             "tokens_per_s": round(tokens / dt, 1), "ms_per_token": round(dt / tokens * 1e3, 3),
             "packed_weight_GB_per_token": round(nbytes.item() / 1e9, 3),
             "weight_stream_GBps": round(nbytes.item() / (dt / tokens) / 1e9, 1),
