@@ -8,10 +8,18 @@ on Llama-2-7B-shaped synthetic weights (BASELINE.json: metric; workload = config
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of all 224 quantized Linears (32 layers x q,k,v,o,gate,up,down) over
-one sequence of 2048 tokens = 26.53 TFLOP, inputs and packed weights resident in HBM.
+one sequence of 2048 tokens = 26.53 TFLOP, inputs and packed weights resident in HBM; every launch goes
+through the product entry (packing.linear(path="auto") -> mxq_linear_f16_auto, what QuantLinear.forward
+calls; --path picks one schedule for A/B runs and says so in config.entry).
 N > 1: whole decoder layers are sharded over the ranks (rank r owns layers [32r/N, 32(r+1)/N),
 SURVEY.md 8e) and N sequences flow through the layer pipeline per step, the [2048, 4096] fp16
-hidden state hopping rank -> rank+1 by RCCL send/recv: per-GPU work is fixed ("weak").
+hidden state hopping rank -> rank+1 by RCCL send/recv: per-GPU work is fixed ("weak").  N > 1 runs are
+contained (mxq_amd/pipeline.py: Watchdog, init_group, run_guarded): 120-s process-group timeout, a deadline per
+phase and a hard one below the driver's limit -- a stuck rank prints its stacks and exits 86, a failed rank exits
+non-zero at once with a rank-tagged traceback -- and rank 0's line carries every rank's own account of the timed
+region (`per_rank`: its GEMMs' device time, the time its stream waited for the hop in / for a send slot, bytes
+hopped, stream-K status, shader clock) and, in `decode_pipeline.per_rank`, each stage's time per token and the
+round trip of the hidden row to the next rank.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (mxq_gemm8_f16_kernel,
 MFMA-bound): algorithmic 2*M*N*K flops of the launches of one step / their device time measured
@@ -39,6 +47,7 @@ if ROOT not in sys.path:
 
 from mxq_amd import llama_shapes as LS  # noqa: E402
 from mxq_amd import packing  # noqa: E402
+from mxq_amd import pipeline  # noqa: E402
 from mxq_amd.pipeline import LayerPipeline, rank_census  # noqa: E402
 
 SEQ = 2048
@@ -327,7 +336,7 @@ def fused_launch_figure(layers, dev, x_h, x_i, y_h, steps=5):
         for lin in fused:
             for _name, p in lin:
                 x = x_i if p.K == LS.INTERMEDIATE else x_h
-                packing.linear(x, p, out=(ys[p.N] if p.N in ys else y_h), path="gemm")
+                packing.linear(x, p, out=(ys[p.N] if p.N in ys else y_h), path="auto")
     step()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -341,6 +350,34 @@ def fused_launch_figure(layers, dev, x_h, x_i, y_h, steps=5):
     return {"workload": "the headline's 224 Linears as 128 launches per step: q|k|v and gate|up fused along the output "
                         "dimension (NOT the headline configuration)",
             "ms_per_step": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "launches_per_step": 4 * len(layers)}
+
+
+class ClockStamps:
+    """Shader clock held between two points of a stream: 8 one-wave workgroups (one per XCD) stamp s_memtime and the 100-MHz
+    s_memrealtime (include/mxq_hip.h: mxq_clock_stamp); sclk = d(s_memtime) / d(s_memrealtime) x 100 MHz per XCD."""
+
+    def __init__(self, dev):
+        from mxq_amd import _lib
+        self.lib, self.dev = _lib.load(), dev
+        self.a = torch.zeros(32, dtype=torch.int64, device=dev)
+        self.b = torch.zeros(32, dtype=torch.int64, device=dev)
+
+    def stamp(self, which):
+        from mxq_amd import _lib
+        t = self.a if which == 0 else self.b
+        _lib.check(self.lib.mxq_clock_stamp(t.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream), "mxq_clock_stamp")
+
+    def mhz(self):
+        a, b = self.a.view(8, 4).cpu(), self.b.view(8, 4).cpu()
+        by_xcc = {}
+        for r0 in a.tolist():
+            for r1 in b.tolist():
+                if r0[2] == r1[2] and r1[1] > r0[1]:
+                    by_xcc[int(r0[2])] = (r1[0] - r0[0]) / (r1[1] - r0[1]) * 100.0
+        vals = sorted(by_xcc.values())
+        if not vals:
+            return None
+        return {"median": round(vals[len(vals) // 2], 1), "min": round(vals[0], 1), "max": round(vals[-1], 1), "xcds": len(vals)}
 
 
 def main():
@@ -365,6 +402,9 @@ def main():
     ap.add_argument("--fuse", action="store_true",
                     help="NOT the headline configuration: q|k|v and gate|up as one launch each (5 launches per layer "
                          "instead of 7; same weights, same FLOPs), reported with config.fused_launches = true")
+    ap.add_argument("--path", default="auto",
+                    help="packing.linear path of the timed launches.  Default 'auto' = the product entry, mxq_linear_f16_auto, with "
+                         "the workspace and scratch QuantLinear.forward passes; 'gemm', 'whole', 'gemm8', ... pick one schedule (A/B)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -378,21 +418,34 @@ def main():
     # share devices and the hidden state hops through host memory; numbers from such a run mean nothing)
     backend = os.environ.get("MXQ_BENCH_BACKEND", "nccl")
     local_rank = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    # N > 1: every phase has a deadline (a stuck rank prints where it is stuck and exits 86; the launcher names it), the whole
+    # run a hard one below the driver's 600 s, and the process group a 120-s timeout instead of torch's 10 minutes
+    dog = pipeline.Watchdog(rank, world, hard_deadline_s=float(os.environ.get("MXQ_BENCH_DEADLINE_S", 540))) if world > 1 else None
+
+    def phase(name, seconds):
+        if dog is not None:
+            dog.phase(name, seconds)
+    phase("rendezvous", 150)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        pipeline.init_group(backend, rank, world, dev)
+        fault = os.environ.get("MXQ_BENCH_FAULT", "")          # tests: "<rank>:exit" | "<rank>:hang" right after the rendezvous
+        if fault and int(fault.split(":")[0]) == rank:
+            if fault.endswith(":exit"):
+                pipeline.rank_log("MXQ_BENCH_FAULT: this rank dies now (exit 17)", rank, world)
+                os._exit(17)
+            pipeline.rank_log("MXQ_BENCH_FAULT: this rank hangs now", rank, world)
+            dog.phase("injected hang", float(os.environ.get("MXQ_BENCH_FAULT_DEADLINE_S", 20)))
+            time.sleep(3600)
 
     if args.figure:
         fig = {"decode_1gpu": decode_1gpu, "fakequant_block": fakequant_block, "config5": config5}[args.figure](dev)
         print(json.dumps({args.figure: fig}), flush=True)
         return
+    phase("build weights", 240)
     my_layers = list(LS.layer_range(rank, world))
     layers = build_layers(my_layers, dev)
     if args.fuse:   # LAYER_LINEARS order: q, k, v, o, gate, up, down
@@ -409,14 +462,17 @@ def main():
     n_micro = world          # sequences in flight per step: per-GPU work stays one full-model pass
 
     def stage(x_hidden):
+        # every launch goes through packing.linear(path="auto") -> mxq_linear_f16_auto: the entry QuantLinear.forward calls,
+        # with the per-stream workspace it passes (2048 tokens: the 256-token fused kernel, stream-K tail on gate / up)
         for lin in layers:
             for name, p in lin:
                 x = x_i if p.K == LS.INTERMEDIATE else x_hidden
-                packing.linear(x, p, out=(y_f[p.N] if p.N in y_f else y_i if p.N == LS.INTERMEDIATE else y_h), path="gemm")
+                packing.linear(x, p, out=(y_f[p.N] if p.N in y_f else y_i if p.N == LS.INTERMEDIATE else y_h), path=args.path)
 
     # N > 1: the schedule is mxq_amd.pipeline.LayerPipeline's (the same object the gloo tests drive on CPU): irecv of
     # micro-batch b+1 posted before b is computed, isend of b's output from a ring slot under b+1's compute
     pipe = LayerPipeline(rank, world) if world > 1 else None
+    stats = None
 
     def stage_fn(h):
         stage(h)
@@ -427,7 +483,7 @@ def main():
         if pipe is None:
             stage(x_h)
         else:
-            pipe.run_microbatches(stage_fn, [x_h] * n_micro, recv_buf, collect=False)
+            pipe.run_microbatches(stage_fn, [x_h] * n_micro, recv_buf, collect=False, stats=stats)
 
     def sync():
         torch.cuda.synchronize()
@@ -435,6 +491,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    phase("warmup", 150)
     for _ in range(args.warmup):
         step()
     sync()
@@ -446,27 +503,41 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             stage(x_h)
-        eager_step = step
 
         def step():   # noqa: F811
             graph.replay()
         step()
         sync()
+    phase("timed steps", 150)
+    stats = pipeline.PipelineStats(dev) if pipe is not None else None
+    clocks = ClockStamps(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
+    clocks.stamp(0)
     for _ in range(args.steps):
         step()
+    clocks.stamp(1)
     ev1.record()
     sync()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    phase("reports", 90)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    packing.workspace_status(dev)      # a stream-K wait that gave up in the timed region raises here (tiles would be NaN)
+    # a stream-K wait that gave up in the timed region (tiles would be NaN) must fail the run: N = 1 raises here; N > 1
+    # reports per rank first (every rank's verdict travels to rank 0's line), then every rank exits 4
+    ws_status = "ok"
+    try:
+        packing.workspace_status(dev)
+    except RuntimeError as e:
+        if world == 1:
+            raise
+        ws_status = str(e)
+    sclk = clocks.mhz()
     bits_per_weight = sum(p.nbytes() for lin in layers for _, p in lin) * 8.0 / (LS.PARAMS_PER_LAYER * max(1, len(my_layers)))
     tokens_per_step = SEQ * n_micro
     flops_per_step = LS.linear_flops(SEQ) * n_micro                      # whole job
@@ -477,8 +548,26 @@ def main():
     kern_ms = dev_ms / args.steps / launches_rank_step
     achieved = flops_rank_step / (dev_ms / args.steps * 1e-3) / 1e12
 
+    per_rank = None
+    if world > 1:        # every rank's own account of the timed region, on rank 0's line: one record explains its curve
+        summ = stats.summary(args.steps)
+        comp = summ.get("stream_compute_ms_per_step") or 0.0
+        rep = {"rank": rank, "layers": [my_layers[0], my_layers[-1]] if my_layers else [], "launches_per_step": launches_rank_step,
+               "device_ms_per_step": round(dev_ms / args.steps, 4), "host_ms_per_step": round(ms_per_step, 4),
+               # this rank's GEMMs alone (HIP events around its stage_fn calls): flat in N if the hops hide under compute
+               "stage_TFLOPs": round(flops_rank_step / comp / 1e9, 1) if comp > 0 else None,
+               "workspace_status": ws_status, "sclk_MHz": sclk}
+        rep.update(summ)
+        per_rank = pipeline.gather_reports(rep)
+        bad = [r for r in per_rank if r["workspace_status"] != "ok"]
+        if bad:
+            if rank == 0:
+                print("bench.py: stream-K wait expired on rank(s) " + ", ".join(f"{r['rank']}: {r['workspace_status']}" for r in bad),
+                      file=sys.stderr, flush=True)
+            raise SystemExit(4)
+
     traffic = None       # HBM bytes per launch from rocprofv3 PMC counters (collected offline, see the file)
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm8_traffic.json") for r in (5, 4, 3, 2))
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gemm8_traffic.json") for r in (6, 5, 4, 3, 2))
                   if os.path.exists(q)), "")
     if world == 1 and tpath:
         traffic = json.load(open(tpath))["avg_hbm_bytes_per_launch"]
@@ -493,13 +582,13 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {world} under RCCL needs {world} ranks on {world} distinct devices, saw ranks_seen="
                   f"{census['ranks_seen']} distinct_devices={census['distinct_devices']}: {census['ranks']}", file=sys.stderr, flush=True)
-        dist.barrier()
-        dist.destroy_process_group()
         raise SystemExit(3)
     decode_fig = None
     if world > 1 and not args.no_decode_pipeline:
+        phase("decode pipeline figure", 240)
         from mxq_amd.llama_decode import decode_pipeline_figure
         decode_fig = decode_pipeline_figure(pipe, dev, tokens=32, ctx=64, verify=True, dist=dist, backend=backend)
+    phase("print", 420 if world == 1 else 60)
     if rank == 0:
         bpw = bits_per_weight
         out = {
@@ -514,6 +603,8 @@ def main():
                        "tokens_per_step": tokens_per_step, "flop_per_step": flops_per_step,
                        "weight_format": "mxq-v1 exact metadata", "bits_per_weight": round(bpw, 3),
                        "fused_launches": bool(args.fuse),
+                       "entry": ("packing.linear(path='auto') -> mxq_linear_f16_auto (the product dispatch QuantLinear.forward calls)"
+                                 if args.path == "auto" else f"packing.linear(path={args.path!r}) (A/B: NOT the product dispatch)"),
                        "launch_mode": "hipGraph replay of the step's launches" if graph is not None else "stream-ordered launches",
                        "parallelism": "single GPU" if world == 1 else
                        f"pp{world}: whole layers sharded, {world} sequences in flight, RCCL send/recv of the "
@@ -525,7 +616,12 @@ def main():
                                             "not measured in this run") if traffic is not None else None,
                          "kernel": "mxq_gemm8_f16_kernel", "avg_launch_ms": round(kern_ms, 5),
                          "launches_per_step": launches_rank_step,
-                         "algorithmic_flop_per_launch": flops_rank_step / launches_rank_step},
+                         "algorithmic_flop_per_launch": flops_rank_step / launches_rank_step,
+                         # the shader clock the chip held over the timed region (s_memtime / s_memrealtime stamps on the launch
+                         # stream, per XCD): the peak is quoted at 2400 MHz, so frac_at_held_clock = frac x 2400 / sclk
+                         "sclk_MHz_during_timed_region": sclk,
+                         "frac_at_held_clock": (round(achieved / (PEAK_F16_TFLOPS * sclk["median"] / 2400.0), 4)
+                                                if sclk and sclk["median"] > 0 else None)},
         }
         if world == 1 and not args.headline_only and not args.no_live_traffic:
             lt = live_traffic()
@@ -540,6 +636,8 @@ def main():
             out["distinct_devices"] = census["distinct_devices"]
             out["ranks"] = census["ranks"]
             out["backend"] = backend
+            out["per_rank"] = per_rank
+            out["phases_s"] = dog.history
         if decode_fig is not None:
             decode_fig.pop("token_ids", None)
             out["decode_pipeline"] = decode_fig
@@ -553,9 +651,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(dev)
         print(json.dumps(out), flush=True)
     if dist is not None:
+        phase("teardown", 60)
         dist.barrier()
         dist.destroy_process_group()
+    if dog is not None:
+        dog.done()
 
 
 if __name__ == "__main__":
-    main()
+    pipeline.run_guarded(main)     # any failure of a rank: tagged traceback on stderr, immediate non-zero exit

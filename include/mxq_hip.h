@@ -146,6 +146,10 @@ size_t mxq_gemm_workspace_bytes(void);
  * workspace is reused.  mxq_workspace_status copies the four ints to `status4` (HOST memory) after synchronising `stream`
  * -- the one entry point of this library that synchronises. */
 int mxq_workspace_status(const void* workspace, size_t workspace_bytes, int* status4, void* stream);
+/* Measurement helper: one launch of 8 single-wave workgroups (one per XCD) writing {s_memtime, s_memrealtime (100 MHz), XCC id, 0}
+ * as 4 x uint64 each into `out32_u64` (32 x uint64, device memory).  Two stamps on one stream around a timed region give the
+ * shader clock the chip held in between, d(s_memtime) / d(s_memrealtime) x 100 MHz per XCD (bench.py: roofline.sclk_MHz). */
+int mxq_clock_stamp(void* out32_u64, void* stream);
 /* Bytes of workspace the dispatch of mxq_linear_f16_auto can use for a call of this shape (0: it never touches one --
  * GEMV, skinny kernel, or, with `hoisting` != 0, the hoisted mode from mxq_hoist_min_tokens() tokens on); at most
  * mxq_gemm_workspace_bytes().  For callers that own one workspace per captured graph.  Host-only helper. */

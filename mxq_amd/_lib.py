@@ -44,6 +44,7 @@ SIGNATURES = {
                                  c_void_p]),
     "mxq_gemm_workspace_bytes": (c_size_t, []),
     "mxq_workspace_status": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mxq_clock_stamp": (c_int, [c_void_p, c_void_p]),
     "mxq_linear_workspace_need": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "mxq_stream_capture_id": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mxq_hoist_scratch_bytes": (c_size_t, [c_int, c_int]),

@@ -412,6 +412,26 @@ int mxq_stream_capture_id(void* stream, int* active, unsigned long long* id) {
     return 0;
 }
 
+// Clock stamps (measurement helper): workgroup b of 8 -- one per XCD under the round-robin workgroup placement -- writes
+// {s_memtime (shader-clock ticks), s_memrealtime (100 MHz), XCC id, 0} as 4 x u64 at out[4 b].  Two stamps on one stream
+// around a timed region give the shader clock the chip held in between: d(memtime) / d(memrealtime) x 100 MHz per XCD
+// (MI355X_MICROARCH.md, "DVFS give-back" item 6).
+__global__ void mxq_clock_stamp_kernel(unsigned long long* out) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+    const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 15u;     // HW_REG_XCC_ID[3:0]
+    out[4 * blockIdx.x + 0] = t;
+    out[4 * blockIdx.x + 1] = r;
+    out[4 * blockIdx.x + 2] = xcc;
+    out[4 * blockIdx.x + 3] = 0;
+}
+
+int mxq_clock_stamp(void* out32_u64, void* stream) {
+    if (!out32_u64) return MXQ_E_NULL;
+    mxq_clock_stamp_kernel<<<8, 64, 0, (hipStream_t)stream>>>((unsigned long long*)out32_u64);
+    return (int)hipGetLastError();
+}
+
 // The stream-K kernels' status words (csrc/gemm8.hip, SK_STATUS_OFF: the last 16 bytes of the 64-KiB head).  The ONE entry
 // that synchronises: it waits for `stream`, then copies the four ints to the host.
 int mxq_workspace_status(const void* workspace, size_t workspace_bytes, int* status4, void* stream) {

@@ -413,6 +413,24 @@ def decode_pipeline_figure(pipe, dev, tokens: int = 32, ctx: int = 64, layers: i
     nbytes = torch.tensor([float(stage.packed_bytes())], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None and world > 1:
         dist.all_reduce(nbytes)
+    # world > 1: what one token's trip is made of, per rank -- this stage's layers alone (graph replays between two HIP
+    # events, nothing hopping) and the round trip of the [1, hidden] row across the boundary to the next rank.  A batch-1
+    # pipeline is sequential: ms_per_token ~ sum of the stages + one hop per boundary + the id's way back.
+    per_rank = None
+    if dist is not None and world > 1:
+        from .pipeline import gather_reports
+        stage.reset()
+        n_rep = min(16, ctx)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_rep):
+            stage_fn(hbuf, 0)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        stage_us = e0.elapsed_time(e1) / n_rep * 1e3
+        rtt = pipe.hop_round_trip_us(hbuf, iters=20, sync=lambda: torch.cuda.synchronize(dev))
+        per_rank = gather_reports({"rank": rank, "layers": len(stage.layers), "stage_us_per_token": round(stage_us, 2),
+                                   "hop_round_trip_us_to_next_rank": None if rtt is None else round(rtt, 2)}, pipe.group)
     equal = None
     if verify and world > 1 and rank == 0:
         del stage
@@ -434,4 +452,9 @@ def decode_pipeline_figure(pipe, dev, tokens: int = 32, ctx: int = 64, layers: i
             "metadata_mode": "compact (fp16 zero-points)" if compact else "exact (fp32 zero-points)",
             "hipgraph": bool(graph), "launches_per_layer": stage_launches, "first_tokens": toks[:8], "token_ids": toks,
             "backend": backend if world > 1 else None,
+            "per_rank": per_rank,
+            "sum_of_stages_ms": None if per_rank is None else round(sum(r["stage_us_per_token"] for r in per_rank) / 1e3, 3),
+            "sum_of_hops_ms": None if per_rank is None else round(
+                sum((r["hop_round_trip_us_to_next_rank"] or 0.0) / 2 for r in per_rank) / 1e3
+                + max((r["hop_round_trip_us_to_next_rank"] or 0.0) / 2 for r in per_rank) / 1e3, 3),
             "tokens_equal_single_process": equal, "first_mismatch": bad}

@@ -138,3 +138,65 @@ def test_layer_range_partition():
         assert got == list(range(32))
         sizes = [len(layer_range(r, world, 32)) for r in range(world)]
         assert max(sizes) - min(sizes) <= 1
+
+
+# -- bench.py's multi-rank harness at world 8 (tools/pipeline_rehearsal.py: the same Watchdog / init_group / run_guarded /
+#    PipelineStats / gather_reports / hop_round_trip_us objects bench.py uses, around a toy CPU stage) -------------------
+import json
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+def _rehearse(world, extra_env=None, timeout=240):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "tools", "pipeline_rehearsal.py"), "--steps", "2"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    return r, time.time() - t0
+
+
+def test_harness_world8_every_rank_accounts_for_its_waits():
+    r, _ = _rehearse(8)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_ranks"] == 8 and d["ranks_seen"] == 8 and d["decode_tokens_equal_single_process"] is True
+    assert [x["rank"] for x in d["per_rank"]] == list(range(8))
+    for x in d["per_rank"]:
+        first, last = x["rank"] == 0, x["rank"] == 7
+        assert x["microbatches_per_step"] == 8
+        assert x["hops_sent_per_step"] == (0 if last else 8) and x["hops_received_per_step"] == (0 if first else 8)
+        assert x["bytes_sent_per_step"] == (0 if last else 8 * 16 * 64 * 4)
+        assert x["host_compute_ms_per_step"] > 0 and (first or x["host_recv_wait_ms_per_step"] > 0)
+    assert [h["hop_round_trip_us_to_next_rank"] is not None for h in d["hops"]] == [True] * 7 + [False]
+    assert [p[0] for p in d["phases_s"]][:4] == ["start", "rendezvous", "build", "warmup"]
+
+
+@pytest.mark.parametrize("fault,code", [("3:exit", 17), ("5:hang", 86)])
+def test_harness_world8_a_dead_or_stuck_rank_fails_the_job_fast_and_is_named(fault, code):
+    """a deliberately killed rank makes the job exit != 0 well within 180 s with the rank named; a rank
+    that stops responding is ended by its own watchdog (stack dump, exit 86), never by the driver's silent limit."""
+    r, took = _rehearse(8, {"MXQ_BENCH_FAULT": fault, "MXQ_GROUP_TIMEOUT_S": "20", "MXQ_BENCH_FAULT_DEADLINE_S": "5"})
+    who = fault.split(":")[0]
+    assert r.returncode != 0 and took < 120, (r.returncode, took)
+    assert f"[rank {who}/8" in r.stderr and "MXQ_BENCH_FAULT" in r.stderr
+    assert f"exitcode: {code}) local_rank: {who}" in r.stderr                 # the launcher names the rank that failed first
+    if code == 86:
+        assert "WATCHDOG: phase 'injected hang' exceeded its deadline" in r.stderr and "File " in r.stderr   # with its stacks
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]        # no JSON line from a failed job
+
+
+def test_run_guarded_turns_an_exception_into_a_tagged_nonzero_exit():
+    code = ("import sys; sys.path.insert(0, %r)\nfrom mxq_amd.pipeline import run_guarded\n"
+            "def main():\n    raise ValueError('boom')\nrun_guarded(main)\nprint('not reached')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, RANK="2", WORLD_SIZE="4"))
+    assert r.returncode == 1 and "[rank 2/4" in r.stderr and "ValueError: boom" in r.stderr and "not reached" not in r.stdout

@@ -47,11 +47,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        from mxq_amd.pipeline import init_group
+        init_group(backend, rank, world, dev)        # 120-s group timeout: a stuck hop fails instead of blocking 10 minutes
     pipe = LayerPipeline(rank, world)
     fig = decode_pipeline_figure(pipe, dev, tokens=args.tokens, ctx=args.ctx, layers=args.layers, compact=args.compact,
                                  verify=args.verify, graph=not args.no_graph, dist=dist if world > 1 else None,
@@ -69,4 +66,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    from mxq_amd.pipeline import run_guarded
+    run_guarded(main)
