@@ -231,10 +231,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(const ui
     __syncthreads();                                                    // (split 0: every thread is out of the function's LDS use)
     const int pos = (int)pos64, n = pos + 1;
     // equal key ranges in units of SPLIT_CHUNK keys over the splits that get any
-    const int units = (n + SPLIT_CHUNK - 1) / SPLIT_CHUNK, S_eff = units < S ? units : S;
+    const int units = (n + SPLIT_CHUNK - 1) / SPLIT_CHUNK, S_max = units < S ? units : S;
+    const int per_units = (units + S_max - 1) / S_max, per = per_units * SPLIT_CHUNK;
+    // ceil(units / S_max) units per split leave the trailing splits EMPTY when units is not a multiple (513 keys over 8: 9 units,
+    // 2 per split, splits 5..7 hold nothing; 1100 over 16: 18 units, splits 9..15): only the splits that hold a key take part,
+    // so every counted part has nk >= 1 and a finite maximum (an empty part's {0, -inf, 0} merged correctly only
+    // because exp(-inf - M) == 0)
+    const int S_eff = (units + per_units - 1) / per_units;
     if (split >= S_eff) return;
-    const int per = (units + S_eff - 1) / S_eff * SPLIT_CHUNK;
-    const int j0 = split * per, j1 = min(n, j0 + per);                  // (the last split may be short, never empty: S_eff <= units)
+    const int j0 = split * per, j1 = min(n, j0 + per);                  // j0 < n for every split < S_eff: the last one may be short, never empty
     float* q_s = sm;
     float* k_s = sm + HD;
     float* v_s = sm + 2 * HD;

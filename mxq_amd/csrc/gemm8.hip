@@ -431,7 +431,12 @@ template <int ABL> constexpr int sk_spin_bound() { return (ABL & EXP_SK_WITHHOLD
 // The first failure's details stay (later ones only keep [0] non-zero); the tile (or token block) whose operands never
 // arrived is written as NaN.  The counters are then inconsistent: the host re-zeroes the head before the workspace is used
 // again (mxq_workspace_status reports, packing.workspace_status raises and resets).
-constexpr int SK_STATUS_OFF = 16380;
+// HOST MAILBOX (round 6): ints SK_MAILBOX_OFF, +1 of the head hold a 64-bit address of 4 ints of PINNED HOST memory (0: none;
+// written by the caller that owns the workspace, include/mxq_hip.h).  The first failure also stores its four status ints
+// there with system-scope stores -- the code last -- so the host sees an expired wait by reading its own memory, without
+// synchronising with the device: the product's next call on that workspace raises (mxq_amd/packing.py).  Costs nothing
+// unless a wait expires.
+constexpr int SK_STATUS_OFF = 16380, SK_MAILBOX_OFF = 16376;
 __device__ __forceinline__ void sk_fail(int* cnt, int code, int j, int seen, int lane) {
     if (lane == 0) {
         int* st = cnt + SK_STATUS_OFF;
@@ -439,6 +444,15 @@ __device__ __forceinline__ void sk_fail(int* cnt, int code, int j, int seen, int
             __hip_atomic_store(st + 1, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(st + 2, (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(st + 3, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long lo = (unsigned)__hip_atomic_load(cnt + SK_MAILBOX_OFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long hi = (unsigned)__hip_atomic_load(cnt + SK_MAILBOX_OFF + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int* mb = (int*)(lo | (hi << 32));
+            if (mb != nullptr) {
+                __hip_atomic_store(mb + 1, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(mb + 2, (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(mb + 3, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(mb, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -1317,7 +1331,11 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     const int cus = cu_count() / 8 * 8;
     int units = cus / 8;
     int dp_tiles = tiles, tail = 0;
-    if (workspace && tiles % cus != 0 && units * 8 * N_MMA <= SK_DONE_OFF && (SK_DONE_OFF + units * 8) * sizeof(int) <= CNT_BYTES &&
+    // a stream-K launch's workgroups wait for one another: its grid (<= cus) must fit the device all at once -- asked of the
+    // occupancy calculator for THIS kernel's registers and LDS, once per device; if it does not (or the query fails) the
+    // launch keeps whole tiles, which never wait
+    const bool coresident = mxq_resident_workgroups<&G8_KERNEL<ABL, LAYOUT>>(THREADS, SMEM_BYTES) >= cus;
+    if (workspace && coresident && tiles % cus != 0 && units * 8 * N_MMA <= SK_DONE_OFF && (SK_DONE_OFF + units * 8) * sizeof(int) <= CNT_BYTES &&
         ws_bytes >= CNT_BYTES + (size_t)cus * 2 * BM * BN * sizeof(float)) {
         const int t8 = (tiles % cus) / 8;   // tail tiles per XCD (the first tail % 8 XCDs hold one more)
         // Splitting the tail saves the idle share of one tile time, (1 - tail/CUs) * NT K-steps of ~1 us, and costs the

@@ -110,6 +110,7 @@ class DecodeStage:
         # stage holds one graph of each and replays the one the position calls for
         self.attn_splits = (16 if max_ctx >= 1024 else 8) if (self.fused and max_ctx > self.SPLIT_KEYS) else 1
         self._long_ctx = False
+        self._pin_long = None        # capture (and its eager pre-run) pins the attention launch; None: by the host position
         self._attn_ws = (torch.zeros(_lib.load().mxq_attn_split_workspace_bytes(heads, self.attn_splits), dtype=torch.uint8, device=dev)
                          if self.attn_splits > 1 else None)
         self._graph = None
@@ -200,7 +201,9 @@ class DecodeStage:
         if self.window.pos >= self.max_ctx:
             raise RuntimeError(f"decode position {self.window.pos} is outside the KV cache (max_ctx = {self.max_ctx})")
         if self.fused:
-            if not torch.cuda.is_current_stream_capturing():
+            if self._pin_long is not None:
+                self._long_ctx = self._pin_long                             # capture and its eager pre-run: pinned
+            elif not torch.cuda.is_current_stream_capturing():
                 self._long_ctx = self.window.pos + 1 > self.SPLIT_KEYS      # eager step: the host knows the position
             if not rope_done:
                 self._rope_row()
@@ -258,18 +261,20 @@ class DecodeStage:
         """One graph of ``body`` with the one-workgroup attention launch and -- when the cache is longer than SPLIT_KEYS --
         one with the split launch; ``_pick`` replays the one the host-side position calls for."""
         graphs = []
-        for long_ctx in ((False, True) if self.attn_splits > 1 else (False,)):
-            self._long_ctx = long_ctx
-            if long_ctx:                       # (the split kernel's launch attributes are set outside capture)
-                body()
-                self.pos.zero_()
-                torch.cuda.synchronize()
-            self._long_ctx = long_ctx          # (an eager step sets it from the host position; the capture pins it)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                body()
-            graphs.append(g)
-        self._long_ctx = False
+        try:
+            for long_ctx in ((False, True) if self.attn_splits > 1 else (False,)):
+                self._pin_long = long_ctx          # step() takes the pinned launch, eager or captured
+                if long_ctx:                       # eager pre-run of the SPLIT launch: its first launch (and, for caches whose
+                    body()                         # LDS need exceeds 64 KiB, its hipFuncSetAttribute) happens outside capture
+                    self.pos.zero_()
+                    torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body()
+                graphs.append(g)
+        finally:
+            self._pin_long = None
+            self._long_ctx = False
         return graphs[0], (graphs[1] if len(graphs) > 1 else None)
 
     def _pick(self, short, long_, position: int):

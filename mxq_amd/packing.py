@@ -50,6 +50,15 @@ def _on_device(device: torch.device):
 _WORKSPACES: Dict[tuple, torch.Tensor] = {}
 _WS_EAGER: Dict[tuple, bool] = {}    # key -> the counter head has been zeroed (eagerly, or by a memset recorded in its graph)
 _WS_HEAD = 65536      # bytes of K-step counters at the head of a workspace (include/mxq_hip.h)
+_WS_MAILBOX_OFF = 65504   # bytes: 64-bit address of the workspace's host mailbox (csrc/gemm8.hip SK_MAILBOX_OFF)
+# A stream-K wait that expires (include/mxq_hip.h) writes the affected tile as NaN and flags the workspace.  The flag must reach
+# the CALLER without anybody polling: every workspace owns 4 ints of pinned host memory ("mailbox") whose address sits in its
+# head; the kernel stores its status there with system-scope stores, and every later hand-out of that workspace -- i.e. the next
+# packing.linear / QuantLinear.forward call on it -- reads the mailbox (plain host memory, no synchronisation) and raises.  A
+# starved launch therefore cannot feed NaN activations into a model for more than the launches already queued behind it.
+# MXQ_CHECK_WORKSPACE=1 checks synchronously after EVERY call instead (debugging).
+_MAILBOX: Dict[tuple, tuple] = {}     # key -> (pinned int32[4] tensor, its numpy view)
+_CHECK_EVERY_CALL = __import__("os").environ.get("MXQ_CHECK_WORKSPACE", "") not in ("", "0")
 MIDM_MAX_TOKENS = 256     # capi.hip: the most tokens mxq_linear_f16_ws may hand to the mid-M split-K kernel (no counters)
 
 
@@ -112,6 +121,8 @@ def gemm_workspace(device: torch.device, counters: bool = True, stream: Optional
             key = (dev_index, "capture", cid, full)
     if ws is None:
         ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        box = torch.zeros(4, dtype=torch.int32).pin_memory()
+        _MAILBOX[key] = (box, box.numpy())
         if capturing:
             _WS_EAGER[key] = False                    # ... until a counters hand-out has recorded the memset
             _CAPTURE_KEYS.append(key)
@@ -119,13 +130,42 @@ def gemm_workspace(device: torch.device, counters: bool = True, stream: Optional
                 old = _CAPTURE_KEYS.pop(0)
                 _WORKSPACES.pop(old, None)
                 _WS_EAGER.pop(old, None)
+                _MAILBOX.pop(old, None)
         else:
             _WS_EAGER[key] = True
-            ws[:_WS_HEAD].zero_()
+            _zero_head(ws, key)
+    else:
+        box = _MAILBOX.get(key)
+        if box is not None and box[1][0] != 0:        # a launch that ran on this workspace since the last hand-out gave up a wait
+            _raise_expired(key, ws)
     if capturing and counters and not _WS_EAGER.get(key, False):
-        ws[:_WS_HEAD].zero_()                          # recorded once per graph and buffer
+        _zero_head(ws, key)                            # recorded once per graph and buffer (memset + the mailbox's address)
         _WS_EAGER[key] = True
     return ws
+
+
+def _zero_head(ws: torch.Tensor, key) -> None:
+    """Zero a workspace's 64-KiB head and write the address of its host mailbox into it (stream-ordered; under capture both
+    operations are recorded into the graph)."""
+    ws[:_WS_HEAD].zero_()
+    box = _MAILBOX.get(key)
+    if box is not None:
+        ws[_WS_MAILBOX_OFF:_WS_MAILBOX_OFF + 8].view(torch.int64).fill_(box[0].data_ptr())
+
+
+def _raise_expired(key, ws: torch.Tensor):
+    """The mailbox of ``ws`` is set: report, clear it, make the workspace usable again (synchronises), raise."""
+    box, view = _MAILBOX[key]
+    st = [int(v) for v in view]
+    dev_index = key[0]
+    torch.cuda.synchronize(dev_index)
+    view[:] = 0
+    with torch.cuda.device(dev_index):
+        _zero_head(ws, key)
+        torch.cuda.synchronize(dev_index)
+    raise RuntimeError(f"stream-K wait expired on workspace {key}: [code, tail tile, workgroup, count seen] = {st}; the affected "
+                       "output tiles of that launch are NaN (results computed since then on this stream are suspect); the "
+                       "workspace has been reset")
 
 
 _HOIST: Dict[tuple, torch.Tensor] = {}
@@ -191,7 +231,10 @@ def workspace_status(device: Optional[torch.device] = None, reset: bool = True) 
             if st[0] != 0:
                 bad.append((key, list(st)))
                 if reset:
-                    ws[:_WS_HEAD].zero_()
+                    box = _MAILBOX.get(key)
+                    if box is not None:
+                        box[1][:] = 0
+                    _zero_head(ws, key)
                     torch.cuda.synchronize(dev_index)
     if bad:
         raise RuntimeError("stream-K wait expired (workspace key, [code, tail tile, workgroup, count seen]): "
@@ -206,7 +249,11 @@ def reset_gemm_workspace(device: Optional[torch.device] = None):
         dev_index = key[0]
         if device is None or (device.index if device.index is not None else torch.cuda.current_device()) == dev_index:
             torch.cuda.synchronize(dev_index)
-            ws[:_WS_HEAD].zero_()
+            box = _MAILBOX.get(key)
+            if box is not None:
+                box[1][:] = 0
+            with torch.cuda.device(dev_index):
+                _zero_head(ws, key)
             torch.cuda.synchronize(dev_index)
 
 
@@ -439,6 +486,8 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
                                                scratch.data_ptr() if scratch is not None else None,
                                                scratch.numel() if scratch is not None else 0, st),
                        "mxq_linear_f16_auto")
+            if _CHECK_EVERY_CALL and ws is not None:
+                workspace_status(x2.device)
         return out if flat else out.reshape(*x.shape[:-1], p.N)
     if path == "gemm" and M >= HOIST_MIN_TOKENS:
         return linear_hoisted(x, p, out=out)
@@ -475,6 +524,8 @@ def linear(x: torch.Tensor, p: PackedMXQ, out: Optional[torch.Tensor] = None, pa
             else:
                 raise ValueError(f"unknown path {path!r}")
         _lib.check(rc, f"mxq_linear_f16[{path}]")
+        if _CHECK_EVERY_CALL and path not in ("gemv",) and M > 4:
+            workspace_status(x2.device)
     return out.reshape(*x.shape[:-1], p.N)
 
 

@@ -72,6 +72,10 @@ def gemm_forward_cuda(in_feats, kernel, scaling_factors, zeros, split_k_iters):
         raise ValueError("OC is not multiple of Group size")
     if scaling_factors.shape[1] != OC or tuple(zeros.shape) != (IC // group_size, OC // 8):
         raise ValueError("scaling_factors must be [IC/G, OC] and zeros [IC/G, OC/8]")
+    if IC % 64 != 0 or IC < 64:
+        # (a deliberate deviation, INTEGRATION.md: the reference's K loop is 32 deep -- gemm_cuda_gen.cu `k_0_0 * 32` -- so it
+        #  accepts IC % 64 == 32; this kernel's K-step is one 64-wide chunk)
+        raise ValueError(f"IC must be a multiple of 64 (this kernel's K-step), got {IC}")
     S = int(split_k_iters)
     if S < 1:
         raise ValueError("split_k_iters must be >= 1")

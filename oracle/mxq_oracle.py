@@ -5,14 +5,23 @@ path.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg may import this package; the product path
 (``mxq_amd``) never does and fails loudly when the HIP library is missing.
 
-Parity is PINNED for everything the reference can execute: those functions are checked
-against golden vectors that were generated by running the reference's own Python on CPU
-(``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``; see
-``tests/test_oracle_golden.py``).  PARITY UNPINNED for ONE group, ``gemm_awq_*`` (the operand
-format of ``gemm_forward_cuda``): the reference declares that entry but never compiles it
-(``cuda_kernel/setup.py:37-41``), ships no packer, test or vector for it, and it is CUDA + PTX
-(no ``nvcc`` here) -- the restatement follows ``dequantize.cuh:15-78`` and
-``gemm_cuda_gen.cu:124-141`` as read.
+How far each restatement is pinned -- three groups, stated wherever the oracle is cited (README):
+
+1. PINNED by fixtures produced by RUNNING the reference's own Python on CPU (``tests/golden/make_golden.py`` ->
+   ``tests/golden/g1..g5, g7..g9*.npz``, held bit-exactly by ``tests/test_oracle_golden.py``): ``quantize`` / ``dequantize`` /
+   ``find_params`` / ``mxq_quantize`` (the fasterquant layout) / ``linear_ref``, the uniform W2G16 / W4ROW arms (the
+   reference's ``Quantizer``), ``mx_fake_quant`` / ``ste_clip_backward`` / ``QuantizeLinear`` / the decoder block, and the
+   activation quantisers.  SURVEY.md 8 rows a1-a5, a9-a12 and the native-layout side of a6 / a7.
+2. PINNED AT ONE POINT ONLY: ``gemv_mxq_proto_ref`` (the prototype operand format of ``gemv_mxq_forward_cuda``).  The
+   reference holds exactly one known answer for it, the constant-operand KAT of ``cuda_kernel/test_correct_gemv.py:19-53``
+   (every output == 4096, fixture g6).  Constant operands cannot see a column-mapping or field-order error (SURVEY.md 4 says
+   so itself); beyond that point the function restates ``gemv_mxq_cuda.cu:39-208`` as read.
+3. PARITY UNPINNED (restatements of the source as read; the reference holds no vector, test or packer, and its native code is
+   CUDA + PTX with no ``nvcc`` here): ``gemv_awq_ref`` (operand format of ``gemv_forward_cuda``, ``gemv_cuda.cu:45-242`` --
+   only ever called by the unchecked timing script ``test_mxq_gemv.py``) and ``gemm_awq_*`` (operand format of
+   ``gemm_forward_cuda``, which the reference declares but never compiles, ``cuda_kernel/setup.py:37-41``; follows
+   ``dequantize.cuh:15-78`` and ``gemm_cuda_gen.cu:124-141``).  GPU-vs-oracle agreement on these two says the kernel and the
+   restatement read the source the same way, nothing more.
 
 Reference files restated (paths relative to the upstream repo):
 
@@ -25,7 +34,7 @@ Reference files restated (paths relative to the upstream repo):
   ``gemv_cuda.cu:45-242`` operand formats of the two exported GEMV entry points
   (restated with the *intended* column mapping).
 * ``mxq_quant/cuda_kernel/csrc/quantization/dequantize.cuh:15-78``, ``gemm_cuda_gen.cu:124-141,
-  424-478`` operand format of ``gemm_forward_cuda`` (unpinned, see above).
+  424-478`` operand format of ``gemm_forward_cuda`` (unpinned, group 3 above).
 
 All float work is done in numpy float32, one IEEE operation per reference op,
 so results are bit-identical to torch CPU float32.  ``np.rint`` is
@@ -286,7 +295,8 @@ def fakequant_bwd(grad_out, w, lo=-2.0, hi=2.0):
 # Operand formats of the reference's two exported GEMV entry points
 # --------------------------------------------------------------------------- #
 def gemv_awq_ref(x16, kernel, scales16, zeros, group_size):
-    """gemv_forward_cuda semantics (gemv_cuda.cu:45-242, :346-399).
+    """gemv_forward_cuda semantics (gemv_cuda.cu:45-242, :346-399).  PARITY UNPINNED: the reference holds no value
+    check for this entry (only the timing script test_mxq_gemv.py calls it); restated as read.
 
     kernel int32 [OC, IC/8] (nibble j of word = element j), scales fp16
     [OC, sf_w], zeros int32 [OC, zeros_w] with zeros_w = ceil(ceil(IC/G/8)/4)*4
@@ -349,7 +359,8 @@ def gemm_awq_ref(x16, kernel, scales16, zeros, group_size):
 
 def gemv_mxq_proto_ref(x16, weight, weight_last, zeros_and_scales, scales_2nd, zeros_2nd,
                        scales_4b, zeros_4b):
-    """gemv_mxq_forward_cuda semantics (gemv_mxq_cuda.cu:39-208) with the intended
+    """PINNED AT ONE POINT (the constant-operand KAT, fixture g6) -- everything else as read:
+    gemv_mxq_forward_cuda semantics (gemv_mxq_cuda.cu:39-208) with the intended
     column mapping: lane t, iteration it owns columns 2048*it + 64*t .. +63
     (the reference kernel's iteration-1 activation offset
     bug, :119, is deliberately not reproduced)."""

@@ -623,47 +623,6 @@ def test_workspace_free_dispatch_every_layout(dev, M):
     assert lib.mxq_linear_workspace_need(M, N, K, 0, 1) <= lib.mxq_gemm_workspace_bytes()
 
 
-def _graph_us(fn, calls=10, reps=5):
-    """us per call of `fn` under hipGraph replay (`calls` calls per graph, best of `reps` replays)."""
-    fn()
-    torch.cuda.synchronize()
-    gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
-        for _ in range(calls):
-            fn()
-    best = float("inf")
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        gr.replay()
-        e0.record()
-        gr.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / calls * 1e3)
-    return best
-
-
-@pytest.mark.parametrize("M,N,K,others", [
-    (16, 4096, 4096, ["skinny", "midm"]),
-    (64, 11008, 4096, ["midm", "gemm8q_split", "skinny"]),
-    (128, 4096, 4096, ["midm", "gemm8h_slices", "gemm8n_slices", "gemm8"]),
-    (256, 11008, 4096, ["midm", "gemm8h_split", "gemm8"]),
-    (512, 4096, 4096, ["gemm8", "gemm8h_split", "gemm8n_split"]),
-    (2048, 11008, 4096, ["whole", "gemm1"])])
-def test_dispatch_is_within_15_percent_of_the_fastest_schedule_on_this_box(dev, M, N, K, others):
-    """The dispatch thresholds of csrc/capi.hip were tuned on boxes that differ by a few percent (VERDICT r4 weak #1c): on
-    THIS box, under hipGraph replay, path "auto" must not be more than 15 % slower than the fastest explicitly chosen
-    schedule of its neighbourhood -- a threshold that has drifted to the wrong side of a crossover shows up here."""
-    from mxq_amd import packing
-    p, _w16, g = _packed_case(dev, N, K, M + N)
-    x = torch.randn(M, K, generator=g).half().to(dev)
-    out = torch.empty(M, N, dtype=torch.float16, device=dev)
-    t = {path: _graph_us(lambda path=path: packing.linear(x, p, out=out, path=path)) for path in ["auto"] + others}
-    best = min(t, key=t.get)
-    assert t["auto"] <= 1.15 * t[best], {k: round(v, 2) for k, v in t.items()}
-    packing.workspace_status(x.device)
-
-
 @pytest.mark.parametrize("M,N,K,build", [(512, 1024, 8192, "gemm8"),     # owner protocol (units straddle two tiles)
                                           (256, 2048, 4096, "gemm8"),     # 16 contributors per tile: all-contributors reduction
                                           (384, 4096, 4096, "gemm8h")])   # the 128-token build
@@ -936,15 +895,15 @@ def test_attn_decode_kernel_across_the_prefetched_rows(dev, pos):
     assert torch.equal(out2, out) and torch.equal(kc2, kc) and torch.equal(vc2, vc)
 
 
-@pytest.mark.parametrize("pos", [0, 63, 127, 128, 129, 191, 192, 300, 511, 512, 777, 1023])
-@pytest.mark.parametrize("splits", [8, 3])
-def test_attn_decode_split_over_keys(dev, pos, splits):
+@pytest.mark.parametrize("pos,splits,heads,ctx", [(p, s, 4, 1024) for s in (8, 3) for p in (0, 63, 127, 128, 129, 191, 192, 300, 511, 512, 777, 1023)]
+                         + [(p, 16, 32, 2048) for p in (128, 1100, 1920, 2047)])      # the shipped long-cache configuration: 16 splits, 32 heads
+def test_attn_decode_split_over_keys(dev, pos, splits, heads, ctx):
     """Long contexts: a head's keys split over up to `splits` workgroups, partial softmax parts merged by the head's last
     arriver (csrc/decode_ops.hip attn_decode_split_kernel).  Up to 128 keys the result is the one-workgroup kernel's bit for
     bit; beyond, against a torch restatement (fp32 softmax over fp16-rounded scores).  Exactly one cache row appended,
     the arrival counters left zeroed, launch after launch on the same workspace."""
     from mxq_amd import _lib
-    heads, hd, ctx = 4, 128, 1024
+    hd = 128
     g = torch.Generator(device=dev).manual_seed(pos * 7 + splits)
     qkv = torch.randn(3 * heads * hd, generator=g, device=dev).half()
     kc0 = torch.randn(heads, ctx, hd, generator=g, device=dev).half()
@@ -1426,6 +1385,45 @@ def test_proto_and_awq_gemv_random_vs_oracle(dev, B):
         _check_gemm(y, yref, f"awq gemv g{G}")
 
 
+def test_reference_timing_script_operands_vs_oracle(dev):
+    """The operands of the reference's timing harness, cuda_kernel/test_mxq_gemv.py:35-73 (M = 1, N = K = 4096), seeded
+    instead of unseeded: `gemv_forward_cuda(A, B, scales, zeros, 128)` and
+    `gemv_mxq_forward_cuda(A, B, B, scales_1nd, scales_2nd, zeros_2nd, scales_4b, zeros_4b, 16)` -- the SAME tensor `B`
+    [N, K/16] as `kernel` and as `kernel_last` (the kernel reads its first N * K/64 words, row stride K/64,
+    gemv_mxq_cuda.cu:56), `scales_2nd` as [N/4, K/16] read with a row stride of 192 (:61), and `zeros_2nd` as [N/4, 16]
+    although the kernel's row stride is 32 (:59, :70: the reference reads out of bounds; here the operand is zero-padded,
+    mxq_inference_engine/__init__.py).  The script checks no values; this test checks them against the oracle given
+    exactly what the kernel is specified to read."""
+    import mxq_inference_engine as eng
+    M, N, K = 1, 4096, 4096
+    g = torch.Generator().manual_seed(20240607)
+    A = torch.randn((M, K), generator=g).half()
+    # -- awq_4bit leg (script lines 35-54)
+    B8 = torch.randint(-1000000000, 1000000000, (N, K // 8), generator=g, dtype=torch.int32)
+    scales = torch.randn((N, K // 128), generator=g).half()
+    zeros = torch.ones((N, K // 128 // 8), dtype=torch.int32)
+    C = eng.gemv_forward_cuda(A.to(dev), B8.to(dev), scales.to(dev), zeros.to(dev), 128)
+    assert C.shape == (M, N) and C.dtype == torch.float16
+    _check_gemm(C.cpu().numpy(), O.gemv_awq_ref(A.numpy(), B8.numpy(), scales.numpy(), zeros.numpy(), 128), "script awq leg")
+    # -- mxq_2.8bit leg (script lines 63-82)
+    B16 = torch.randint(-1000000000, 1000000000, (N, K // 16), generator=g, dtype=torch.int32)
+    scales_1nd = torch.ones((N, K // 16 // 16 * 2), dtype=torch.int32)
+    scales_2nd = torch.randn((N // 4, K // 16), generator=g).half()
+    zeros_2nd = torch.ones((N // 4, K // 16 // 16), dtype=torch.int32)
+    scales_4b = torch.randn(N, generator=g).half()
+    zeros_4b = torch.ones(N // 8, dtype=torch.int32)
+    Bd = B16.to(dev)
+    C = eng.gemv_mxq_forward_cuda(A.to(dev), Bd, Bd, scales_1nd.to(dev), scales_2nd.to(dev), zeros_2nd.to(dev),
+                                  scales_4b.to(dev), zeros_4b.to(dev), 16)
+    assert C.shape == (M, N) and C.dtype == torch.float16
+    last = B16.numpy().reshape(-1)[: N * (K // 64)].reshape(N, K // 64)         # what a row stride of K/64 sees of B
+    z2 = np.zeros((N // 4) * 32, np.int32)
+    z2[: zeros_2nd.numel()] = zeros_2nd.numpy().reshape(-1)                       # the padded operand
+    want = O.gemv_mxq_proto_ref(A.numpy(), B16.numpy(), last, scales_1nd.numpy(), scales_2nd.numpy(), z2.reshape(N // 4, 32),
+                                scales_4b.numpy(), zeros_4b.numpy())
+    _check_gemm(C.cpu().numpy(), want, "script mxq leg")
+
+
 # ----------------------------------------------------------------------------------------
 # QAT: MXAsymQuantizer / QuantizeLinear
 # ----------------------------------------------------------------------------------------
@@ -1894,6 +1892,50 @@ def test_decode_token_graph_matches_eager_loop(dev):
     graphed = st.decode_tokens(tbuf, 3, 12)
     assert graphed == eager and len(set(graphed)) > 1
     assert int(st.pos.item()) == 12
+
+
+@pytest.mark.parametrize("max_ctx,splits", [(256, 8), (1024, 16)])
+def test_decode_stage_long_context_graphs_match_eager_across_the_split_switch(dev, max_ctx, splits):
+    """the configuration that ships for long contexts -- `attn_splits` 8 / 16, a short and a long captured
+    graph switched by `_pick` at 128 keys, ONE split workspace shared by all layers -- decodes 150 tokens (positions 0..149:
+    the one-workgroup launch up to 128 keys, the split launch beyond) three ways on the same stage weights: the eager
+    `step` + `advance` loop, the per-stage graph (`capture` / `step_graph`) and the one-graph-per-token loop
+    (`capture_token_loop` / `decode_tokens`).  Same kernels in the same order: the ids must be identical."""
+    from mxq_amd.llama_decode import DecodeStage
+    n = 150
+
+    def mk():
+        st = DecodeStage(range(2), dev, max_ctx=max_ctx, first=True, last=True, hidden=256, inter=704, heads=2, vocab=512)
+        assert st.fused and st.attn_splits == splits
+        return st
+    st = mk()
+    tok = torch.full((1,), 3, dtype=torch.int64, device=dev)
+    eager, used_long = [], []
+    for _ in range(n):
+        h = st.step(st.embed_token(tok))
+        used_long.append(st._long_ctx)
+        st.advance()
+        tok = st.head(h).reshape(-1)[:1].clone()
+        eager.append(int(tok.item()))
+    assert used_long == [i + 1 > 128 for i in range(n)]            # the split launch really ran from the 129th key on
+    st2 = mk().capture()
+    assert st2._graph_long is not None
+    tok = torch.full((1,), 3, dtype=torch.int64, device=dev)
+    staged = []
+    for _ in range(n):
+        h = st2.step_graph(st2.embed_token(tok))
+        tok = st2.head(h).reshape(-1)[:1].clone()
+        staged.append(int(tok.item()))
+    st3 = mk()
+    tbuf = torch.zeros(1, dtype=torch.int64, device=dev)
+    st3.capture_token_loop(tbuf)
+    assert st3._tgraph_long is not None
+    st3.reset()
+    looped = st3.decode_tokens(tbuf, 3, n)
+    first_bad = next((i for i, (a, b, c) in enumerate(zip(eager, staged, looped)) if not a == b == c), None)
+    assert first_bad is None, (first_bad, eager[first_bad], staged[first_bad], looped[first_bad])
+    assert len(set(eager)) > 1 and int(st3.pos.item()) == n
+    assert int(st3._attn_ws[:1024].view(torch.int32).abs().sum().item()) == 0      # arrival counters left zeroed
 
 
 def test_g5_decoder_block_fwd_bwd(dev, g5):
