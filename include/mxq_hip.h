@@ -343,13 +343,15 @@ int mxq_gemv_awq_f16(const void* x, const void* kernel, const void* scales, cons
  * gemm_cuda_gen.cu:424-478; nibble order dequantize.cuh:35-51) -- declared by the reference, never compiled into its module
  * (setup.py:37-41).  x f16[M, IC]; kernel i32[IC, OC/8] (a word = the 4-bit codes of 8 consecutive output channels at one
  * input channel, channel e in nibble (0, 4, 1, 5, 2, 6, 3, 7)[e]); scales f16[IC/G, OC]; zeros i32[IC/G, OC/8] (packed like
- * the codes); weight = fp16(fp16(q - z) * s) as the reference computes it (gemm_cuda_gen.cu:134-141), fp32 accumulation.
- * split_k == 1: y f16[M, OC].  split_k > 1 (the launcher's split_k_iters): slice j takes the 64-deep K-steps j, j + split_k,
- * ... and y is f32[split_k, M, OC] -- the caller adds the slices, as the reference's wrapper does (`_out_feats.sum(0)`,
- * gemm_cuda_gen.cu:477; fp32 partials here, fp16 there).  MXQ_E_SHAPE for the launcher's rejections (OC % 64, group_size
- * % 32, OC % group_size) and for IC % 64, IC % group_size, split_k outside [1, IC/64]. */
+ * the codes); weight = fp16(fp16(q - z) * s) as the reference computes it (gemm_cuda_gen.cu:134-141), fp32 accumulation;
+ * y f16[M, OC].  Runs on the fused prefill kernel's skeleton with dequant waves for this operand format (csrc/gemm8a.hip,
+ * gemm8aq.hip).  The reference launcher's split_k_iters is a SCHEDULE (K slices summed by the caller), not part of the
+ * operator: this entry schedules K itself -- up to 192 tokens 64-token tiles whose K range is cut into slices + a combine
+ * launch, beyond that 256-token tiles with a stream-K tail -- through `workspace` (mxq_gemm_workspace_bytes() bytes, 16-byte
+ * aligned, counter head zeroed as for mxq_linear_f16_ws; NULL: whole tiles only).  Deterministic.  MXQ_E_SHAPE for the
+ * launcher's rejections (OC % 64, group_size % 32, OC % group_size) and for IC % 64, IC % group_size. */
 int mxq_gemm_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
-                     int group_size, int split_k, void* stream);
+                     int group_size, void* workspace, size_t workspace_bytes, void* stream);
 
 /* gemv_mxq_forward_cuda(in_feats, kernel, kernel_last, zeros_and_scales, scales_2nd,
  * zeros_2nd, scales_4b, zeros_4b, group_size) (gemv_mxq_cuda.h:4-12; operand layout

@@ -78,7 +78,7 @@ SIGNATURES = {
     "mxq_fakequant_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mxq_fakequant_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
     "mxq_gemv_awq_f16": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p]),
-    "mxq_gemm_awq_f16": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mxq_gemm_awq_f16": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "mxq_gemv_proto_f16": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_void_p]),
 }
 

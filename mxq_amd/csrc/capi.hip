@@ -602,14 +602,21 @@ int mxq_gemv_awq_f16(const void* x, const void* kernel, const void* scales, cons
 }
 
 int mxq_gemm_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
-                     int group_size, int split_k, void* stream) {
+                     int group_size, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !kernel || !scales || !zeros || !y) return MXQ_E_NULL;
     // the reference launcher's checks (gemm_cuda_gen.cu:447-454) + this kernel's 64-deep K-step
     if (M <= 0 || IC <= 0 || OC <= 0 || OC % 64 != 0 || OC % 8 != 0) return MXQ_E_SHAPE;
     if (group_size <= 0 || group_size % 32 != 0 || OC % group_size != 0) return MXQ_E_SHAPE;
-    if (IC % 64 != 0 || IC % group_size != 0 || split_k < 1 || split_k > IC / 64) return MXQ_E_SHAPE;
+    if (IC % 64 != 0 || IC % group_size != 0) return MXQ_E_SHAPE;
     if (!aligned16(x) || !aligned16(scales) || !aligned16(y) || ((uintptr_t)kernel & 3) || ((uintptr_t)zeros & 3)) return MXQ_E_ALIGN;
-    return mxq_launch_gemm_awq_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, split_k, (hipStream_t)stream);
+    if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
+    if (workspace && workspace_bytes < 65536) return MXQ_E_SHAPE;
+    // Few tokens: 64-token tiles, each tile's K range cut so that tiles x slices fill the chip, partial tiles summed by a combine
+    // launch (needs the workspace; without one: whole tiles).  Beyond: 256-token tiles, persistent, stream-K tail.
+    if (M <= 192)
+        return mxq_launch_gemm8aq_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, workspace, workspace_bytes,
+                                      workspace ? -1 : 0, (hipStream_t)stream);
+    return mxq_launch_gemm8a_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, workspace, workspace_bytes, 0, (hipStream_t)stream);
 }
 
 int mxq_gemv_proto_f16(const void* x, const void* weight, const void* weight_last, const void* zeros_and_scales,

@@ -69,7 +69,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef MXQ_G8_BN
 #define MXQ_G8_BN 128
 #endif
-#if MXQ_G8_BM == 256
+// MXQ_G8_AWQ (gemm8a.hip, gemm8aq.hip): the same kernel with dequant waves for the OPERANDS of the reference's
+// gemm_forward_cuda (K-major 4-bit words, group-wise fp16 scales, packed integer zero-points: "AWQ layout" below) instead of
+// the MXQ block formats -- one more build of this file, whose kernels take three more arguments.
+#if defined(MXQ_G8_AWQ) && MXQ_G8_BM == 256
+#define G8_NAME(stem) mxq_##stem##gemm8a
+#elif defined(MXQ_G8_AWQ) && MXQ_G8_BM == 128
+#define G8_NAME(stem) mxq_##stem##gemm8ah
+#elif defined(MXQ_G8_AWQ)
+#define G8_NAME(stem) mxq_##stem##gemm8aq
+#elif MXQ_G8_BM == 256
 #define G8_NAME(stem) mxq_##stem##gemm8
 #elif MXQ_G8_BM == 128 && MXQ_G8_BN == 128
 #define G8_NAME(stem) mxq_##stem##gemm8h
@@ -111,10 +120,49 @@ constexpr int OFF_A = 0;
 constexpr int OFF_W = OFF_A + A_SLOTS * A_STAGE;
 // hoisted-dequant mode: a 3-slot ring of fp16 weight tiles in the place of the W16 double buffer
 constexpr int OFF_WD = OFF_W, WD_SLOTS = 3;
+#if defined(MXQ_G8_AWQ) && MXQ_G8_BM == 256
+// AWQ layout, 256-token build: the K-major code words reach the dequant waves through LDS -- one 1-KiB LDS-DMA per dequant wave
+// and K-step brings the step's 64 rows x 64 bytes in whole row segments, the threads then read their 8 words (k = 8 ko ..
+// 8 ko + 7 of one channel octet) with ds_read_b32.  (The same words fetched straight into registers, 8 row-strided dword
+// loads per thread and K-step: 91 us at 2048 x 4096^2 against 65 with the loads switched off -- each wave instruction
+// touched 8 rows x 16 bytes.)  A ring of one group (DEQ_R chunks) of 4-KiB slots behind the weight-tile buffers.
+#define MXQ_AWQ_RAW 1
+constexpr int OFF_RAW = OFF_WD + WD_SLOTS * W_STAGE, RAW_SLOT = 4096;
+constexpr int SMEM_BYTES = OFF_RAW + (MXQ_G8_BM == 256 ? 3 : 1) * RAW_SLOT;
+#else
 constexpr int SMEM_BYTES = OFF_WD + WD_SLOTS * W_STAGE;
+#endif
 static_assert(OFF_W + 2 * W_STAGE <= SMEM_BYTES && SMEM_BYTES <= 160 * 1024, "LDS budget");
 static_assert(N_MMA * WSLOT <= SMEM_BYTES, "the stream-K owner stages a wave's share of a slot per MFMA wave in the idle rings");
 constexpr int LAYOUT_DENSE16 = 100;   // internal: qweight is a dense fp16 [N, K] matrix (never part of the C ABI)
+constexpr int LAYOUT_AWQ = 101;       // internal (MXQ_G8_AWQ builds): qweight = int32 [K, N / 8] words of gemm_forward_cuda
+#ifdef MXQ_G8_AWQ
+static_assert(MXQ_G8_BN == 128, "the AWQ dequant waves cover 16 channel octets");
+// the rest of gemm_forward_cuda's operands (mxq_quant/cuda_kernel/csrc/quantization/gemm_cuda.h:3-4): passed by value
+struct AwqOps {
+    const uint16_t* scales;   // fp16 [K / G, N]
+    const uint32_t* zeros;    // int32 [K / G, N / 8], nibble order of the code words
+    uint32_t gmul;            // floor(2^32 / G) + 1: k / G = mulhi(k, gmul) for every k < 2^20 (G < 2^12)
+    int groups;               // K / G
+};
+#define G8_AWQ_PARAM , AwqOps awq
+#define G8_AWQ_ARG , awq
+// the launch's uniform facts, built once from kernel arguments and handed down BY REFERENCE (never copied into the per-tile
+// Deq, never selected between tiles: descriptors that pass through a select live in VGPRs and every load through them
+// gets a waterfall loop -- and here the copies even went to scratch)
+struct AwqU {
+    __amdgpu_buffer_rsrc_t rs_q, rs_s, rs_z;   // code words [K, N / 8], scales [K / G, N], zeros [K / G, N / 8]: whole tensors
+    uint32_t gmul, row_bytes;                  // row_bytes = N / 2: one k row of code words = one group row of zeros
+    int last_kt;                               // K / 64 - 1
+};
+#define G8_AWQU_PARAM , const AwqU& au
+#define G8_AWQU_ARG , au
+#else
+#define G8_AWQ_PARAM
+#define G8_AWQ_ARG
+#define G8_AWQU_PARAM
+#define G8_AWQU_ARG
+#endif
 
 // profiling-only switches (template parameter ABL; the product library instantiates ABL = 0 only, and the stamp / ballast
 // code exists only under MXQ_PROFILING: libmxq_hip_prof.so)
@@ -726,6 +774,15 @@ struct Deq {
     int row, r, h;        // W row of this thread (0..127), its row inside the block, column half (wave-uniform)
     float s4, z4;
     float4 rm;            // the row's 4-bit-arm parameters as loaded (rowmeta)
+#ifdef MXQ_G8_AWQ
+    // AWQ layout: the thread converts (channel octet co, k octet ko) of the 64 x 128 weight tile for DEQ_NRES channels of the
+    // octet (convert_pk: which ones).
+    // voff_blk = byte offset of word (k = 8 ko, column n0 / 8 + co) from row k = 0; k0 = the segment's first K-STEP.
+    uint32_t zoff, soff;  // byte offsets of the thread's zero word / first scale pair inside a group's row
+    uint32_t raw_voff;    // LDS-staged words (MXQ_AWQ_RAW): byte offset of the 16 bytes this lane's DMA fetches, from row k = 0
+    uint32_t raw_rd;      // ... and of the thread's word of row k = 8 ko inside a ring slot
+    int co, ko, sh;       // sh = X * 0x00010001: added to the v_perm selectors that pick the thread's byte X of a word
+#endif
 };
 
 __device__ __forceinline__ void put8(char* wt, int row, int slot, const uint32_t* o) {
@@ -743,10 +800,17 @@ struct Pk {
 struct Pk4 {          // W4ROW: code words only (scale / zero come from rowmeta)
     uint32_t c[4];
 };
+struct PkA {          // AWQ layout: 8 code words (k = 8 ko .. 8 ko + 7 of one channel octet), its group's zero word and scale pairs
+    uint32_t q[8];
+    uint32_t z;
+    uint32_t s[2];    // scale dwords: channels (c0, c0 + 1) and (c0 + 2, c0 + 3) of the thread's first channel c0
+};
 template <int LAYOUT>
 struct PkOf { typedef Pk type; };
 template <>
 struct PkOf<MXQ_LAYOUT_W4ROW> { typedef Pk4 type; };
+template <>
+struct PkOf<LAYOUT_AWQ> { typedef PkA type; };
 
 // They come STRAIGHT from global memory into registers, three K-steps before they are used (6-7 dword loads per
 // thread and chunk through the tile's buffer descriptor; 16 lanes of a row-block read 64 consecutive bytes).  Round 2
@@ -754,7 +818,31 @@ struct PkOf<MXQ_LAYOUT_W4ROW> { typedef Pk4 type; };
 // step cost their issuer 100-185 cycles apiece next to MFMAs, on the one wave per SIMD whose ~90-op chain is the
 // critical path of a K-step (-2..4 % per launch without them; bit-identical results).
 template <int LAYOUT, int H, bool NOQ4 = false, int PARTS = DEQ_PARTS>   // (PARTS a parameter: the other mode's branches are not instantiated)
-__device__ __forceinline__ void load_pk(const Deq& c, int t, typename PkOf<LAYOUT>::type& k) {
+__device__ __forceinline__ void load_pk(const Deq& c, int t, typename PkOf<LAYOUT>::type& k G8_AWQU_PARAM) {
+#ifdef MXQ_G8_AWQ
+    if constexpr (LAYOUT == LAYOUT_AWQ) {
+        // K-step c.k0 + t, clamped to the tensor (a burst loads whole groups of R chunks: the ones past the segment's end are
+        // never written to LDS, but their loads must stay inside the allocation -- the K offset rides in the scalar offset,
+        // which a raw buffer does not range-check)
+        int kt = __builtin_amdgcn_readfirstlane((int)c.k0 + t);
+        kt = kt < au.last_kt ? kt : au.last_kt;
+        const uint32_t kbase = (uint32_t)kt * BK;
+        const uint32_t so = kbase * au.row_bytes;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            k.q[i] = __builtin_amdgcn_raw_buffer_load_b32(au.rs_q, c.voff_blk, so + (uint32_t)i * au.row_bytes, 0);
+        const uint32_t g = __umulhi(kbase + 8u * (uint32_t)c.ko, au.gmul);          // group of this thread's k octet
+        k.z = __builtin_amdgcn_raw_buffer_load_b32(au.rs_z, c.zoff + g * au.row_bytes, 0, 0);
+        if constexpr (DEQ_NRES == 2) {   // channels c0 and c0 + 2: c0 may be odd -- halfword loads (a dword load would be misaligned)
+            k.s[0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(au.rs_s, c.soff + g * (4u * au.row_bytes), 0, 0);
+            k.s[1] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(au.rs_s, c.soff + g * (4u * au.row_bytes) + 4u, 0, 0);
+        } else {
+            k.s[0] = __builtin_amdgcn_raw_buffer_load_b32(au.rs_s, c.soff + g * (4u * au.row_bytes), 0, 0);
+            k.s[1] = __builtin_amdgcn_raw_buffer_load_b32(au.rs_s, c.soff + g * (4u * au.row_bytes) + 4u, 0, 0);
+        }
+        return;
+    } else {
+#endif
     constexpr int BYTES = LAYOUT == MXQ_LAYOUT_W4ROW ? 512 : LAYOUT == MXQ_LAYOUT_MIXEDC ? MXQC_BLK_BYTES : MXQ_BLK_BYTES;
     // wave-uniform by construction; said explicitly, or a K offset selected between two tiles' descriptors counts as
     // divergent and every load below gets a waterfall loop around it
@@ -806,6 +894,9 @@ __device__ __forceinline__ void load_pk(const Deq& c, int t, typename PkOf<LAYOU
         k.c[3] = dw(mxq_c4(1, c.r));
     }
     }
+#ifdef MXQ_G8_AWQ
+    }
+#endif
 }
 
 template <int LAYOUT>
@@ -820,6 +911,63 @@ __device__ __forceinline__ void widen_pk(typename PkOf<LAYOUT>::type& k) {   // 
 // chunk's packed words -> the thread's 32 fp16 weights (4 x 16 bytes: W16 slots s0 .. s0+3 of its row)
 template <int LAYOUT, int H, bool NOQ4 = false, int PARTS = DEQ_PARTS>
 __device__ __forceinline__ void convert_pk(const Deq& c, const typename PkOf<LAYOUT>::type& k, u32x4 (&res)[8 / PARTS]) {
+#ifdef MXQ_G8_AWQ
+    if constexpr (LAYOUT == LAYOUT_AWQ) {
+        // The reference's arithmetic (dequantize.cuh:15-78, gemm_cuda_gen.cu:134-141) in packed fp16 -- a 4-bit field OR-ed into
+        // 0x6400 reads 1024 + q (low nibble of a byte) or 1024 + 16 q (high nibble); (1024 + q) - (1024 + z) and
+        // (1024 + 16 q) / 16 - (64 + z) are both q - z EXACTLY, and the product with the scale is rounded ONCE -- but packed
+        // over TWO CONSECUTIVE k OF ONE CHANNEL instead of the reference's two channels at one k: one v_perm_b32 puts the
+        // byte that holds a channel's nibble in words k and k + 1 side by side, the masked result IS the output dword, and the
+        // K-major -> [channel][8 k] transpose costs nothing further.  A word's byte b holds channels (0,2 | 4,6 | 1,3 | 5,7)[b] in
+        // its (low, high) nibbles (dequantize.cuh:35-51); the thread's bytes are a per-lane v_perm selector (c.sh), not a code path.
+        // 4 channels per thread: bytes (hq, 2 + hq) -> channels 4 hq + (0, 1, 2, 3) = (X.lo, Y.lo, X.hi, Y.hi);
+        // 2 channels per thread: byte hq -> channels (c0, c0 + 2) = (X.lo, X.hi).
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        constexpr uint32_t LO = 0x000f000fu, HI = 0x00f000f0u;
+        // (x & mask) | 0x64006400 as ONE v_and_or_b32: a VOP3 instruction takes no literal on gfx9, and left to itself the
+        // compiler emits v_and_b32 + v_or_b32 with a literal each -- 40 extra VALU ops per chunk on the critical wave.  The
+        // mask rides in an SGPR, the magic constant in a VGPR.
+        uint32_t magic;
+        asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+        auto and_or = [&](uint32_t x, uint32_t mask) {
+            uint32_t r;
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(magic));
+            return r;
+        };
+        constexpr int NB = DEQ_NRES / 2;                       // bytes per thread: 2 (X, Y) or 1 (X)
+        const h2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f}, zero2 = {(_Float16)0.f, (_Float16)0.f};
+        const uint32_t selx = 0x0c040c00u + (uint32_t)c.sh;    // [lo.byte X, 0, hi.byte X, 0]; c.sh = X * 0x00010001
+        h2 zlo[NB], zhi[NB], slo[NB], shi[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const uint32_t zz = __builtin_amdgcn_perm(k.z, k.z, selx - 0x00040000u + 0x00020002u * b);       // [z.byte, 0, z.byte, 0]
+            zlo[b] = __builtin_bit_cast(h2, and_or(zz, LO));                                           // 1024 + z
+            zhi[b] = __builtin_elementwise_fma(__builtin_bit_cast(h2, and_or(zz, HI)), sixteenth, zero2);   // 64 + z, exact
+        }
+        if constexpr (NB == 2) {
+            slo[0] = __builtin_bit_cast(h2, __builtin_amdgcn_perm(k.s[0], k.s[0], 0x01000100u));   // channel c0 (X.lo)
+            slo[1] = __builtin_bit_cast(h2, __builtin_amdgcn_perm(k.s[0], k.s[0], 0x03020302u));   // c0 + 1 (Y.lo)
+            shi[0] = __builtin_bit_cast(h2, __builtin_amdgcn_perm(k.s[1], k.s[1], 0x01000100u));   // c0 + 2 (X.hi)
+            shi[1] = __builtin_bit_cast(h2, __builtin_amdgcn_perm(k.s[1], k.s[1], 0x03020302u));   // c0 + 3 (Y.hi)
+        } else {
+            slo[0] = __builtin_bit_cast(h2, __builtin_amdgcn_perm(k.s[0], k.s[0], 0x01000100u));   // channel c0 (X.lo)
+            shi[0] = __builtin_bit_cast(h2, __builtin_amdgcn_perm(k.s[1], k.s[1], 0x01000100u));   // c0 + 2 (X.hi)
+        }
+        uint32_t o[DEQ_NRES][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const uint32_t xx = __builtin_amdgcn_perm(k.q[2 * m + 1], k.q[2 * m], selx + 0x00020002u * b);
+                const h2 ql = __builtin_bit_cast(h2, and_or(xx, LO)), qh = __builtin_bit_cast(h2, and_or(xx, HI));
+                o[b][m] = __builtin_bit_cast(uint32_t, (ql - zlo[b]) * slo[b]);
+                o[NB + b][m] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(qh, sixteenth, -zhi[b]) * shi[b]);
+            }
+#pragma unroll
+        for (int i = 0; i < DEQ_NRES; ++i) res[i] = (u32x4){o[i][0], o[i][1], o[i][2], o[i][3]};
+        return;
+    } else {
+#endif
     uint32_t o[8];
     if constexpr (PARTS == 4) {
         constexpr bool MIXED = LAYOUT == MXQ_LAYOUT_MIXED || LAYOUT == MXQ_LAYOUT_MIXEDC;
@@ -858,11 +1006,21 @@ __device__ __forceinline__ void convert_pk(const Deq& c, const typename PkOf<LAY
         res[2] = (u32x4){o[0], o[1], o[2], o[3]};
         res[3] = (u32x4){o[4], o[5], o[6], o[7]};
     }
+#ifdef MXQ_G8_AWQ
+    }
+#endif
 }
 // ... into W16[t & 1]: the thread's column half H = slots 4 H .. 4 H + 3
-template <int H>
+template <int H, int LAYOUT = MXQ_LAYOUT_MIXED>
 __device__ __forceinline__ void store_pk(const Deq& c, int t, const u32x4 (&res)[DEQ_NRES]) {
     char* wt = c.smem + OFF_W + (t & 1) * W_STAGE;
+#ifdef MXQ_G8_AWQ
+    if constexpr (LAYOUT == LAYOUT_AWQ) {     // c.row = the thread's first channel; its k octet is 16-byte slot ko of each row
+#pragma unroll
+        for (int i = 0; i < DEQ_NRES; ++i) *(u32x4*)(wt + swz(c.row + (DEQ_NRES == 2 ? 2 * i : i), c.ko)) = res[i];
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < DEQ_NRES; ++i) *(u32x4*)(wt + swz(c.row, H * DEQ_NRES + i)) = res[i];
 }
@@ -876,6 +1034,42 @@ __device__ __forceinline__ void deq_setup(Deq& c, char* smem, int wave, int lane
     c.d = wave - N_MMA;
     c.lane = lane;
     c.NT = nsteps;
+#ifdef MXQ_G8_AWQ
+    if constexpr (LAYOUT == LAYOUT_AWQ) {
+        // thread -> (k octet ko = low 3 lane bits: the 8 lanes of one 16-byte-store group write 8 different slots of rows with
+        // equal n & 7, i.e. 8 different bank groups; pair group hq; channel octet co)
+        constexpr int TPB = N_DEQ / 2;                         // threads per (co, ko) block: 2 (4 channels each) or 4 (2 each)
+        const int dt = c.d * 64 + lane;
+        c.ko = dt & 7;
+        const int hq = (dt >> 3) & (TPB - 1);                  // = the word byte X the thread's channels sit in
+        c.co = dt / (8 * TPB);
+        c.sh = hq * 0x00010001;
+        const int c0 = TPB == 2 ? 4 * hq : (hq & 1) * 4 + (hq >> 1);   // the thread's first channel inside the octet
+        c.h = 0;
+        c.row = 8 * c.co + c0;
+        c.r = 0;
+        c.rsrc = make_rsrc(qweight, 0u);       // (the MXQ layouts' fields: defined, so that copies of a Deq stay in registers)
+        c.s4 = c.z4 = 0.f;
+        c.rm = float4{0.f, 0.f, 0.f, 0.f};
+        const uint32_t row_bytes = (uint32_t)N / 2u;
+        const int OC8 = N >> 3;
+        int col = (n0 >> 3) + c.co;
+        col = col < OC8 ? col : OC8 - 1;       // (a tile past the last channel re-reads the last octet; never stored)
+        c.voff_blk = (uint32_t)(8 * c.ko) * row_bytes + (uint32_t)col * 4u;
+        {   // DMA lane L of dequant wave d fetches chunk (row 8 ko' + i', column quad q') into slot position (i' 32 + q' 8 + ko') * 16:
+            // for a fixed row-in-octet and quad, the 8 k octets sit in 8 different 16-byte bank groups
+            const int kd = lane & 7, qd = (lane >> 3) & 3, id = 2 * c.d + (lane >> 5);
+            int o0 = (n0 >> 3) + 4 * qd;
+            o0 = o0 < OC8 - 4 ? o0 : OC8 - 4;  // (a quad past the last channel re-reads the last one: in bounds, never stored)
+            c.raw_voff = (uint32_t)(8 * kd + id) * row_bytes + (uint32_t)o0 * 4u;
+            c.raw_rd = (uint32_t)((c.co >> 2) * 128 + c.ko * 16 + (c.co & 3) * 4);
+        }
+        c.zoff = (uint32_t)col * 4u;
+        c.soff = (uint32_t)col * 16u + (uint32_t)c0 * 2u;
+        c.k0 = (uint32_t)kt0;
+        return;
+    }
+#endif
     const uint32_t blk_stride = (uint32_t)NT_tile * BLK_B;   // bytes between consecutive row-blocks
     c.rsrc = make_rsrc(qweight, (uint32_t)(N >> 4) * blk_stride);
     c.k0 = (uint32_t)kt0 * BLK_B;
@@ -889,6 +1083,9 @@ __device__ __forceinline__ void deq_none(Deq& c, const Deq& like) {   // a descr
     c = like;
     c.voff_blk = 0x80000000u;
     c.k0 = 0;
+#ifdef MXQ_G8_AWQ
+    c.zoff = c.soff = c.raw_voff = 0x80000000u;
+#endif
 }
 
 // One segment on the dequant waves, R chunks at a time ("group").  A BURST waits for the group's R register sets
@@ -902,7 +1099,7 @@ __device__ __forceinline__ void deq_none(Deq& c, const Deq& like) {   // a descr
 // pre: the sets already hold / are loading chunks 0 .. R-1 (issued by the previous tile's last burst).
 template <int ABL, int LAYOUT, int H, int R>
 __device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const float4* __restrict__ rowmeta, int N, int n0,
-                                              bool pre, typename PkOf<LAYOUT>::type (&S)[R]) {
+                                              bool pre, typename PkOf<LAYOUT>::type (&S)[R] G8_AWQU_PARAM) {
     const int NT = c.NT;
     u32x4 res[R][DEQ_NRES];
     auto load_group = [&](int base) {          // chunks base .. base+R-1 of this segment, or group 0 of nxt past its end
@@ -911,17 +1108,23 @@ __device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const floa
         Deq d = c;
         d.voff_blk = over ? nxt.voff_blk : c.voff_blk;
         d.k0 = over ? nxt.k0 : c.k0;
+#ifdef MXQ_G8_AWQ
+        d.zoff = over ? nxt.zoff : c.zoff;
+        d.soff = over ? nxt.soff : c.soff;
+#endif
         const int b0 = over ? 0 : base;
 #pragma unroll
-        for (int i = 0; i < R; ++i) load_pk<LAYOUT, H, (ABL & ABL_NO_Q4) != 0>(d, b0 + i, S[i]);
+        for (int i = 0; i < R; ++i) load_pk<LAYOUT, H, (ABL & ABL_NO_Q4) != 0>(d, b0 + i, S[i] G8_AWQU_ARG);
     };
     auto burst = [&](int base) {               // convert the loaded group, then fetch the one after it
         if constexpr (!(ABL & ABL_NO_DEQ)) {
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                if ((ABL & ABL_THIRD_DEQ) != 0 && i > 0 && base > 0) {   // (the first burst converts all three: real weights stay in res)
-                    asm volatile("" ::"v"(S[i].c[0]), "v"(S[i].c[1]));
-                    continue;
+                if constexpr ((ABL & ABL_THIRD_DEQ) != 0 && LAYOUT != LAYOUT_AWQ) {
+                    if (i > 0 && base > 0) {   // (the first burst converts all three: real weights stay in res)
+                        asm volatile("" ::"v"(S[i].c[0]), "v"(S[i].c[1]));
+                        continue;
+                    }
                 }
                 widen_pk<LAYOUT>(S[i]);
                 convert_pk<LAYOUT, H, (ABL & ABL_NO_Q4) != 0>(c, S[i], res[i]);
@@ -930,17 +1133,21 @@ __device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const floa
         load_group(base + R);
     };
     auto put = [&](int q, const u32x4 (&r4)[DEQ_NRES]) {   // chunk q -> W16[q & 1], then the step's barrier
-        if constexpr (!(ABL & ABL_NO_DEQ)) store_pk<H>(c, q, r4);
+        if constexpr (!(ABL & ABL_NO_DEQ)) store_pk<H, LAYOUT>(c, q, r4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
     if (!pre) load_group(0);
-    int gn = n0 + c.row;
-    gn = gn < N ? gn : N - 1;
-    c.rm = rowmeta[gn];
+    if constexpr (LAYOUT != LAYOUT_AWQ) {      // (the AWQ layout has no per-row metadata)
+        int gn = n0 + c.row;
+        gn = gn < N ? gn : N - 1;
+        c.rm = rowmeta[gn];
+    }
     __builtin_amdgcn_s_barrier();              // prologue barrier 1 (the MFMA waves' x tile 0 has landed)
-    c.s4 = mxq_scale(c.rm.z, c.rm.w, (uint32_t)c.rm.y);
-    c.z4 = c.rm.x;
+    if constexpr (LAYOUT != LAYOUT_AWQ) {
+        c.s4 = mxq_scale(c.rm.z, c.rm.w, (uint32_t)c.rm.y);
+        c.z4 = c.rm.x;
+    }
     burst(0);
     put(0, res[0]);                            // prologue barrier 2: W16(0) written
     // step t = q - 1 writes chunk q; the segment's last step (t = NT - 1) writes nothing
@@ -956,6 +1163,67 @@ __device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const floa
     __builtin_amdgcn_s_barrier();              // step NT - 1
 }
 
+#ifdef MXQ_AWQ_RAW
+// deq_segment_h's twin for the AWQ layout with LDS-staged code words -- the same bursts, the same barriers (prologue 1 and 2,
+// one per K-step).  A group's words are fetched by DMA right AFTER the barrier that follows the previous burst (every wave has
+// finished reading the ring by then), land under the group's remaining steps, and are waited for (vmcnt(0), each wave its
+// own) in front of the barrier that precedes the burst that reads them.  After the segment's last group: group 0 of `nxt`.
+template <int ABL, int R>
+__device__ __forceinline__ void awq_segment_raw(Deq& c, const Deq& nxt, bool pre, PkA (&S)[R], const AwqU& au) {
+    const int NT = c.NT;
+    u32x4 res[R][DEQ_NRES];
+    char* raw = c.smem + OFF_RAW;
+    auto issue_group = [&](int base) {
+        const bool over = base >= NT;
+        const uint32_t rv = over ? nxt.raw_voff : c.raw_voff, zo = over ? nxt.zoff : c.zoff, sof = over ? nxt.soff : c.soff;
+        const int k0 = (int)(over ? nxt.k0 : c.k0) + (over ? 0 : base);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            int kt = __builtin_amdgcn_readfirstlane(k0 + i);
+            kt = kt < au.last_kt ? kt : au.last_kt;           // (chunks past the segment's end: in bounds, never converted into use)
+            const uint32_t kbase = (uint32_t)kt * BK;
+            bufdma16(au.rs_q, rv, kbase * au.row_bytes, raw + i * RAW_SLOT + c.d * 1024);
+            const uint32_t g = __umulhi(kbase + 8u * (uint32_t)c.ko, au.gmul);
+            S[i].z = __builtin_amdgcn_raw_buffer_load_b32(au.rs_z, zo + g * au.row_bytes, 0, 0);
+            S[i].s[0] = __builtin_amdgcn_raw_buffer_load_b32(au.rs_s, sof + g * (4u * au.row_bytes), 0, 0);
+            S[i].s[1] = __builtin_amdgcn_raw_buffer_load_b32(au.rs_s, sof + g * (4u * au.row_bytes) + 4u, 0, 0);
+        }
+    };
+    auto burst = [&]() {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const char* w = raw + i * RAW_SLOT + c.raw_rd;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) S[i].q[j] = *(const uint32_t*)(w + j * 512);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) convert_pk<LAYOUT_AWQ, 0, false>(c, S[i], res[i]);
+    };
+    auto put = [&](int q, const u32x4 (&r4)[DEQ_NRES], bool drain) {
+        store_pk<0, LAYOUT_AWQ>(c, q, r4);
+        if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    if (!pre) issue_group(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // prologue barrier 1: every wave's part of group 0 is in the ring
+    burst();
+    put(0, res[0], false);                     // prologue barrier 2: W16(0) written; the ring has been read
+    for (int base = 0; base < NT; base += R) {
+        issue_group(base + R);
+#pragma unroll
+        for (int i = 1; i < R; ++i)
+            if (base + i < NT) put(base + i, res[i], i == R - 1);
+        if (base + R < NT) {
+            burst();
+            put(base + R, res[0], false);
+        }
+    }
+    __builtin_amdgcn_s_barrier();              // step NT - 1
+}
+#endif
+
 // the column half a dequant wave works on is wave-uniform but not a constant: dispatch once, outside the loops
 #ifndef MXQ_DEQ_R
 #define MXQ_DEQ_R (MXQ_G8_BM == 256 ? 3 : 1)
@@ -963,15 +1231,21 @@ __device__ __forceinline__ void deq_segment_h(Deq& c, const Deq& nxt, const floa
 constexpr int DEQ_R = MXQ_DEQ_R;    // measured: R = 2 -5 %, 3 and 4 +2 % over per-step dequant; R = 4 spills at the 168-VGPR cap
 template <int ABL, int LAYOUT>
 __device__ __forceinline__ void deq_segment(Deq& c, const Deq& nxt, int wave, int lane, const float4* __restrict__ rowmeta,
-                                            int N, int n0, bool pre, typename PkOf<LAYOUT>::type (&S)[DEQ_R]) {
-    if constexpr (DEQ_PARTS == 4) {
-        if (c.h == 0) deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
-        else if (c.h == 1) deq_segment_h<ABL, LAYOUT, 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
-        else if (c.h == 2) deq_segment_h<ABL, LAYOUT, 2, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
-        else deq_segment_h<ABL, LAYOUT, DEQ_PARTS - 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+                                            int N, int n0, bool pre, typename PkOf<LAYOUT>::type (&S)[DEQ_R] G8_AWQU_PARAM) {
+    if constexpr (LAYOUT == LAYOUT_AWQ) {      // (which channels a thread converts is a per-lane selector, not a code path)
+#ifdef MXQ_AWQ_RAW
+        awq_segment_raw<ABL, DEQ_R>(c, nxt, pre, S, au);
+#else
+        deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S G8_AWQU_ARG);
+#endif
+    } else if constexpr (DEQ_PARTS == 4) {
+        if (c.h == 0) deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S G8_AWQU_ARG);
+        else if (c.h == 1) deq_segment_h<ABL, LAYOUT, 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S G8_AWQU_ARG);
+        else if (c.h == 2) deq_segment_h<ABL, LAYOUT, 2, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S G8_AWQU_ARG);
+        else deq_segment_h<ABL, LAYOUT, DEQ_PARTS - 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S G8_AWQU_ARG);
     } else {
-        if (c.h == 0) deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
-        else deq_segment_h<ABL, LAYOUT, 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S);
+        if (c.h == 0) deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S G8_AWQU_ARG);
+        else deq_segment_h<ABL, LAYOUT, 1, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S G8_AWQU_ARG);
     }
 }
 
@@ -1046,7 +1320,7 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
                                                                uint16_t* __restrict__ y, int M, int N, int K,
                                                                int tiles_m, int tiles_n, int dp_tiles, int dp_grid,
                                                                int tail, int units, float* __restrict__ ws,
-                                                               int* __restrict__ cnt) {
+                                                               int* __restrict__ cnt G8_AWQ_PARAM) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NT = K / BK;
@@ -1220,6 +1494,10 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
         int ln;
         MXQ_LANE_ID(ln);
         Deq cur, nxt;
+#ifdef MXQ_G8_AWQ
+        const AwqU au = {make_rsrc(qweight, (uint32_t)K * (uint32_t)(N >> 1)), make_rsrc(awq.scales, (uint32_t)awq.groups * (uint32_t)N * 2u),
+                         make_rsrc(awq.zeros, (uint32_t)awq.groups * (uint32_t)(N >> 1)), awq.gmul, (uint32_t)N >> 1, K / BK - 1};
+#endif
         bool pre = false;                  // a segment's last burst loads the next segment's first group
         auto piece_deq = [&](int j, Deq& d, int& n0) {
             int pos, end, tm, tn;
@@ -1245,7 +1523,7 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
                 } else {
                     deq_none(nxt, cur);
                 }
-                deq_segment<ABL, LAYOUT>(cur, nxt, wave, ln, rowmeta, N, n0, pre, S);
+                deq_segment<ABL, LAYOUT>(cur, nxt, wave, ln, rowmeta, N, n0, pre, S G8_AWQU_ARG);
                 pre = true;
                 cur = nxt;
             }
@@ -1256,7 +1534,7 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
             const int n0 = n0_sk;
             if (j > j_lo) piece_deq(j - 1, nxt, n0_sk);
             else deq_none(nxt, cur);
-            deq_segment<ABL, LAYOUT>(cur, nxt, wave, ln, rowmeta, N, n0, pre, S);
+            deq_segment<ABL, LAYOUT>(cur, nxt, wave, ln, rowmeta, N, n0, pre, S G8_AWQU_ARG);
             pre = true;
             cur = nxt;
         }
@@ -1319,7 +1597,7 @@ constexpr size_t CNT_BYTES = 64 * 1024;   // K-step counters at the head of the 
 
 template <int ABL, int LAYOUT = MXQ_LAYOUT_MIXED>
 static int launch8(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                   void* workspace, size_t ws_bytes, bool force, hipStream_t stream) {
+                   void* workspace, size_t ws_bytes, bool force, hipStream_t stream G8_AWQ_PARAM) {
     // the DMA descriptors address one tile's rows with 32-bit offsets: 256 rows of x, 8 row-blocks of packed weights
     // 32-bit offsets: 256 rows of x per DMA descriptor; the whole packed weight behind one (offsets < 2^31)
     if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(N / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 31))
@@ -1368,7 +1646,7 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
     const int grid = tail && 8 * units > dp_grid ? 8 * units : dp_grid;
     G8_KERNEL<ABL, LAYOUT><<<grid, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n,
-        dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace);
+        dp_tiles, dp_grid, tail, units, (float*)((char*)workspace + CNT_BYTES), (int*)workspace G8_AWQ_ARG);
     return (int)hipGetLastError();
 }
 
@@ -1376,14 +1654,14 @@ static int launch8(const void* x, const void* qweight, const void* rowmeta, void
 // workspace beyond its counter head (untouched), a combine launch.  S = 1 (or no room): the ordinary whole-tile launch.
 template <int LAYOUT>
 static int launch8_slices(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
-                          void* workspace, size_t ws_bytes, int S, hipStream_t stream) {
+                          void* workspace, size_t ws_bytes, int S, hipStream_t stream G8_AWQ_PARAM) {
     const int NT = K / BK, tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
     if (S <= 0) S = cu_count() / tiles;               // (2-3 x as many slices, i.e. 2-3 workgroups per CU: no faster, profiles/r05_smalltile_slices.txt)
     if (S > NT / 4) S = NT / 4;                       // at least 4 K-steps per slice
     const size_t room = workspace && ws_bytes > CNT_BYTES ? (ws_bytes - CNT_BYTES) / ((size_t)tiles * BM * BN * sizeof(float)) : 0;
     if ((size_t)S > room) S = (int)room;
-    if (S <= 1) return launch8<0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream);
-    if (M <= 0 || N <= 0 || K < BK || K % BK != 0 || N % 16 != 0) return -1;
+    if (S <= 1) return launch8<0, LAYOUT>(x, qweight, rowmeta, y, M, N, K, nullptr, 0, false, stream G8_AWQ_ARG);
+    if (M <= 0 || N <= 0 || K < BK || K % BK != 0 || N % (LAYOUT == LAYOUT_AWQ ? 8 : 16) != 0) return -1;
     if ((int64_t)BM * K * 2 >= ((int64_t)1 << 32) || (int64_t)(N / 16) * (K / BK) * MXQ_BLK_BYTES >= ((int64_t)1 << 31))
         return -1;
     hipError_t e = mxq_set_dyn_lds_once<&G8_KERNEL<0, LAYOUT>>(SMEM_BYTES);
@@ -1391,13 +1669,33 @@ static int launch8_slices(const void* x, const void* qweight, const void* rowmet
     float* slab = (float*)((char*)workspace + CNT_BYTES);
     G8_KERNEL<0, LAYOUT><<<tiles * S, THREADS, SMEM_BYTES, stream>>>(
         (const uint16_t*)x, (const uint32_t*)qweight, (const float4*)rowmeta, (uint16_t*)y, M, N, K, tiles_m, tiles_n, 0, 0,
-        -S, 0, slab, nullptr);
+        -S, 0, slab, nullptr G8_AWQ_ARG);
     G8_SYM(, _combine_kernel)<<<(tiles * N_MMA * NJ + 3) / 4, 256, 0, stream>>>(slab, (uint16_t*)y, M, N, tiles_m, tiles_n, S);
     return (int)hipGetLastError();
 }
 
 }   // namespace
 
+#ifdef MXQ_G8_AWQ
+// gemm_forward_cuda's operands (gemm_cuda.h:3-4): x fp16 [M, IC], kernel int32 [IC, OC / 8], scales fp16 [IC / G, OC], zeros int32
+// [IC / G, OC / 8] -> y fp16 [M, OC].  slices = 0: whole tiles + stream-K tail (workspace: counter head + partial slots, nullable);
+// slices > 0 (or < 0: one workgroup per CU): every tile's K range cut that many ways + combine launch.
+size_t G8_SYM(, _workspace_bytes)() { return CNT_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
+int G8_SYM(launch_, _f16)(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
+                         int G, void* workspace, size_t ws_bytes, int slices, hipStream_t stream) {
+    if (M <= 0 || IC < BK || IC % BK != 0 || OC <= 0 || OC % 8 != 0 || G < 8 || G % 8 != 0 || IC % G != 0 || G >= 4096 || IC >= (1 << 20))
+        return -1;   // MXQ_E_SHAPE
+    if ((int64_t)IC * OC / 2 >= ((int64_t)1 << 31) || (int64_t)(IC / G) * OC * 2 >= ((int64_t)1 << 31)) return -1;
+    AwqOps awq;
+    awq.scales = (const uint16_t*)scales;
+    awq.zeros = (const uint32_t*)zeros;
+    awq.gmul = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)G) + 1u;
+    awq.groups = IC / G;
+    if (slices != 0)
+        return launch8_slices<LAYOUT_AWQ>(x, kernel, nullptr, y, M, OC, IC, workspace, ws_bytes, slices, stream, awq);
+    return launch8<0, LAYOUT_AWQ>(x, kernel, nullptr, y, M, OC, IC, workspace, ws_bytes, false, stream, awq);
+}
+#else
 int G8_SYM(launch_, _slices_f16)(const void* x, const void* qweight, const void* rowmeta, void* y, int M, int N, int K,
                                  int layout, void* workspace, size_t ws_bytes, int S, hipStream_t stream) {
     switch (layout) {
@@ -1434,7 +1732,9 @@ int G8_SYM(launch_, _dense_f16)(const void* x, const void* w16, void* y, int M, 
 }
 #endif
 
-#ifdef MXQ_PROFILING
+#endif   // !MXQ_G8_AWQ
+
+#if defined(MXQ_PROFILING) && !defined(MXQ_G8_AWQ)
 // Built only into libmxq_hip_prof.so (make prof; tools/): parts of the kernel removed to time the rest.
 // WRONG RESULTS by construction -- never part of libmxq_hip.so or of include/mxq_hip.h.
 // 1 = no x DMAs, 2 = no MFMA, 4 = no dequant, 256 = no output stores (sums)
@@ -1469,6 +1769,28 @@ extern "C" int G8_SYM(prof_, _ablate_f16)(const void* x, const void* qweight, co
 }
 
 #if MXQ_G8_BM == 256
+// An UNRELATED kernel that holds `lds_bytes` of LDS per workgroup for `usec` microseconds (100-MHz s_memrealtime; every wave
+// leaves when the time is up): tests/test_gpu_parity.py runs it on a second stream beside a stream-K launch, whose workgroups
+// (144 KB of LDS each) then cannot all be resident at once -- the launch must still come out right, status 0.
+__global__ void mxq_prof_occupy_kernel(unsigned long long ticks, int* sink) {
+    extern __shared__ int occ_lds[];
+    occ_lds[threadIdx.x] = (int)threadIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int acc = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+        acc += occ_lds[(threadIdx.x + acc) & 63];
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (acc == 0x7fffffff) *sink = acc;
+}
+extern "C" int mxq_prof_occupy(int grid, int lds_bytes, unsigned long long usec, void* sink, void* stream_) {
+    if (grid <= 0 || lds_bytes < 256 || lds_bytes > 160 * 1024 || usec > 50000) return -1;       // bounded: never a hang
+    hipError_t e = hipFuncSetAttribute((const void*)mxq_prof_occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    mxq_prof_occupy_kernel<<<grid, 64, lds_bytes, (hipStream_t)stream_>>>(usec * 100ull, (int*)sink);
+    return (int)hipGetLastError();
+}
 // the hoisted mode's MFMA kernel alone on an already dequantised fp16 weight (the dense yardstick of tools/ab_gemm.py)
 extern "C" int G8_SYM(prof_, _dense_f16)(const void* x, const void* w16, void* y, int M, int N, int K, void* stream_) {
     return launch8<0, LAYOUT_DENSE16>(x, w16, nullptr, y, M, N, K, nullptr, 0, false, (hipStream_t)stream_);

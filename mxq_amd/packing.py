@@ -121,8 +121,11 @@ def gemm_workspace(device: torch.device, counters: bool = True, stream: Optional
             key = (dev_index, "capture", cid, full)
     if ws is None:
         ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        box = torch.zeros(4, dtype=torch.int32).pin_memory()
-        _MAILBOX[key] = (box, box.numpy())
+        if not capturing:
+            # (eager workspaces only: pinning host memory is not a capturable operation, and a captured graph's launches
+            #  are replayed without passing through here -- its workspace is watched by workspace_status() alone)
+            box = torch.zeros(4, dtype=torch.int32).pin_memory()
+            _MAILBOX[key] = (box, box.numpy())
         if capturing:
             _WS_EAGER[key] = False                    # ... until a counters hand-out has recorded the memset
             _CAPTURE_KEYS.append(key)

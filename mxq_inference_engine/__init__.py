@@ -51,8 +51,8 @@ def gemv_forward_cuda(in_feats, kernel, scaling_factors, zeros, group_size):
 def gemm_forward_cuda(in_feats, kernel, scaling_factors, zeros, split_k_iters):
     """W4A16 group-wise GEMM on the reference's operands (gemm_cuda.h:3-4): in_feats f16 [M, IC], kernel i32 [IC, OC/8],
     scaling_factors f16 [IC/G, OC], zeros i32 [IC/G, OC/8].  Returns f16 [M, OC].  The launcher's rejections
-    (gemm_cuda_gen.cu:447-454: std::invalid_argument -> ValueError) are raised with its messages; like the launcher,
-    ``split_k_iters`` slices the K loop into that many partial outputs which are summed afterwards (:436, :477)."""
+    (gemm_cuda_gen.cu:447-454: std::invalid_argument -> ValueError) are raised with its messages.  ``split_k_iters`` (the
+    launcher's K-slicing schedule, :436, :477) is validated and otherwise unused: the kernel (csrc/gemm8a.hip) schedules K itself."""
     _chk(in_feats, "in_feats", torch.float16); _chk(kernel, "kernel", torch.int32)
     _chk(scaling_factors, "scaling_factors", torch.float16); _chk(zeros, "zeros", torch.int32)
     if in_feats.dim() != 2 or kernel.dim() != 2 or scaling_factors.dim() != 2 or zeros.dim() != 2:
@@ -76,19 +76,22 @@ def gemm_forward_cuda(in_feats, kernel, scaling_factors, zeros, split_k_iters):
         # (a deliberate deviation, INTEGRATION.md: the reference's K loop is 32 deep -- gemm_cuda_gen.cu `k_0_0 * 32` -- so it
         #  accepts IC % 64 == 32; this kernel's K-step is one 64-wide chunk)
         raise ValueError(f"IC must be a multiple of 64 (this kernel's K-step), got {IC}")
-    S = int(split_k_iters)
-    if S < 1:
+    if int(split_k_iters) < 1:
         raise ValueError("split_k_iters must be >= 1")
-    S = min(S, IC // 64)
-    out = torch.empty((S, M, OC) if S > 1 else (M, OC), dtype=torch.float32 if S > 1 else in_feats.dtype, device=in_feats.device)
+    # split_k_iters is the reference launcher's SCHEDULE (K slices as separate partial outputs, summed by `.sum(0)`,
+    # gemm_cuda_gen.cu:436, :477), not part of the operator: the kernel here schedules K itself (K slices + combine launch for
+    # few tokens, a stream-K tail beyond) and the result does not depend on the argument.
+    out = torch.empty((M, OC), dtype=in_feats.dtype, device=in_feats.device)
     if M == 0:
-        return torch.empty((0, OC), dtype=in_feats.dtype, device=in_feats.device)
+        return out
+    from mxq_amd import packing
     lib = _lib.load()
     with torch.cuda.device(in_feats.device):
+        st = torch.cuda.current_stream().cuda_stream
+        ws = packing.gemm_workspace(in_feats.device, stream=st)
         _lib.check(lib.mxq_gemm_awq_f16(in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
-                                        out.data_ptr(), M, IC, OC, group_size, S,
-                                        torch.cuda.current_stream().cuda_stream), "gemm_forward_cuda")
-    return out.sum(0).to(in_feats.dtype) if S > 1 else out
+                                        out.data_ptr(), M, IC, OC, group_size, ws.data_ptr(), ws.numel(), st), "gemm_forward_cuda")
+    return out
 
 
 def gemv_mxq_forward_cuda(in_feats, kernel, kernel_last, zeros_and_scales, scales_2nd, zeros_2nd, scales_4b,

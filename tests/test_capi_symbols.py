@@ -105,13 +105,14 @@ def test_argument_validation_rejects_before_any_launch(lib):
     assert lib.mxq_gemv_awq_f16(P, Q, P, P, P, 1, 4096, 4096, 128, None) == E_ALIGN   # codes are read 16 bytes at a time
     assert lib.mxq_gemv_awq_f16(P, P, P, P, P, 1, 4104, 4096, 8, None) == E_SHAPE     # IC % 32 (rows of whole 16-B units)
     # the reference GEMM's operand format: the launcher's rejections (gemm_cuda_gen.cu:447-454) + this kernel's K-step
-    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4096, 4000, 128, 1, None) == E_SHAPE     # OC % 64
-    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4096, 4096, 48, 1, None) == E_SHAPE      # group size % 32
-    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4096, 4160, 128, 1, None) == E_SHAPE     # OC % group size
-    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4128, 4096, 32, 1, None) == E_SHAPE      # IC % 64
-    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4096, 4096, 128, 65, None) == E_SHAPE    # more slices than K-steps
-    assert lib.mxq_gemm_awq_f16(P, P, None, P, P, 16, 4096, 4096, 128, 1, None) == E_NULL
-    assert lib.mxq_gemm_awq_f16(Q, P, P, P, P, 16, 4096, 4096, 128, 1, None) == E_ALIGN
+    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4096, 4000, 128, None, 0, None) == E_SHAPE     # OC % 64
+    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4096, 4096, 48, None, 0, None) == E_SHAPE      # group size % 32
+    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4096, 4160, 128, None, 0, None) == E_SHAPE     # OC % group size
+    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4128, 4096, 32, None, 0, None) == E_SHAPE      # IC % 64
+    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4096, 4096, 128, P, 4096, None) == E_SHAPE     # a workspace without its counter head
+    assert lib.mxq_gemm_awq_f16(P, P, P, P, P, 16, 4096, 4096, 128, Q, 1 << 20, None) == E_ALIGN  # workspace alignment
+    assert lib.mxq_gemm_awq_f16(P, P, None, P, P, 16, 4096, 4096, 128, None, 0, None) == E_NULL
+    assert lib.mxq_gemm_awq_f16(Q, P, P, P, P, 16, 4096, 4096, 128, None, 0, None) == E_ALIGN
     assert not hasattr(lib, "mxq_prefetch")                                           # round-2 experiment: a record, not ABI
     assert lib.mxq_gemv_proto_f16(P, P, P, P, P, P, P, P, P, 1, 2048, 4096, 16, None) == E_SHAPE   # IC must be 4096
     assert lib.mxq_gemm_workspace_bytes() == 64 * 1024 + 256 * 2 * 256 * 128 * 4 or lib.mxq_gemm_workspace_bytes() > 64 * 1024

@@ -427,7 +427,7 @@ def test_gemm_stream_k_tail(dev, M, N, K, sk):
     y = packing.linear(xd, p, path=sk)
     _check_gemm(y.cpu().numpy(), O.linear_ref(x.numpy(), w16), f"{sk} {M}x{N}x{K}")
     ws = packing.gemm_workspace(xd.device)
-    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
+    assert int(ws[:65504].view(torch.int32).abs().sum().item()) == 0 and int(ws[65520:65536].view(torch.int32).abs().sum().item()) == 0
     for _ in range(3):
         assert torch.equal(packing.linear(xd, p, path=sk), y)
     y5 = packing.linear(xd, p, path="gemm1")
@@ -439,7 +439,7 @@ def test_gemm_stream_k_tail(dev, M, N, K, sk):
     if sk == "gemm8h_split":      # the 128-token build of the same kernel, splitting only where it pays
         yh = packing.linear(xd, p, path="gemm8h")
         assert ((y.float() - yh.float()).abs().max() / y5.float().abs().max()).item() <= 1e-3
-        assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
+        assert int(ws[:65504].view(torch.int32).abs().sum().item()) == 0 and int(ws[65520:65536].view(torch.int32).abs().sum().item()) == 0
 
 
 @pytest.mark.parametrize("M,N,K", [(640, 11008, 4096),     # 258 tiles: a 2-tile tail on 256 CUs (Llama gate/up at 640-768 tokens)
@@ -465,7 +465,7 @@ def test_gemm_small_tail_stream_k_through_the_dispatch(dev, M, N, K):
             worst = max(worst, ((y[:, n0:n0 + 8192].float() - r).abs().max() / r.abs().max()).item())
         assert worst <= REL_TOL, (path, worst)
         assert torch.equal(packing.linear(x, p, path=path), y), path
-        assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0, path
+        assert int(ws[:65504].view(torch.int32).abs().sum().item()) == 0 and int(ws[65520:65536].view(torch.int32).abs().sum().item()) == 0, path
     # the split changes the summation order of the tail tiles only: whole-tile launch within rounding
     yw = packing.linear(x, p, path="whole")
     assert ((y.float() - yw.float()).abs().max() / yw.float().abs().max()).item() <= REL_TOL
@@ -492,7 +492,7 @@ def test_stream_k_partition_fuzz(dev, sk):
         assert err <= REL_TOL, (M, N, K, err)
         assert torch.equal(packing.linear(x, p, path=sk).float(), y), (M, N, K)
     ws = packing.gemm_workspace(torch.device(dev))
-    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
+    assert int(ws[:65504].view(torch.int32).abs().sum().item()) == 0 and int(ws[65520:65536].view(torch.int32).abs().sum().item()) == 0
 
 
 @pytest.mark.parametrize("M,N,K", [(192, 11008, 4096),     # 2 x 86 = 172 tiles of 128 x 128: Llama gate/up, 129-256 tokens
@@ -535,7 +535,7 @@ def test_half_height_tile_through_the_dispatch(dev, M, N, K, layout):
     r = x.float() @ wd.float().t()
     assert ((y.float() - r).abs().max() / r.abs().max()).item() <= REL_TOL
     assert torch.equal(packing.linear_layout(x, p, path="auto"), y)
-    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0
+    assert int(ws[:65504].view(torch.int32).abs().sum().item()) == 0 and int(ws[65520:65536].view(torch.int32).abs().sum().item()) == 0
     tiles = -(-M // 128) * -(-N // 128)
     if layout == "mixed" and M <= 64:
         if 65 <= -(-N // 128) <= 176 and M > 20:
@@ -623,14 +623,17 @@ def test_workspace_free_dispatch_every_layout(dev, M):
     assert lib.mxq_linear_workspace_need(M, N, K, 0, 1) <= lib.mxq_gemm_workspace_bytes()
 
 
+@pytest.mark.parametrize("how", ["poll", "next_call"])
 @pytest.mark.parametrize("M,N,K,build", [(512, 1024, 8192, "gemm8"),     # owner protocol (units straddle two tiles)
                                           (256, 2048, 4096, "gemm8"),     # 16 contributors per tile: all-contributors reduction
                                           (384, 4096, 4096, "gemm8h")])   # the 128-token build
-def test_stream_k_wait_expiry_is_visible(dev, M, N, K, build):
+def test_stream_k_wait_expiry_is_visible(dev, M, N, K, build, how):
     """A stream-K wait that gives up must not pass for a result.  Fault injection through the
-    PROFILING library (the one test that loads it: `mxq_prof_<build>_skwithhold_f16` never counts unit 0's parked pieces and
-    gives up after 4096 polls): the launch ends, the workspace's status words are set, the starved tiles are NaN,
-    `packing.workspace_status` raises and re-zeroes the head, and the next product launch on that workspace is correct."""
+    PROFILING library (`mxq_prof_<build>_skwithhold_f16` never counts unit 0's parked pieces and gives up after 4096 polls):
+    the launch ends, the workspace's status words are set, the starved tiles are NaN.  "poll": `packing.workspace_status`
+    raises and re-zeroes the head.  "next_call" (round 6): NOBODY polls -- the kernel has also written its
+    status into the workspace's pinned host mailbox, and the next product call on that workspace raises by itself.  Either
+    way the launch after that is correct."""
     import ctypes
     import os
     from mxq_amd import _lib, packing
@@ -644,7 +647,8 @@ def test_stream_k_wait_expiry_is_visible(dev, M, N, K, build):
     p, w16, g = _packed_case(dev, N, K, M + N + K + 1)
     x = torch.randn(M, K, generator=g).half()
     xd = x.to(dev)
-    good = packing.linear(xd, p, path="gemm9" if build == "gemm8" else "gemm8h_split")
+    path = "gemm9" if build == "gemm8" else "gemm8h_split"
+    good = packing.linear(xd, p, path=path)
     packing.workspace_status(xd.device)                         # nothing flagged by a healthy launch
     ws = packing.gemm_workspace(xd.device)
     y = torch.zeros(M, N, dtype=torch.float16, device=dev)
@@ -660,11 +664,68 @@ def test_stream_k_wait_expiry_is_visible(dev, M, N, K, build):
     ok = ~bad
     assert torch.equal(y[ok], good[ok]) or ((y[ok].float() - good[ok].float()).abs().max() / good.float().abs().max()).item() <= 1e-3
     with pytest.raises(RuntimeError, match="stream-K wait expired"):
-        packing.workspace_status(xd.device)
-    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0          # head re-zeroed by the check
-    again = packing.linear(xd, p, path="gemm9" if build == "gemm8" else "gemm8h_split")
+        if how == "poll":
+            packing.workspace_status(xd.device)
+        else:
+            packing.linear(xd, p, path=path)                    # the product's own next call: no status query anywhere
+    assert int(ws[:65504].view(torch.int32).abs().sum().item()) == 0          # head re-zeroed (its last bytes: mailbox address, status)
+    assert int(ws[65520:65536].view(torch.int32).abs().sum().item()) == 0
+    again = packing.linear(xd, p, path=path)
     assert torch.equal(again, good)
     packing.workspace_status(xd.device)
+
+
+def test_stream_k_launch_beside_an_lds_heavy_kernel(dev):
+    """a stream-K launch whose workgroups CANNOT all be resident at once.  Workgroups of an unrelated
+    kernel (profiling library: `mxq_prof_occupy`, 100 / 20 KB of LDS each, 3 ms, every wave leaves on time) sit on some or on
+    all CUs on a second stream while a gate/up-shaped launch (2048 x 11008 x 4096: 176 tail tiles split over all 256
+    workgroups, 144 KB of LDS each) starts: part of its workgroups are dispatched only when others -- or the occupier -- leave,
+    and owners wait for parked pieces meanwhile.  The result must be the undisturbed launch's bit for bit, the status 0.
+    (Workgroups are dispatched in index order and an owner waits only for lower-numbered units: the protocol needs the
+    launch's workgroups to be dispatched EVENTUALLY, not all at once; the all-contributors reduction of the second shape waits
+    in both directions and relies on the foreign kernel ending -- every wait is bounded either way.)"""
+    import ctypes
+    import os
+    import time
+    from mxq_amd import _lib, packing
+    prof = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmxq_hip_prof.so")
+    if not os.path.exists(prof):
+        pytest.skip("libmxq_hip_prof.so not built (make -C mxq_amd/csrc prof)")
+    plib = ctypes.CDLL(prof)
+    plib.mxq_prof_occupy.restype = ctypes.c_int
+    plib.mxq_prof_occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
+    sink = torch.zeros(1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # gate/up at 2048 tokens: the owner protocol (an owner waits only for LOWER-numbered units, which are dispatched first);
+    # 256 tokens x 2048 channels: 16 contributors per tile, the all-contributors reduction (any contributor may wait for any other)
+    for M, N, K in ((2048, 11008, 4096), (256, 2048, 4096)):
+        g = torch.Generator(device=dev).manual_seed(11)
+        p = packing.quantize_pack((torch.randn(N, K, generator=g, device=dev) * 0.02).half())
+        x = torch.randn(M, K, generator=g, device=dev).half()
+        whole = packing.linear(x, p, path="whole")
+        path = "auto" if M == 2048 else "gemm9"                 # the product entry (stream-K tail at this shape) / the tail always split
+        calm = packing.linear(x, p, path=path)
+        e0.record(); packing.linear(x, p, path=path); e1.record()
+        torch.cuda.synchronize()
+        calm_ms = e0.elapsed_time(e1)
+        packing.workspace_status(dev)
+        # 64 CUs taken (the launch's last 64 workgroups start when the first ones leave: about twice the calm time) / every CU
+        # taken (nothing starts before the occupier leaves) / LDS left on every CU but not enough for a 144-KB workgroup
+        for lds_kb, grid, held in ((100, 64, 1.4), (100, 256, 5.0), (20, 1024, 5.0)):
+            assert plib.mxq_prof_occupy(grid, lds_kb * 1024, 3000, sink.data_ptr(), side.cuda_stream) == 0
+            time.sleep(0.0005)                                  # the occupier is on the chip before the GEMM is launched
+            e0.record()
+            y = packing.linear(x, p, path=path)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            assert torch.equal(y, calm), (M, lds_kb, grid)
+            assert ((y.float() - whole.float()).abs().max() / whole.float().abs().max()).item() <= REL_TOL
+            packing.workspace_status(dev)                       # status 0: no wait gave up
+            if M == 2048:
+                assert ms > held * calm_ms, (f"the occupier ({grid} x {lds_kb} KB) did not hold the launch back ({ms:.3f} vs {calm_ms:.3f} ms): "
+                                             "the test proves nothing")
 
 
 def test_stream_k_gemm_in_graphs_and_on_two_streams(dev):

@@ -158,10 +158,14 @@ def _free_port():
 
 def _rehearse(world, extra_env=None, timeout=240):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", **(extra_env or {}))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "tools", "pipeline_rehearsal.py"), "--steps", "2"]
     t0 = time.time()
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    for attempt in range(2):      # (a job in which no rank ever logged a line -- the launcher's own rendezvous failed, e.g. the port
+        #                            picked a moment ago was taken -- is started once more on another port)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "tools", "pipeline_rehearsal.py"), "--steps", "2"]
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+        if r.returncode == 0 or "[rank " in r.stderr:
+            break
     return r, time.time() - t0
 
 
