@@ -611,12 +611,19 @@ int mxq_gemm_awq_f16(const void* x, const void* kernel, const void* scales, cons
     if (!aligned16(x) || !aligned16(scales) || !aligned16(y) || ((uintptr_t)kernel & 3) || ((uintptr_t)zeros & 3)) return MXQ_E_ALIGN;
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
     if (workspace && workspace_bytes < 65536) return MXQ_E_SHAPE;
-    // Few tokens: 64-token tiles, each tile's K range cut so that tiles x slices fill the chip, partial tiles summed by a combine
-    // launch (needs the workspace; without one: whole tiles).  Beyond: 256-token tiles, persistent, stream-K tail.
-    if (M <= 192)
-        return mxq_launch_gemm8aq_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, workspace, workspace_bytes,
-                                      workspace ? -1 : 0, (hipStream_t)stream);
-    return mxq_launch_gemm8a_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, workspace, workspace_bytes, 0, (hipStream_t)stream);
+    // The fused kernel's dispatch by tile count (gemm8h_mode / gemm8q_mode above), on this operand format's builds: up to 64 tokens
+    // 64-token tiles, then 128-token tiles while there are at most 176 of them (<= 1024 tokens) -- <= 64 tiles: every tile's K range cut so that tiles x slices fill the
+    // chip, partial tiles summed by a combine launch; 65 .. 176 tiles: one launch, stream-K over the otherwise idle CUs (both need
+    // the workspace) -- beyond that 256-token tiles, persistent, stream-K tail.
+    hipStream_t st = (hipStream_t)stream;
+    const int tn = (OC + 127) / 128;
+    if (M <= 64 && workspace && workspace_bytes >= mxq_gemm8aq_workspace_bytes() && tn <= 176)
+        return mxq_launch_gemm8aq_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, workspace, workspace_bytes, tn <= 64 ? -1 : -2, st);
+    if (M <= 64 && !workspace) return mxq_launch_gemm8aq_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, nullptr, 0, 0, st);
+    const int t128 = ((M + 127) / 128) * tn;
+    if (M <= 1024 && workspace && workspace_bytes >= mxq_gemm8ah_workspace_bytes() && t128 <= 176)
+        return mxq_launch_gemm8ah_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, workspace, workspace_bytes, t128 <= 64 ? -1 : -2, st);
+    return mxq_launch_gemm8a_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, workspace, workspace_bytes, 0, st);
 }
 
 int mxq_gemv_proto_f16(const void* x, const void* weight, const void* weight_last, const void* zeros_and_scales,

@@ -120,15 +120,16 @@ constexpr int OFF_A = 0;
 constexpr int OFF_W = OFF_A + A_SLOTS * A_STAGE;
 // hoisted-dequant mode: a 3-slot ring of fp16 weight tiles in the place of the W16 double buffer
 constexpr int OFF_WD = OFF_W, WD_SLOTS = 3;
-#if defined(MXQ_G8_AWQ) && MXQ_G8_BM == 256
-// AWQ layout, 256-token build: the K-major code words reach the dequant waves through LDS -- one 1-KiB LDS-DMA per dequant wave
+#if defined(MXQ_G8_AWQ)
+// AWQ layout: the K-major code words reach the dequant waves through LDS -- one 1-KiB LDS-DMA per dequant wave
 // and K-step brings the step's 64 rows x 64 bytes in whole row segments, the threads then read their 8 words (k = 8 ko ..
 // 8 ko + 7 of one channel octet) with ds_read_b32.  (The same words fetched straight into registers, 8 row-strided dword
 // loads per thread and K-step: 91 us at 2048 x 4096^2 against 65 with the loads switched off -- each wave instruction
-// touched 8 rows x 16 bytes.)  A ring of one group (DEQ_R chunks) of 4-KiB slots behind the weight-tile buffers.
+// touched 8 rows x 16 bytes.)  A ring of three 4-KiB slots behind the weight-tile buffers: one group of DEQ_R = 3 chunks in
+// the 256-token build; chunk q in slot q % 3, fetched two steps ahead, in the small-tile builds (DEQ_R = 1).
 #define MXQ_AWQ_RAW 1
 constexpr int OFF_RAW = OFF_WD + WD_SLOTS * W_STAGE, RAW_SLOT = 4096;
-constexpr int SMEM_BYTES = OFF_RAW + (MXQ_G8_BM == 256 ? 3 : 1) * RAW_SLOT;
+constexpr int SMEM_BYTES = OFF_RAW + 3 * RAW_SLOT;
 #else
 constexpr int SMEM_BYTES = OFF_WD + WD_SLOTS * W_STAGE;
 #endif
@@ -155,8 +156,8 @@ struct AwqU {
     uint32_t gmul, row_bytes;                  // row_bytes = N / 2: one k row of code words = one group row of zeros
     int last_kt;                               // K / 64 - 1
 };
-#define G8_AWQU_PARAM , const AwqU& au
-#define G8_AWQU_ARG , au
+#define G8_AWQU_PARAM , const AwqU& au, int& raw_slot
+#define G8_AWQU_ARG , au, raw_slot
 #else
 #define G8_AWQ_PARAM
 #define G8_AWQ_ARG
@@ -1222,6 +1223,73 @@ __device__ __forceinline__ void awq_segment_raw(Deq& c, const Deq& nxt, bool pre
     }
     __builtin_amdgcn_s_barrier();              // step NT - 1
 }
+// ... and for the small-tile builds (one chunk per K-step, no bursts; 8 dequant waves of which the first four carry the DMAs):
+// chunk q lives in ring slot q % 3 and is fetched TWO steps before it is converted -- its DMA goes out right after the barrier
+// that follows the conversion of chunk q - 3 + 2 ... i.e. at the top of iteration q - 2 (slot last read by iteration q - 3),
+// and every wave waits for its own part of chunk q + 1 (vmcnt: this iteration's four operations may stay in flight) in front
+// of the barrier of iteration q.  The group's scale / zero words come one step ahead, straight into registers.
+template <int ABL>
+__device__ __forceinline__ void awq_segment_raw1(Deq& c, const Deq& nxt, bool pre, PkA (&S)[1], const AwqU& au, int& raw_slot) {
+    const int NT = c.NT;
+    u32x4 res[DEQ_NRES];
+    char* raw = c.smem + OFF_RAW;
+    PkA nx = S[0];                             // (pre: the previous segment's last iteration loaded this segment's chunk 0 into S[0])
+    auto kbase_of = [&](int q, bool& over) {   // first k row of chunk q of this segment / of chunk q - NT of nxt; clamped to the tensor
+        over = q >= NT;
+        int kt = __builtin_amdgcn_readfirstlane((int)(over ? nxt.k0 : c.k0) + (over ? q - NT : q));
+        kt = kt < au.last_kt ? kt : au.last_kt;
+        return (uint32_t)kt * BK;
+    };
+    auto issue_zs = [&](int q, PkA& k) {
+        bool over;
+        const uint32_t kbase = kbase_of(q, over);
+        const uint32_t zo = over ? nxt.zoff : c.zoff, sof = over ? nxt.soff : c.soff;
+        const uint32_t g = __umulhi(kbase + 8u * (uint32_t)c.ko, au.gmul);
+        k.z = __builtin_amdgcn_raw_buffer_load_b32(au.rs_z, zo + g * au.row_bytes, 0, 0);
+        if constexpr (DEQ_NRES == 2) {
+            k.s[0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(au.rs_s, sof + g * (4u * au.row_bytes), 0, 0);
+            k.s[1] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(au.rs_s, sof + g * (4u * au.row_bytes) + 4u, 0, 0);
+        } else {
+            k.s[0] = __builtin_amdgcn_raw_buffer_load_b32(au.rs_s, sof + g * (4u * au.row_bytes), 0, 0);
+            k.s[1] = __builtin_amdgcn_raw_buffer_load_b32(au.rs_s, sof + g * (4u * au.row_bytes) + 4u, 0, 0);
+        }
+    };
+    auto issue_dma = [&](int q, int slot) {    // (every wave issues one operation: the waves beyond the fourth fetch nothing)
+        bool over;
+        const uint32_t kbase = kbase_of(q, over);
+        const uint32_t rv = over ? nxt.raw_voff : c.raw_voff;
+        if (c.d < 4) bufdma16(au.rs_q, rv, kbase * au.row_bytes, raw + slot * RAW_SLOT + c.d * 1024);
+    };
+    // slot of the chunk being converted; it runs on from segment to segment (the previous segment's last two iterations have
+    // fetched this segment's chunks 0 and 1 into the slots that follow its own)
+    int slot = raw_slot;
+    if (!pre) {
+        issue_zs(0, nx);
+        issue_dma(0, slot);
+        issue_dma(1, slot == 2 ? 0 : slot + 1);
+    }
+    // in flight at most: z/s(0), DMA(0), DMA(1) in this order (pre: z/s(0), DMA(1)) -- chunk 0's words have landed once at most
+    // one operation is outstanding
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // prologue barrier 1
+    for (int q = 0; q < NT; ++q) {
+        PkA cur = nx;
+        issue_zs(q + 1, nx);                   // 3 operations
+        issue_dma(q + 2, slot == 0 ? 2 : slot - 1);   // slot (q + 2) % 3
+        const char* w = raw + slot * RAW_SLOT + c.raw_rd;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cur.q[j] = *(const uint32_t*)(w + j * 512);
+        convert_pk<LAYOUT_AWQ, 0, false>(c, cur, res);
+        store_pk<0, LAYOUT_AWQ>(c, q, res);
+        // this iteration's 4 operations may fly on; everything older -- chunk q + 1's words among it -- has landed
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // q = 0: prologue barrier 2; q >= 1: the barrier of step q - 1
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    S[0] = nx;                                 // scale / zero words of the next segment's chunk 0
+    raw_slot = slot;
+    __builtin_amdgcn_s_barrier();              // step NT - 1
+}
 #endif
 
 // the column half a dequant wave works on is wave-uniform but not a constant: dispatch once, outside the loops
@@ -1234,7 +1302,8 @@ __device__ __forceinline__ void deq_segment(Deq& c, const Deq& nxt, int wave, in
                                             int N, int n0, bool pre, typename PkOf<LAYOUT>::type (&S)[DEQ_R] G8_AWQU_PARAM) {
     if constexpr (LAYOUT == LAYOUT_AWQ) {      // (which channels a thread converts is a per-lane selector, not a code path)
 #ifdef MXQ_AWQ_RAW
-        awq_segment_raw<ABL, DEQ_R>(c, nxt, pre, S, au);
+        if constexpr (DEQ_R > 1) awq_segment_raw<ABL, DEQ_R>(c, nxt, pre, S, au);
+        else awq_segment_raw1<ABL>(c, nxt, pre, S, au, raw_slot);
 #else
         deq_segment_h<ABL, LAYOUT, 0, DEQ_R>(c, nxt, rowmeta, N, n0, pre, S G8_AWQU_ARG);
 #endif
@@ -1497,6 +1566,7 @@ __global__ __launch_bounds__(THREADS) void G8_KERNEL(const uint16_t* __restrict_
 #ifdef MXQ_G8_AWQ
         const AwqU au = {make_rsrc(qweight, (uint32_t)K * (uint32_t)(N >> 1)), make_rsrc(awq.scales, (uint32_t)awq.groups * (uint32_t)N * 2u),
                          make_rsrc(awq.zeros, (uint32_t)awq.groups * (uint32_t)(N >> 1)), awq.gmul, (uint32_t)N >> 1, K / BK - 1};
+        int raw_slot = 0;
 #endif
         bool pre = false;                  // a segment's last burst loads the next segment's first group
         auto piece_deq = [&](int j, Deq& d, int& n0) {
@@ -1679,7 +1749,8 @@ static int launch8_slices(const void* x, const void* qweight, const void* rowmet
 #ifdef MXQ_G8_AWQ
 // gemm_forward_cuda's operands (gemm_cuda.h:3-4): x fp16 [M, IC], kernel int32 [IC, OC / 8], scales fp16 [IC / G, OC], zeros int32
 // [IC / G, OC / 8] -> y fp16 [M, OC].  slices = 0: whole tiles + stream-K tail (workspace: counter head + partial slots, nullable);
-// slices > 0 (or < 0: one workgroup per CU): every tile's K range cut that many ways + combine launch.
+// slices > 0 (or -1: one workgroup per CU): every tile's K range cut that many ways + combine launch; -2: stream-K with the
+// tail always split (launches of few tiles).
 size_t G8_SYM(, _workspace_bytes)() { return CNT_BYTES + (size_t)(cu_count() / 8 * 8) * 2 * BM * BN * sizeof(float); }
 int G8_SYM(launch_, _f16)(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
                          int G, void* workspace, size_t ws_bytes, int slices, hipStream_t stream) {
@@ -1691,6 +1762,8 @@ int G8_SYM(launch_, _f16)(const void* x, const void* kernel, const void* scales,
     awq.zeros = (const uint32_t*)zeros;
     awq.gmul = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)G) + 1u;
     awq.groups = IC / G;
+    if (slices == -2)    // stream-K, the tail always split
+        return launch8<0, LAYOUT_AWQ>(x, kernel, nullptr, y, M, OC, IC, workspace, ws_bytes, true, stream, awq);
     if (slices != 0)
         return launch8_slices<LAYOUT_AWQ>(x, kernel, nullptr, y, M, OC, IC, workspace, ws_bytes, slices, stream, awq);
     return launch8<0, LAYOUT_AWQ>(x, kernel, nullptr, y, M, OC, IC, workspace, ws_bytes, false, stream, awq);

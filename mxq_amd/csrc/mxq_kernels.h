@@ -154,11 +154,15 @@ int mxq_launch_actquant_seg(const void* x, void* out, void* range_ws, int64_t n_
 int mxq_launch_gemv_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y,
                             int B, int IC, int OC, int group_size, hipStream_t stream);
 // the reference GEMM's operand format on the fused kernel's skeleton (gemm8a.hip: 256-token tile; gemm8aq.hip: 64-token tile).
-// slices 0: whole tiles + stream-K tail; > 0: that many K slices per tile + combine launch; < 0: as many as fill the chip
+// (gemm8ah.hip: 128-token tile).  slices 0: whole tiles + stream-K tail where it pays; > 0: that many K slices per tile + combine
+// launch; -1: as many as fill the chip; -2: stream-K, the tail always split
 int mxq_launch_gemm8a_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
                           int G, void* workspace, size_t ws_bytes, int slices, hipStream_t stream);
 int mxq_launch_gemm8aq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
                            int G, void* workspace, size_t ws_bytes, int slices, hipStream_t stream);
+int mxq_launch_gemm8ah_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
+                           int G, void* workspace, size_t ws_bytes, int slices, hipStream_t stream);
+size_t mxq_gemm8ah_workspace_bytes();
 size_t mxq_gemm8a_workspace_bytes();
 size_t mxq_gemm8aq_workspace_bytes();
 int mxq_launch_gemv_proto_f16(const void* x, const void* weight, const void* weight_last,

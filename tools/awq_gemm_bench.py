@@ -33,7 +33,7 @@ for IC, OC in ((4096, 4096), (4096, 11008), (11008, 4096)):
     zeros = torch.randint(-2**31, 2**31 - 1, (IC // G, OC // 8), dtype=torch.int32, device=dev)
     scales = (torch.rand(IC // G, OC, device=dev) * 0.004 + 0.001).half()
     wd = torch.randn(OC, IC, device=dev).half()
-    for M, S in ((16, 8), (128, 4), (2048, 1)):
+    for M, S in ((16, 8), (64, 8), (128, 4), (256, 2), (512, 1), (1024, 1), (2048, 1)):
         x = torch.randn(M, IC, device=dev).half()
         t = us(lambda: eng.gemm_forward_cuda(x, kern, scales, zeros, S))
         tt = us(lambda: torch.matmul(x, wd.t()))
