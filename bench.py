@@ -218,6 +218,32 @@ def _events_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def launch_floor(dev, launches=160, reps=5):
+    """Fixed cost of ONE dependent decode launch, in microseconds: a hipGraph of `launches` GEMV launches, each fed by the one
+    before it (RMSNorm prologue + residual epilogue as in the decode layer), on a weight of 4096 x 64 -- 147 KB, i.e. next to no
+    bytes.  What is left is what every launch of the token loop pays before and after its bytes: the gap to the previous
+    kernel, the first loads' round trip, activation staging, the final reduction and store.  A layer of 5 launches cannot be
+    shorter than 5 x this, whatever the HBM does."""
+    g = torch.Generator(device=dev).manual_seed(2)
+    p = packing.quantize_pack((torch.randn(LS.HIDDEN, 64, generator=g, device=dev) * 0.02).half())
+    norm_w = torch.ones(64, device=dev, dtype=torch.float16)
+    h0 = torch.randn(1, LS.HIDDEN, generator=g, device=dev).half()
+
+    def chain():
+        h = h0
+        for _ in range(launches):
+            h = packing.linear_fused(h[:, :64], p, 1, norm_w, residual=h)
+        return h
+    chain()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        chain()
+    gr.replay()
+    torch.cuda.synchronize()
+    return round(min(_events_ms(gr.replay, 3) for _ in range(reps)) * 1e3 / launches, 3)
+
+
 def decode_1gpu(dev, tokens=64, ctx=512):
     """Side figure, not `value`: BASELINE configs[2] on ONE GPU -- greedy decode, batch 1, all 32 layers, hipGraph token
     loop (mxq_amd/llama_decode.py), in both metadata modes.  Bytes = the packed weights a token streams (codes + group
@@ -225,15 +251,22 @@ def decode_1gpu(dev, tokens=64, ctx=512):
     algorithmic bytes per token.  The dominant kernels are the streaming GEMVs (csrc/gemv.hip).
     """
     from mxq_amd.llama_decode import decode_pipeline_figure
+    floor_us = launch_floor(dev)
     out = {"workload": f"BASELINE configs[2] on one GPU: Llama-2-7B W2/4A16 greedy decode, batch 1, {tokens} tokens from position 0 "
                        f"(KV cache of {ctx}), hipGraph token loop; bytes = packed weight bytes per token",
-           "peak_GBps": PEAK_HBM_GBPS}
+           "peak_GBps": PEAK_HBM_GBPS,
+           # the latency floor next to every `frac` below (VERDICT r5 next #4): a dependent launch that moves no bytes
+           "fixed_cost_us_per_launch": floor_us, "launches_per_token": 5 * LS.N_LAYERS + 4,
+           "latency_floor_ms_per_token": round(floor_us * (5 * LS.N_LAYERS + 4) / 1e3, 4)}
     for mode, compact in (("exact", False), ("compact", True)):
         fig = decode_pipeline_figure(LayerPipeline(0, 1), dev, tokens=tokens, ctx=ctx, compact=compact)
         out[mode] = {"tokens_per_s": fig["tokens_per_s"], "ms_per_token": fig["ms_per_token"],
                      "packed_weight_GB_per_token": fig["packed_weight_GB_per_token"],
                      "GBps": fig["weight_stream_GBps"], "frac": round(fig["weight_stream_GBps"] / PEAK_HBM_GBPS, 4),
                      "launches_per_layer": fig.get("launches_per_layer"), "us_per_layer": round(fig["ms_per_token"] * 1e3 / LS.N_LAYERS, 2),
+                     # bytes over the time that is NOT the launches' fixed cost: what the streaming itself achieves
+                     "GBps_beyond_the_latency_floor": round(fig["packed_weight_GB_per_token"] /
+                                                            max(1e-9, fig["ms_per_token"] - out["latency_floor_ms_per_token"]) * 1e3, 1),
                      "first_tokens": fig["first_tokens"]}
         if not compact:      # the same at a LONG context: 64 tokens from position 1920 of a 2048-row cache (split attention launch)
             fig = decode_pipeline_figure(LayerPipeline(0, 1), dev, tokens=tokens, ctx=2048, start=1920, compact=False)
