@@ -8,6 +8,8 @@
 
 #include "mxq_kernels.h"
 
+#include "mxq_gemv_common.h"   // wave_allsum / wave_allmax / quad_allsum: the shuffle butterflies as vector-ALU operations, bit-identical
+
 namespace {
 
 constexpr int HD = 128;        // head dim (Llama-2-7B)
@@ -129,8 +131,7 @@ __device__ __forceinline__ bool attn_one_workgroup(float* sm, int h, const uint1
                 }
             }
         }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
+        acc = quad_allsum(acc);
         if (part == 0) sc[j] = h2f(f2h(acc * scale));   // fp16 scores as baddbmm produces them
     }
     __syncthreads();
@@ -138,8 +139,7 @@ __device__ __forceinline__ bool attn_one_workgroup(float* sm, int h, const uint1
     // softmax over [0, pos]
     float mx = -INFINITY;
     for (int j = tid; j <= pos; j += ATT_THREADS) mx = fmaxf(mx, sc[j]);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = wave_allmax(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -149,8 +149,7 @@ __device__ __forceinline__ bool attn_one_workgroup(float* sm, int h, const uint1
         sc[j] = p;
         sum += p;
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum = wave_allsum(sum);
     __syncthreads();          // everyone has read red[] (max) before it is reused
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
@@ -284,8 +283,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(const ui
                 acc += q_s[part_ * 32 + v * 8 + 2 * e + 1] * h2f((uint16_t)(ws[e] >> 16));
             }
         }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
+        acc = quad_allsum(acc);
         return acc;
     };
     for (int j = j0 + kj; j < jc; j += 2 * (ATT_THREADS / 4)) {
@@ -308,16 +306,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(const ui
         float acc = 0.f;
 #pragma unroll
         for (int e = 0; e < 32; ++e) acc += q_s[part_ * 32 + e] * k_s[part_ * 32 + e];
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
+        acc = quad_allsum(acc);
         if (part_ == 0) sc[pos - j0] = h2f(f2h(acc * scale));
     }
     __syncthreads();
     const int nk = j1 - j0;
     float mx = -INFINITY;
     for (int j = tid; j < nk; j += ATT_THREADS) mx = fmaxf(mx, sc[j]);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = wave_allmax(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -327,8 +323,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(const ui
         sc[j] = p;
         sum += p;
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum = wave_allsum(sum);
     __syncthreads();
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
@@ -459,8 +454,7 @@ __global__ __launch_bounds__(LMH_THREADS) void lmhead_argmax_kernel(const uint16
 #pragma unroll
         for (int j = 0; j < 8; ++j) ss += (float)x[i][j] * (float)x[i][j];
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    ss = wave_allsum(ss);
     const float inv = rsqrtf(ss / (float)LMH_K + eps);      // every wave holds the whole row: no cross-wave step
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -486,8 +480,7 @@ __global__ __launch_bounds__(LMH_THREADS) void lmhead_argmax_kernel(const uint16
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc = __builtin_amdgcn_fdot2((h2){wv[i][2 * j], wv[i][2 * j + 1]}, (h2){x[i][2 * j], x[i][2 * j + 1]}, acc, false);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        acc = wave_allsum(acc);
         const float logit = (float)(_Float16)acc;           // F.linear's fp16 output
         if (row < V && (logit > best || (logit == best && row < besti))) { best = logit; besti = row; }   // (a NaN logit never wins)
     };

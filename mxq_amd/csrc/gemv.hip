@@ -189,8 +189,17 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
 
     // ---- stage the activations: code-dot order + per-group fp32 sums; idle threads write to their dummy slot
     float ss = 0.f;
-    auto stage_act = [&](int i, Act t) {
+    // wlive (wave-uniform): some thread of this wave has a group to stage.  A wave without one skips the staging ARITHMETIC (round 6:
+    // ~50-100 vector-ALU ops per call on every wave of the workgroup, in the launch's serial prologue; with K = 4096 and 512
+    // threads three quarters of it ran on clamped copies) but still consumes every loaded value -- it writes their raw bits to its
+    // dummy slots -- so that no load can be sunk into the conditional part behind the weight tiles' loads (a first version that
+    // skipped the whole call had its activation loads moved there by the compiler: a drain of both tiles before the staging,
+    // and the layer got slower although this part got faster).  Bit-identical.
+    auto stage_act = [&](int i, Act t, bool wlive) {
         const bool live = i < MB * NG;                  // i = m * NG + g: rows are K * 2 = NG * 32 bytes
+        float sum = 0.f;
+        uint4 o0 = __builtin_bit_cast(uint4, t.a0), o1 = __builtin_bit_cast(uint4, t.a1);
+        if (wlive) {
         if (MB > 1 && min(i, MB * NG - 1) / NG >= M) {  // rows beyond M are staged as zeros (select, not branch)
             const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
             t.a0 = zero;
@@ -215,8 +224,6 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
                 t.a1[j] = (_Float16)(g1 / (1.0f + __expf(-g1))) * t.b1[j];
             }
         }
-        float sum = 0.f;
-        uint4 o0, o1;
         if constexpr (PRO == 3) {                      // staged by the producer: a plain copy
             o0 = __builtin_bit_cast(uint4, t.a0);
             o1 = __builtin_bit_cast(uint4, t.a1);
@@ -225,18 +232,25 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
             o0 = stage8(__builtin_bit_cast(uint4, t.a0), sum);
             o1 = stage8(__builtin_bit_cast(uint4, t.a1), sum);
         }
+        } else {                                        // an idle wave: every loaded value still goes somewhere
+            if constexpr (PRO == 1 || PRO == 2) {
+                const uint4 b0 = __builtin_bit_cast(uint4, t.b0), b1 = __builtin_bit_cast(uint4, t.b1);
+                o0.x ^= b0.x ^ b0.y ^ b0.z ^ b0.w;
+                o1.x ^= b1.x ^ b1.y ^ b1.z ^ b1.w;
+            }
+            if constexpr (PRO == 3) sum = t.sum;
+        }
         char* dst = live ? smem + (size_t)i * 32 : dummy + lane * 32;
         float* sdst = live ? xsum + i : (float*)(dummy + 64 * 32) + lane;
         *(uint4*)dst = o0;
         *(uint4*)(dst + 16) = o1;
         *sdst = sum;
     };
-    stage_act(tid, act0);
-    stage_act(tid + GEMV_THREADS, act1);
-    for (int i = tid + 2 * GEMV_THREADS; i < MB * NG; i += GEMV_THREADS) stage_act(i, load_act(i));   // M > 1 / odd shapes
+    stage_act(tid, act0, wave * 64 < MB * NG);
+    stage_act(tid + GEMV_THREADS, act1, GEMV_THREADS + wave * 64 < MB * NG);
+    for (int i = tid + 2 * GEMV_THREADS; i < MB * NG; i += GEMV_THREADS) stage_act(i, load_act(i), true);   // M > 1 / odd shapes
     if constexpr (PRO == 1) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        ss = wave_allsum(ss);                           // (vector-ALU butterfly, bit-identical to the shuffles: mxq_gemv_common.h)
         if (lane == 0) wsum[wave] = ss;
     }
     __syncthreads();
@@ -253,8 +267,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void mxq_gemv_f16_kernel(const uint16
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             float a = 4.0f * (P[m] - Q[m]), b = R[m], c = X4[m];
-            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64); c += __shfl_xor(c, 16, 64);
-            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64); c += __shfl_xor(c, 32, 64);
+            a = swap16_sum(a); b = swap16_sum(b); c = swap16_sum(c);     // + lane ^ 16, then + lane ^ 32: no LDS round trips
+            a = swap32_sum(a); b = swap32_sum(b); c = swap32_sum(c);
             if (cs == 0) {
                 float* d = red + (((rbl * W + wave) * MB + m) * 16 + r) * 3;
                 d[0] = a; d[1] = b; d[2] = c;
