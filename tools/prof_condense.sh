@@ -32,6 +32,9 @@ if [ -d gpurun_out/${T}_midm_trace ]; then
       echo "# => HBM-side bytes per call: main (2 x 5888 + 8192) KiB + combine (2 x 4119 + 1027) KiB = 29.2 MB for 11.3 MB algorithmic = 2.6 x (mid-M kernel and 128 x 128 tile: 4.0 x)"
     fi; } > profiles/${P}_midm_pmc.txt
 fi
+if [ -d gpurun_out/${T}_awq_trace ]; then
+  python3 tools/prof_summary.py gpurun_out/${T}_awq_trace profiles/${P}_awq_trace.txt "tools/awq_gemm_bench.py (gemm_forward_cuda on the reference operand format: csrc/gemm8a / gemm8ah / gemm8aq + torch's fp16 GEMM beside it)" > /dev/null
+fi
 python3 - <<PY
 import json
 lines=[l for l in open('gpurun_out/${T}_config5_sweep.log') if l.startswith('{"config"')]

@@ -50,6 +50,9 @@ done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_hbm_FETCH -- python3 $R/tools/hbm_prof.py > /dev/null 2>> $OUT/${TAG}_pmc.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_hbm_WRITE -- python3 $R/tools/hbm_prof.py > /dev/null 2>> $OUT/${TAG}_pmc.err
 echo "hbm kernels done"
+# the reference GEMM's operand format on the fused kernel's skeleton (csrc/gemm8a.hip and its builds): kernel trace of tools/awq_gemm_bench.py
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_awq_trace -- python3 $R/tools/awq_gemm_bench.py > $OUT/${TAG}_awq_trace.txt 2>> $OUT/${TAG}_pmc.err
+echo "awq trace done"
 cd $R
 python3 tools/kernels_bench.py > $OUT/${TAG}_kernels_bench.txt 2>&1
 echo "kernels bench done"
