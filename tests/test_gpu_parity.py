@@ -1889,7 +1889,14 @@ def test_decode_gemv_launches_full_size_vs_oracle(dev):
 
 @pytest.mark.parametrize("M,IC,OC,G,S", [(16, 4096, 4096, 128, 8), (128, 4096, 4096, 128, 4), (2048, 4096, 4096, 64, 1),
                                          (16, 4096, 11008, 128, 8), (128, 4096, 11008, 32, 2), (2048, 4096, 11008, 128, 1),
-                                         (1, 256, 64, 32, 1), (130, 320, 192, 64, 3)])
+                                         (1, 256, 64, 32, 1), (130, 320, 192, 64, 3),
+                                         # round 6, one case per schedule of the rebuilt kernel (csrc/capi.hip mxq_gemm_awq_f16):
+                                         (2048, 11008, 4096, 128, 1),   # 256-token tiles, 172 K-steps (not a multiple of the burst of 3)
+                                         (1000, 4096, 11008, 128, 1),   # 256-token tiles, ragged token tile, stream-K tail (344 tiles)
+                                         (512, 4096, 4096, 128, 1),     # 128-token tiles, 128 of them: stream-K, the tail always split
+                                         (300, 11008, 4096, 64, 1),     # 128-token tiles, 96 of them, 172 K-steps, ragged tokens
+                                         (64, 4096, 11008, 128, 1),     # 64-token tiles, 86 of them: stream-K
+                                         (48, 11008, 4096, 32, 1)])     # 64-token tiles, 32 of them: K slices + combine launch
 def test_gemm_forward_cuda_reference_operands_vs_oracle(dev, M, IC, OC, G, S):
     """`gemm_forward_cuda(in_feats, kernel, scaling_factors, zeros, split_k_iters)` on the reference's
     operand format (gemm_cuda.h:3-4; K-major int32 words of 8 interleaved nibbles, group-G scales [IC/G, OC], packed
