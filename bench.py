@@ -453,8 +453,8 @@ def main():
     backend = os.environ.get("MXQ_BENCH_BACKEND", "nccl")
     local_rank = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     # N > 1: every phase has a deadline (a stuck rank prints where it is stuck and exits 86; the launcher names it), the whole
-    # run a hard one below the driver's 600 s, and the process group a 120-s timeout instead of torch's 10 minutes
-    dog = pipeline.Watchdog(rank, world, hard_deadline_s=float(os.environ.get("MXQ_BENCH_DEADLINE_S", 540))) if world > 1 else None
+    # run a hard one (450 s) below the driver's 600 s, and the process group a 120-s timeout instead of torch's 10 minutes
+    dog = pipeline.Watchdog(rank, world, hard_deadline_s=float(os.environ.get("MXQ_BENCH_DEADLINE_S", 450))) if world > 1 else None
 
     def phase(name, seconds):
         if dog is not None:
