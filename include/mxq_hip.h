@@ -346,8 +346,9 @@ int mxq_gemv_awq_f16(const void* x, const void* kernel, const void* scales, cons
  * the codes); weight = fp16(fp16(q - z) * s) as the reference computes it (gemm_cuda_gen.cu:134-141), fp32 accumulation;
  * y f16[M, OC].  Runs on the fused prefill kernel's skeleton with dequant waves for this operand format (csrc/gemm8a.hip,
  * gemm8aq.hip).  The reference launcher's split_k_iters is a SCHEDULE (K slices summed by the caller), not part of the
- * operator: this entry schedules K itself -- up to 192 tokens 64-token tiles whose K range is cut into slices + a combine
- * launch, beyond that 256-token tiles with a stream-K tail -- through `workspace` (mxq_gemm_workspace_bytes() bytes, 16-byte
+ * operator: this entry schedules K itself -- up to 32 tokens a streaming kernel (128 channels x one K slice per workgroup, the last
+ * arriver of a channel block sums the slices; csrc/skinny_awq.hip), then 64- / 128-token tiles by tile count (K slices + a combine
+ * launch, or stream-K), beyond that 256-token tiles with a stream-K tail -- through `workspace` (mxq_gemm_workspace_bytes() bytes, 16-byte
  * aligned, counter head zeroed as for mxq_linear_f16_ws; NULL: whole tiles only).  Deterministic.  MXQ_E_SHAPE for the
  * launcher's rejections (OC % 64, group_size % 32, OC % group_size) and for IC % 64, IC % group_size. */
 int mxq_gemm_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,

@@ -611,12 +611,17 @@ int mxq_gemm_awq_f16(const void* x, const void* kernel, const void* scales, cons
     if (!aligned16(x) || !aligned16(scales) || !aligned16(y) || ((uintptr_t)kernel & 3) || ((uintptr_t)zeros & 3)) return MXQ_E_ALIGN;
     if (workspace && !aligned16(workspace)) return MXQ_E_ALIGN;
     if (workspace && workspace_bytes < 65536) return MXQ_E_SHAPE;
-    // The fused kernel's dispatch by tile count (gemm8h_mode / gemm8q_mode above), on this operand format's builds: up to 64 tokens
+    // Up to 32 tokens: a streaming kernel (one workgroup per 128 channels x K slice, last arriver sums the slices).  Beyond -- and as
+    // its fallback -- the fused kernel's dispatch by tile count (gemm8h_mode / gemm8q_mode above) on this operand format's builds:
     // 64-token tiles, then 128-token tiles while there are at most 176 of them (<= 1024 tokens) -- <= 64 tiles: every tile's K range cut so that tiles x slices fill the
     // chip, partial tiles summed by a combine launch; 65 .. 176 tiles: one launch, stream-K over the otherwise idle CUs (both need
     // the workspace) -- beyond that 256-token tiles, persistent, stream-K tail.
     hipStream_t st = (hipStream_t)stream;
     const int tn = (OC + 127) / 128;
+    if (M <= 32) {     // few tokens: the streaming kernel (skinny_awq.hip), unless the K range does not fit its LDS unsliced
+        const int e = mxq_launch_skinny_awq_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, workspace, workspace_bytes, st);
+        if (e != MXQ_NOT_MY_SHAPE) return e;
+    }
     if (M <= 64 && workspace && workspace_bytes >= mxq_gemm8aq_workspace_bytes() && tn <= 176)
         return mxq_launch_gemm8aq_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, workspace, workspace_bytes, tn <= 64 ? -1 : -2, st);
     if (M <= 64 && !workspace) return mxq_launch_gemm8aq_f16(x, kernel, scales, zeros, y, M, IC, OC, group_size, nullptr, 0, 0, st);

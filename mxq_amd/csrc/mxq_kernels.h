@@ -163,6 +163,10 @@ int mxq_launch_gemm8aq_f16(const void* x, const void* kernel, const void* scales
 int mxq_launch_gemm8ah_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
                            int G, void* workspace, size_t ws_bytes, int slices, hipStream_t stream);
 size_t mxq_gemm8ah_workspace_bytes();
+// the same operand format for <= 32 tokens: a streaming kernel (skinny_awq.hip); workspace nullable (then one K slice per block);
+// MXQ_NOT_MY_SHAPE: the K range does not fit its LDS unsliced
+int mxq_launch_skinny_awq_f16(const void* x, const void* kernel, const void* scales, const void* zeros, void* y, int M, int IC, int OC,
+                              int G, void* workspace, size_t ws_bytes, hipStream_t stream);
 size_t mxq_gemm8a_workspace_bytes();
 size_t mxq_gemm8aq_workspace_bytes();
 int mxq_launch_gemv_proto_f16(const void* x, const void* weight, const void* weight_last,

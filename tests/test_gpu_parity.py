@@ -1896,7 +1896,11 @@ def test_decode_gemv_launches_full_size_vs_oracle(dev):
                                          (512, 4096, 4096, 128, 1),     # 128-token tiles, 128 of them: stream-K, the tail always split
                                          (300, 11008, 4096, 64, 1),     # 128-token tiles, 96 of them, 172 K-steps, ragged tokens
                                          (64, 4096, 11008, 128, 1),     # 64-token tiles, 86 of them: stream-K
-                                         (48, 11008, 4096, 32, 1)])     # 64-token tiles, 32 of them: K slices + combine launch
+                                         (48, 11008, 4096, 32, 1),      # 64-token tiles, 32 of them: K slices + combine launch
+                                         # <= 32 tokens: the streaming kernel (csrc/skinny_awq.hip)
+                                         (32, 4096, 4096, 64, 1),       # two token blocks, 8 K slices per channel block
+                                         (20, 11008, 4096, 128, 1),     # ragged tokens, 172 K-steps over 8 slices (the last one shorter)
+                                         (7, 320, 192, 32, 1)])         # half a channel block at the edge, 5 K-steps, G = 32
 def test_gemm_forward_cuda_reference_operands_vs_oracle(dev, M, IC, OC, G, S):
     """`gemm_forward_cuda(in_feats, kernel, scaling_factors, zeros, split_k_iters)` on the reference's
     operand format (gemm_cuda.h:3-4; K-major int32 words of 8 interleaved nibbles, group-G scales [IC/G, OC], packed
@@ -1913,6 +1917,26 @@ def test_gemm_forward_cuda_reference_operands_vs_oracle(dev, M, IC, OC, G, S):
                               torch.from_numpy(zw).to(dev), S)
     assert y.shape == (M, OC) and y.dtype == torch.float16
     _check_gemm(y.cpu().numpy(), O.gemm_awq_ref(x, kern, s, zw, G), f"awq gemm {M}x{IC}x{OC} G{G} S{S}")
+
+
+def test_gemm_awq_c_entry_without_a_workspace(dev):
+    """`mxq_gemm_awq_f16` with `workspace == NULL` (a direct C caller): nothing may split K across workgroups -- the streaming
+    kernel takes the call when the whole K range fits its LDS (IC = 1024), else the tile kernel runs on whole tiles (IC = 4096);
+    same results as with a workspace, to accumulation order."""
+    from mxq_amd import _lib, packing
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    st = torch.cuda.current_stream().cuda_stream
+    for M, IC, OC, G in ((16, 1024, 256, 64), (16, 4096, 256, 128), (100, 1024, 256, 64)):
+        q, z = rng.integers(0, 16, size=(IC, OC)), rng.integers(0, 16, size=(IC // G, OC))
+        s = (rng.random((IC // G, OC)) * 0.004 + 0.001).astype(np.float16)
+        x = rng.standard_normal((M, IC)).astype(np.float16)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        kern, zw, xd, sd = t(O.gemm_awq_pack(q)), t(O.gemm_awq_pack(z)), t(x), t(s)
+        y = torch.empty(M, OC, dtype=torch.float16, device=dev)
+        _lib.check(lib.mxq_gemm_awq_f16(xd.data_ptr(), kern.data_ptr(), sd.data_ptr(), zw.data_ptr(), y.data_ptr(), M, IC, OC, G,
+                                        None, 0, st), "mxq_gemm_awq_f16 without a workspace")
+        _check_gemm(y.cpu().numpy(), O.gemm_awq_ref(x, kern.cpu().numpy(), s, zw.cpu().numpy(), G), f"awq, no workspace {M}x{IC}x{OC}")
 
 
 def test_gemm_forward_cuda_integer_exact_and_rejections(dev):

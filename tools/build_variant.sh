@@ -12,7 +12,7 @@ make -j8 > /dev/null
 # fallen behind the Makefile's -amdgpu-kernarg-preload-count=16, biasing every A/B by ~0.24 us per launch against the variant)
 cxx=$(make -s print-CXXFLAGS-$unit)
 /opt/rocm/bin/hipcc $cxx -I. $flags -x hip -c "$R/$src" -o /tmp/variant_$name.o
-objs=""; for f in capi pack gemm gemm8 gemm8h gemm8q gemm8n dense256 midm gemv skinny decode_ops gemv_compat gemm8a gemm8ah gemm8aq fakequant actquant; do
+objs=""; for f in capi pack gemm gemm8 gemm8h gemm8q gemm8n dense256 midm gemv skinny decode_ops gemv_compat gemm8a gemm8ah gemm8aq skinny_awq fakequant actquant; do
   if [ "$f" = "$unit" ]; then objs="$objs /tmp/variant_$name.o"; else objs="$objs $f.o"; fi; done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o "$R/tools/_variants/lib_$name.so" 2>/dev/null
 echo "tools/_variants/lib_$name.so"
