@@ -618,6 +618,11 @@ def main():
                   f"{census['ranks_seen']} distinct_devices={census['distinct_devices']}: {census['ranks']}", file=sys.stderr, flush=True)
         raise SystemExit(3)
     decode_fig = None
+    if world > 1 and rank == 0:
+        # the headline of this run, on stderr, BEFORE the side figure: should the decode pipeline fail on hardware it has never
+        # seen, the record still holds what the timed region measured (stdout carries the one complete line at the end)
+        pipeline.rank_log("headline so far: " + json.dumps({"value_TFLOPs": round(value, 3), "n_gpus": world, "steps": args.steps,
+                                                            "ms_per_step": round(ms_per_step, 4), "per_rank": per_rank}), rank, world)
     if world > 1 and not args.no_decode_pipeline:
         phase("decode pipeline figure", 240)
         from mxq_amd.llama_decode import decode_pipeline_figure
