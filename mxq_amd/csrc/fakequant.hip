@@ -271,7 +271,14 @@ template <typename T>
 int launch_bwd(const void* gout, const void* w, void* gin, int64_t n, float lo, float hi, hipStream_t stream) {
     const int64_t nvec = n / T::VEC;
     int64_t blocks = (nvec + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;   // cap + grid-stride (guide section 6, G11)
+#ifndef MXQ_FQ_BWD_CAP
+#define MXQ_FQ_BWD_CAP (256 * 64)
+#endif
+    // cap + grid-stride.  Round 6: the cap was 2048 workgroups (8 per CU); a plain copy of the same bytes with the same 16-byte
+    // nt accesses runs at 4.6 TB/s from 2048 workgroups, 6.0-6.5 from 8192 and 6.7 from 16384 (tools/probes/copy_probe.hip,
+    // profiles/r06_copy_probe.txt): short-lived workgroups, each touching a few 4-KiB lines spread over the whole tensor, keep
+    // more HBM channels busy than few long-lived ones walking with a large stride
+    if (blocks > MXQ_FQ_BWD_CAP) blocks = MXQ_FQ_BWD_CAP;
     if (blocks < 1) blocks = 1;
     mxq_fakequant_bwd_kernel<T><<<(unsigned)blocks, 256, 0, stream>>>(gout, w, gin, nvec, lo, hi);
     return (int)hipGetLastError();
