@@ -68,6 +68,8 @@ def test_inference_engine_validation():
     x = torch.zeros(1, 4096, dtype=torch.float16)
     with pytest.raises(ValueError):
         eng.gemv_forward_cuda(x, x, x, x, 128)          # CPU tensors are rejected
+    with pytest.raises(ValueError):
+        eng.gemm_forward_cuda(x, x, x, x, 1)            # ... by every entry
     assert callable(eng.gemv_mxq_forward_cuda)
 
 
