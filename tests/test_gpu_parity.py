@@ -1917,6 +1917,13 @@ def test_gemm_forward_cuda_reference_operands_vs_oracle(dev, M, IC, OC, G, S):
                               torch.from_numpy(zw).to(dev), S)
     assert y.shape == (M, OC) and y.dtype == torch.float16
     _check_gemm(y.cpu().numpy(), O.gemm_awq_ref(x, kern, s, zw, G), f"awq gemm {M}x{IC}x{OC} G{G} S{S}")
+    # deterministic (every sum in a fixed order, whatever the K schedule -- slices, stream-K, last arriver), and independent of
+    # the launcher's split_k_iters argument, which this implementation only validates
+    y2 = eng.gemm_forward_cuda(torch.from_numpy(x).to(dev), torch.from_numpy(kern).to(dev), torch.from_numpy(s).to(dev),
+                               torch.from_numpy(zw).to(dev), S + 3)
+    assert torch.equal(y, y2)
+    from mxq_amd import packing
+    packing.workspace_status(dev)
 
 
 def test_gemm_awq_c_entry_without_a_workspace(dev):
