@@ -38,7 +38,8 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
-os.environ.setdefault("NCCL_DEBUG", "WARN")                 # an RCCL failure says why on stderr (rank-tagged by RCCL itself)
+# (NCCL_DEBUG is left alone: RCCL writes its log to STDOUT, which must stay the one JSON line; torch's own error text and the
+#  watchdog's stack dumps go to stderr)
 
 import torch  # noqa: E402
 
